@@ -1,0 +1,189 @@
+/*
+ * qmle_sv.h -- C ABI of libqmle_sv.so, the MI355X (gfx950) statevector engine
+ * that replaces the compute seam of cirKITers/qml-essentials' "jaqsi" simulator.
+ *
+ * The reference is 100 % Python/JAX and has no FFI of its own (SURVEY.md F2,
+ * 8-b).  The seam this ABI replaces is
+ *
+ *   simulation.simulate_and_measure(tape, n_qubits, type, obs, use_density)
+ *        qml_essentials/simulation.py:131-139     (per-sample kernel)
+ *   Script._execute_batched(type, obs, args, kwargs, in_axes)
+ *        qml_essentials/script.py:399-408          (jax.vmap over the batch;
+ *        script.py:443-453 marks it as the multi-device replacement point)
+ *
+ * Conventions (identical to the reference):
+ *   - state = 2^n complex64 (float2, re/im interleaved), wire 0 = MOST significant
+ *     bit of the flat index            (simulation.py:100-104, test_jaqsi.py:416-427)
+ *   - a k-qubit gate on wires [w0..w(k-1)] has matrix row/col index
+ *     sum_j bit[w_j] << (k-1-j)        (operations.py:38-50)
+ *   - every execution starts from |0...0>   (simulation.py:100)
+ *   - batch element b uses row b of the angle table (jax.vmap semantics,
+ *     script.py:302-315); results carry a leading batch dimension.
+ *
+ * Ownership: the caller (PyTorch-ROCm in this repo) owns every device buffer;
+ * the library owns only the plan.  No exceptions cross the ABI: 0 = ok, negative
+ * = qmle_status.  Plans are immutable after creation except for a lazily created
+ * device copy of their descriptors; one stream per call; no other global state.
+ * All pointers named d_* are device pointers, everything else is host memory.
+ */
+#ifndef QMLE_SV_H
+#define QMLE_SV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMLE_SV_VERSION 100 /* 0.1.0 */
+#define QMLE_MAX_QUBITS 32
+
+typedef struct qmle_plan qmle_plan;
+typedef void *qmle_stream; /* hipStream_t */
+
+typedef enum qmle_status {
+  QMLE_OK = 0,
+  QMLE_ERR_INVALID_ARG = -1,
+  QMLE_ERR_WIRE_COUNT = -2,      /* operations.py:140-144  "expects k wire(s)" */
+  QMLE_ERR_DUPLICATE_WIRES = -3, /* operations.py:145-146  "duplicate wires"   */
+  QMLE_ERR_WIRE_RANGE = -4,      /* wire >= n_qubits                           */
+  QMLE_ERR_UNKNOWN_OP = -5,
+  QMLE_ERR_MEAS_TYPE = -6,       /* simulation.py:271 "Unknown measurement type" */
+  QMLE_ERR_WORKSPACE = -7,       /* workspace too small                        */
+  QMLE_ERR_HIP = -8,             /* a HIP runtime call failed                  */
+  QMLE_ERR_NO_DEVICE = -9,
+  QMLE_ERR_UNSUPPORTED = -10,
+  QMLE_ERR_SLOT_RANGE = -11
+} qmle_status;
+
+/* Gate vocabulary = the gate classes of qml_essentials/operations.py that the
+ * 23 ansaetze, the encodings and the entanglement circuits put on the tape. */
+typedef enum qmle_opcode {
+  QMLE_OP_ID = 0,      /* operations.py:719  */
+  QMLE_OP_X = 1,       /* PauliX  :746       */
+  QMLE_OP_Y = 2,       /* PauliY  :762       */
+  QMLE_OP_Z = 3,       /* PauliZ  :778       */
+  QMLE_OP_H = 4,       /* :794               */
+  QMLE_OP_S = 5,       /* :810               */
+  QMLE_OP_RX = 6,      /* :1043  slot[0]=theta */
+  QMLE_OP_RY = 7,      /* :1044              */
+  QMLE_OP_RZ = 8,      /* :1045              */
+  QMLE_OP_ROT = 9,     /* :1204  slot = phi,theta,omega */
+  QMLE_OP_CX = 10,     /* :1098  wires = [control,target] */
+  QMLE_OP_CY = 11,     /* :1099              */
+  QMLE_OP_CZ = 12,     /* :1100              */
+  QMLE_OP_CRX = 13,    /* :1485              */
+  QMLE_OP_CRY = 14,    /* :1486              */
+  QMLE_OP_CRZ = 15,    /* :1487              */
+  QMLE_OP_CPHASE = 16, /* ControlledPhaseShift :1171 */
+  QMLE_OP_SWAP = 17,   /* :831               */
+  QMLE_OP_RXX = 18,    /* :1348              */
+  QMLE_OP_RYY = 19,    /* :1349              */
+  QMLE_OP_RZZ = 20,    /* :1350              */
+  QMLE_OP_RZX = 21,    /* :1351              */
+  QMLE_OP_CCX = 22,    /* :1103  wires = [c0,c1,target] */
+  QMLE_OP_CSWAP = 23,  /* :1140  wires = [c,t0,t1]      */
+  QMLE_OP_MAT1 = 24,   /* Operation(matrix=2x2), batch-constant; mat_off -> 8 floats  */
+  QMLE_OP_MAT2 = 25,   /* Operation(matrix=4x4), batch-constant; mat_off -> 32 floats */
+  QMLE_OP_DIAG_ALL = 26, /* DiagonalQubitUnitary on wires 0..n-1 in order (:922-926):
+                            amp[i] *= exp(-i * consts[mat_off+i] * angle[slot0])
+                            (Golomb encoding, unitary.py:661-701)              */
+  QMLE_OP__COUNT = 27
+} qmle_opcode;
+
+/* One tape entry.  Barriers (operations.py:964) are not sent: simulate_pure skips
+ * them (simulation.py:93-94). */
+typedef struct qmle_op {
+  uint16_t opcode;  /* qmle_opcode */
+  int16_t wire[3];  /* reference wire order; unused = -1 */
+  int32_t slot[3];  /* column of the angle table per parameter; unused = -1 */
+  int32_t mat_off;  /* float offset into `consts` for MAT1/MAT2/DIAG_ALL, else -1 */
+} qmle_op;
+
+/* measure_state types (simulation.py:204-271) + engine-internal extras */
+typedef enum qmle_meas {
+  QMLE_MEAS_STATE = 0,    /* out: [B][2^n] complex64                           */
+  QMLE_MEAS_PROBS = 1,    /* out: [B][2^n] float32  |psi|^2                    */
+  QMLE_MEAS_EXPVAL_Z = 2, /* out: [B][n_obs] float32, PauliZ on obs_wires[k]
+                             (fast path simulation.py:241-261, all in ONE pass) */
+  QMLE_MEAS_DENSITY = 3   /* out: [B][2^n][2^n] complex64 = |psi><psi|
+                             (simulation.py:183-189)                           */
+} qmle_meas;
+
+/* plan flags */
+#define QMLE_PLAN_DEFAULT 0u
+#define QMLE_PLAN_NO_FUSION 1u      /* one HBM pass per reference gate (roofline mode) */
+#define QMLE_PLAN_FORCE_GLOBAL 2u   /* never use the whole-state-in-LDS kernel        */
+#define QMLE_PLAN_FORCE_TILE 4u     /* never use the direct per-gate kernels          */
+/* bits 8..15: tile qubits T override (0 = auto); bits 16..23: low-bit count L override */
+#define QMLE_PLAN_TILE_BITS(t) (((unsigned)(t) & 0xffu) << 8)
+#define QMLE_PLAN_LOW_BITS(l) (((unsigned)(l) & 0xffu) << 16)
+
+int qmle_sv_version(void);
+const char *qmle_status_string(int status);
+/* number of HIP devices visible (0 if none / no driver); never fails */
+int qmle_device_count(void);
+
+/* Validate + compile a tape into an execution plan (host only, no HIP calls).
+ * consts: batch-constant floats referenced by mat_off (copied). */
+int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
+                     const float *consts, int n_consts, unsigned flags,
+                     qmle_plan **out);
+int qmle_plan_destroy(qmle_plan *plan);
+/* JSON description of the compiled passes (for tests / DESIGN.md); returns the
+ * number of bytes needed (excluding NUL); writes at most cap-1 bytes + NUL. */
+int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap);
+/* counts: [0]=reference gates, [1]=HBM passes, [2]=whole-state-LDS(0/1),
+ * [3]=tile qubits T, [4]=floats of per-sample matrices, [5]=direct passes */
+int qmle_plan_stats(const qmle_plan *plan, int64_t stats[8]);
+
+/* Minimum workspace for `batch` samples and the bytes that let the engine keep
+ * `states_in_flight` states resident (0 = engine default).  */
+size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type,
+                            int n_obs, int states_in_flight);
+
+/* simulate_and_measure over a batch: d_angles is [batch][n_slots] float32,
+ * d_out as documented per qmle_meas.  obs_wires is HOST memory.  */
+int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                   const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
+                   size_t workspace_bytes, qmle_stream stream);
+
+/* ---- stand-alone measurement / analysis kernels on resident states ---------- */
+/* d_states: [batch][2^n] complex64 */
+int qmle_expval_z(const void *d_states, int n_qubits, int batch, const int32_t *obs_wires,
+                  int n_obs, float *d_out, void *d_workspace, size_t workspace_bytes,
+                  qmle_stream stream);
+size_t qmle_expval_workspace_bytes(int n_qubits, int batch);
+int qmle_probs(const void *d_states, int n_qubits, int batch, float *d_out,
+               qmle_stream stream);
+int qmle_density(const void *d_states, int n_qubits, int batch, void *d_out,
+                 qmle_stream stream);
+/* probs marginalised onto `keep` wires, kept wires in ascending wire order
+ * (jaqsi.py:106-146): d_out [batch][2^n_keep] float32 (zeroed by the call) */
+int qmle_marginal_probs(const void *d_states, int n_qubits, int batch,
+                        const int32_t *keep_wires, int n_keep, float *d_out,
+                        qmle_stream stream);
+/* F_i = |<psi_i|psi_{i+n_pairs}>|^2, i < n_pairs; d_states holds 2*n_pairs states
+ * (Expressibility pairing rule, expressibility.py:49-52; pure-state form of
+ * math.py:60-86) */
+int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d_out,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+size_t qmle_pair_fidelity_workspace_bytes(int n_qubits, int n_pairs);
+/* Meyer-Wallach: d_out[b] = 2 (1 - 1/n sum_j Tr rho_j^2), Tr rho_j^2 = a^2+d^2+2|c|^2
+ * (entanglement.py:86-101 via the Schmidt identity).
+ * d_purities (optional, may be NULL): [batch][n] float32 */
+int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_out,
+                       float *d_purities, void *d_workspace, size_t workspace_bytes,
+                       qmle_stream stream);
+size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch);
+/* numpy.histogram(values, bins=linspace(lo,hi,n_bins+1)) counts (last bin
+ * right-inclusive) -- expressibility.py:104-108; d_counts int32[n_bins], zeroed
+ * by the call */
+int qmle_histogram(const float *d_values, int64_t count, int n_bins, float lo, float hi,
+                   int32_t *d_counts, qmle_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMLE_SV_H */

@@ -1,0 +1,335 @@
+"""ctypes binding of ``libqmle_sv.so`` (C ABI declared in ``include/qmle_sv.h``).
+
+PyTorch is used only for device memory and streams (``tensor.data_ptr()``,
+``torch.cuda.current_stream().cuda_stream``); no torch type crosses the ABI.
+There is NO CPU fallback: if the library is missing, or a compute entry point is
+called without a GPU, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libqmle_sv.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+MAX_QUBITS = 32
+
+# qmle_status -> (exception type, message) -- messages follow the reference where it
+# has one (operations.py:140-146, simulation.py:271)
+OK = 0
+_STATUS_EXC = {
+    -1: ValueError,
+    -2: ValueError,
+    -3: ValueError,
+    -4: ValueError,
+    -5: ValueError,
+    -6: ValueError,
+    -7: RuntimeError,
+    -8: RuntimeError,
+    -9: RuntimeError,
+    -10: NotImplementedError,
+    -11: ValueError,
+}
+
+OPCODES = {
+    "Id": 0, "PauliX": 1, "PauliY": 2, "PauliZ": 3, "H": 4, "S": 5,
+    "RX": 6, "RY": 7, "RZ": 8, "Rot": 9,
+    "CX": 10, "CY": 11, "CZ": 12, "CRX": 13, "CRY": 14, "CRZ": 15,
+    "CPhase": 16, "ControlledPhaseShift": 16, "SWAP": 17,
+    "RXX": 18, "RYY": 19, "RZZ": 20, "RZX": 21, "CCX": 22, "CSWAP": 23,
+    "MAT1": 24, "MAT2": 25, "DIAG_ALL": 26,
+}
+MEAS = {"state": 0, "probs": 1, "expval": 2, "density": 3}
+
+PLAN_DEFAULT = 0
+PLAN_NO_FUSION = 1
+PLAN_FORCE_GLOBAL = 2
+PLAN_FORCE_TILE = 4
+
+
+def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0):
+    f = 0
+    if no_fusion:
+        f |= PLAN_NO_FUSION
+    if force_global:
+        f |= PLAN_FORCE_GLOBAL
+    if force_tile:
+        f |= PLAN_FORCE_TILE
+    return f | ((tile_bits & 0xFF) << 8) | ((low_bits & 0xFF) << 16)
+
+
+class QmleOp(C.Structure):
+    _fields_ = [
+        ("opcode", C.c_uint16),
+        ("wire", C.c_int16 * 3),
+        ("slot", C.c_int32 * 3),
+        ("mat_off", C.c_int32),
+    ]
+
+
+_lib = None
+
+# every symbol include/qmle_sv.h declares: (name, restype, argtypes)
+_VP, _I, _SZ, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+SYMBOLS = [
+    ("qmle_sv_version", _I, []),
+    ("qmle_status_string", C.c_char_p, [_I]),
+    ("qmle_device_count", _I, []),
+    ("qmle_plan_create", _I, [C.POINTER(QmleOp), _I, _I, _I, C.POINTER(_F), _I, C.c_uint,
+                               C.POINTER(_VP)]),
+    ("qmle_plan_destroy", _I, [_VP]),
+    ("qmle_plan_describe", _I, [_VP, C.c_char_p, _SZ]),
+    ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
+    ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
+    ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_expval_z", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_expval_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_probs", _I, [_VP, _I, _I, _VP, _VP]),
+    ("qmle_density", _I, [_VP, _I, _I, _VP, _VP]),
+    ("qmle_marginal_probs", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP]),
+    ("qmle_pair_fidelity", _I, [_VP, _I, _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_pair_fidelity_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
+]
+
+
+def lib() -> C.CDLL:
+    """Load libqmle_sv.so (built by ``__graft_entry__.build()``); fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(handle, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status == OK:
+        return
+    msg = lib().qmle_status_string(status).decode()
+    raise _STATUS_EXC.get(status, RuntimeError)(f"{what}: {msg} (qmle status {status})")
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "qml-essentials_amd needs an AMD GPU (gfx950); no CPU fallback exists. "
+            "Run on the MI355X box (gpurun)."
+        )
+    return torch
+
+
+def _stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i32(values: Sequence[int]):
+    arr = (C.c_int32 * max(1, len(values)))(*[int(v) for v in values])
+    return arr
+
+
+class Plan:
+    """A compiled tape (``qmle_plan``).  Host-only until the first ``run``.
+
+    ops: list of ``(name, wires, slots, mat_off)``; ``slots`` index columns of the
+    per-sample angle table; ``consts`` is the float32 blob for MAT1/MAT2/DIAG_ALL.
+    """
+
+    def __init__(self, ops: List[Tuple[str, Sequence[int], Sequence[int], int]], n_qubits: int,
+                 n_slots: int, consts: Optional[np.ndarray] = None, flags: int = 0):
+        L = lib()
+        arr = (QmleOp * max(1, len(ops)))()
+        for i, (name, wires, slots, mat_off) in enumerate(ops):
+            code = OPCODES.get(name) if isinstance(name, str) else int(name)
+            if code is None:
+                raise ValueError(f"Unknown gate {name!r}")
+            arr[i].opcode = code
+            wires = list(wires)
+            if len(wires) > 3:
+                raise ValueError(f"{name} expects at most 3 wires, got {len(wires)}: {wires}")
+            for k in range(3):
+                arr[i].wire[k] = int(wires[k]) if k < len(wires) else -1
+                arr[i].slot[k] = int(slots[k]) if k < len(slots) else -1
+            arr[i].mat_off = int(mat_off)
+        if consts is None:
+            consts = np.zeros(0, dtype=np.float32)
+        self._consts = np.ascontiguousarray(consts, dtype=np.float32)
+        handle = C.c_void_p()
+        rc = L.qmle_plan_create(
+            arr, len(ops), int(n_qubits), int(n_slots),
+            self._consts.ctypes.data_as(C.POINTER(C.c_float)), int(self._consts.size),
+            C.c_uint(flags), C.byref(handle),
+        )
+        check(rc, "qmle_plan_create")
+        self._h = handle
+        self.n_qubits = int(n_qubits)
+        self.n_slots = int(n_slots)
+        self.n_ops = len(ops)
+        self.flags = flags
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and _lib is not None:
+            _lib.qmle_plan_destroy(h)
+            self._h = None
+
+    def describe(self) -> dict:
+        L = lib()
+        need = L.qmle_plan_describe(self._h, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        L.qmle_plan_describe(self._h, buf, need + 1)
+        return json.loads(buf.value.decode())
+
+    def stats(self) -> dict:
+        arr = (C.c_int64 * 8)()
+        check(lib().qmle_plan_stats(self._h, arr), "qmle_plan_stats")
+        keys = ["n_ops", "n_passes", "whole_state_lds", "tile_bits", "mat_floats",
+                "direct_passes", "n_lowered", "algo_bytes_per_state"]
+        return dict(zip(keys, [int(v) for v in arr]))
+
+    def workspace_bytes(self, batch: int, meas: str, n_obs: int = 0, states_in_flight: int = 0):
+        return int(lib().qmle_workspace_bytes(self._h, batch, MEAS[meas], n_obs, states_in_flight))
+
+    def run(self, angles, meas: str, obs_wires: Sequence[int] = (), out=None, workspace=None,
+            states_in_flight: int = 0):
+        """simulate_and_measure for a batch.  ``angles``: float32 cuda tensor [B, n_slots]."""
+        torch = require_gpu()
+        if meas not in MEAS:
+            raise ValueError(f"Unknown measurement type: {meas!r}")  # simulation.py:271
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if angles is None:
+            angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float32, device=dev)
+        angles = angles.to(device=dev, dtype=torch.float32).contiguous()
+        if angles.dim() != 2 or (self.n_slots and angles.shape[1] != self.n_slots):
+            raise ValueError(f"angles must be [B, {self.n_slots}], got {tuple(angles.shape)}")
+        B = int(angles.shape[0])
+        D = 1 << self.n_qubits
+        n_obs = len(obs_wires)
+        if out is None:
+            if meas == "state":
+                out = torch.empty((B, D), dtype=torch.complex64, device=dev)
+            elif meas == "probs":
+                out = torch.empty((B, D), dtype=torch.float32, device=dev)
+            elif meas == "expval":
+                out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
+            else:
+                out = torch.empty((B, D, D), dtype=torch.complex64, device=dev)
+        need = self.workspace_bytes(B, meas, n_obs, states_in_flight)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        rc = lib().qmle_run_batch(
+            self._h, C.c_void_p(angles.data_ptr()), B, MEAS[meas], _i32(obs_wires), n_obs,
+            C.c_void_p(out.data_ptr()), C.c_void_p(workspace.data_ptr()),
+            C.c_size_t(workspace.numel()), _stream_ptr(),
+        )
+        check(rc, "qmle_run_batch")
+        return out
+
+
+# ---- stand-alone measurement / analysis kernels -------------------------------------
+def _states_info(states):
+    torch = require_gpu()
+    if states.dtype != torch.complex64 or not states.is_cuda:
+        raise ValueError("states must be a complex64 CUDA tensor [B, 2^n]")
+    states = states.contiguous()
+    if states.dim() == 1:
+        states = states.unsqueeze(0)
+    B, D = int(states.shape[0]), int(states.shape[1])
+    n = D.bit_length() - 1
+    if 1 << n != D:
+        raise ValueError(f"state length {D} is not a power of two")
+    return torch, states, B, n
+
+
+def expval_z(states, obs_wires: Sequence[int]):
+    torch, states, B, n = _states_info(states)
+    out = torch.empty((B, len(obs_wires)), dtype=torch.float32, device=states.device)
+    wsb = int(lib().qmle_expval_workspace_bytes(n, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_expval_z(C.c_void_p(states.data_ptr()), n, B, _i32(obs_wires), len(obs_wires),
+                              C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), wsb,
+                              _stream_ptr()), "qmle_expval_z")
+    return out
+
+
+def probs(states):
+    torch, states, B, n = _states_info(states)
+    out = torch.empty((B, 1 << n), dtype=torch.float32, device=states.device)
+    check(lib().qmle_probs(C.c_void_p(states.data_ptr()), n, B, C.c_void_p(out.data_ptr()),
+                           _stream_ptr()), "qmle_probs")
+    return out
+
+
+def density(states):
+    torch, states, B, n = _states_info(states)
+    out = torch.empty((B, 1 << n, 1 << n), dtype=torch.complex64, device=states.device)
+    check(lib().qmle_density(C.c_void_p(states.data_ptr()), n, B, C.c_void_p(out.data_ptr()),
+                             _stream_ptr()), "qmle_density")
+    return out
+
+
+def marginal_probs(states, keep: Sequence[int]):
+    torch, states, B, n = _states_info(states)
+    out = torch.empty((B, 1 << len(keep)), dtype=torch.float32, device=states.device)
+    check(lib().qmle_marginal_probs(C.c_void_p(states.data_ptr()), n, B, _i32(keep), len(keep),
+                                    C.c_void_p(out.data_ptr()), _stream_ptr()),
+          "qmle_marginal_probs")
+    return out
+
+
+def pair_fidelity(states):
+    """|<psi_i|psi_{i+S}>|^2 for states [2S, 2^n] -> [S]."""
+    torch, states, B, n = _states_info(states)
+    if B % 2:
+        raise ValueError("pair_fidelity needs an even number of states")
+    S = B // 2
+    out = torch.empty((S,), dtype=torch.float32, device=states.device)
+    wsb = int(lib().qmle_pair_fidelity_workspace_bytes(n, S))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_pair_fidelity(C.c_void_p(states.data_ptr()), n, S, C.c_void_p(out.data_ptr()),
+                                   C.c_void_p(ws.data_ptr()), wsb, _stream_ptr()),
+          "qmle_pair_fidelity")
+    return out
+
+
+def meyer_wallach(states, return_purities: bool = False):
+    torch, states, B, n = _states_info(states)
+    out = torch.empty((B,), dtype=torch.float32, device=states.device)
+    pur = torch.empty((B, n), dtype=torch.float32, device=states.device) if return_purities else None
+    wsb = int(lib().qmle_meyer_wallach_workspace_bytes(n, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_meyer_wallach(C.c_void_p(states.data_ptr()), n, B, C.c_void_p(out.data_ptr()),
+                                   C.c_void_p(pur.data_ptr()) if pur is not None else None,
+                                   C.c_void_p(ws.data_ptr()), wsb, _stream_ptr()),
+          "qmle_meyer_wallach")
+    return (out, pur) if return_purities else out
+
+
+def histogram(values, n_bins: int, lo: float = 0.0, hi: float = 1.0):
+    torch = require_gpu()
+    values = values.to(dtype=torch.float32).contiguous().reshape(-1)
+    counts = torch.empty((n_bins,), dtype=torch.int32, device=values.device)
+    check(lib().qmle_histogram(C.c_void_p(values.data_ptr()), values.numel(), n_bins,
+                               C.c_float(lo), C.c_float(hi), C.c_void_p(counts.data_ptr()),
+                               _stream_ptr()), "qmle_histogram")
+    return counts

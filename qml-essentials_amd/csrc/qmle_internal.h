@@ -1,0 +1,104 @@
+// Internal structures shared by the host-side plan compiler (qmle_plan.cpp) and
+// the gfx950 kernels / C-ABI entry points (qmle_sv.hip).  Not part of the ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "qmle_sv.h"
+
+namespace qmle {
+
+// All kernels work in "bit position" space: wire w of an n-qubit register is bit
+// p = n-1-w of the flat amplitude index (wire 0 = MSB, simulation.py:100-104).
+
+enum LKind : uint8_t {
+  LK_1Q = 0,       // (0..2 controls) x dense/diagonal 2x2 on t0
+  LK_2Q = 1,       // (0..1 controls) x dense 4x4 on (t0,t1); row = 2*bit[t0] + bit[t1]
+  LK_DIAG_ALL = 2  // full-register diagonal exp(-i * mark[i] * x)
+};
+enum LFlag : uint8_t {
+  LF_DIAG = 1,     // matrix is diagonal
+};
+
+// Device-visible lowered operation (16 bytes).
+struct LoweredOp {
+  uint8_t kind;
+  uint8_t flags;
+  int8_t t0, t1;     // target bit positions (t1 = -1 for LK_1Q)
+  int8_t c0, c1;     // control bit positions or -1
+  uint8_t nc;        // number of controls
+  uint8_t pad;
+  uint32_t mat_off;  // LK_1Q/LK_2Q: float offset in the per-sample matrix row
+                     // LK_DIAG_ALL: float offset of the marks in the const blob
+  int32_t slot;      // LK_DIAG_ALL: angle-table column, else -1
+};
+static_assert(sizeof(LoweredOp) == 16, "LoweredOp layout");
+
+// One source gate feeding the per-sample matrix builder (24 bytes).
+struct BuildOp {
+  uint16_t opcode;
+  uint16_t pad;
+  int32_t slot[3];
+  int32_t const_off;
+  uint32_t pad2;
+};
+static_assert(sizeof(BuildOp) == 24, "BuildOp layout");
+
+// A matrix = product of build ops [begin,end) in tape order (later gate on the left).
+struct BuildGroup {
+  uint32_t begin, end;
+  uint32_t mat_off;
+  uint32_t dim;  // 2 or 4
+};
+
+enum StageKind : int { ST_DIRECT = 0, ST_TILE = 1, ST_DIAG_ALL = 2 };
+
+struct Stage {
+  int kind = ST_TILE;
+  int op_begin = 0, op_end = 0;  // range in Plan::dev_ops
+  int T = 0, L = 0;              // tile qubits, contiguous low bits
+  int n_tile_ops = 0;
+  int8_t tile_bits[QMLE_MAX_QUBITS];   // ascending global positions of local bits
+  int8_t outer_bits[QMLE_MAX_QUBITS];  // ascending global positions of the rest
+  std::vector<int> src_ops;            // reference tape indices covered
+  double algo_bytes_per_state = 0;     // SURVEY 8-d bytes of the covered gates
+};
+
+struct DevicePlan {  // lazily created by the first run on a device
+  void *blob = nullptr;
+  size_t blob_bytes = 0;
+  LoweredOp *d_ops = nullptr;
+  BuildOp *d_build = nullptr;
+  BuildGroup *d_groups = nullptr;
+  float *d_consts = nullptr;
+};
+
+}  // namespace qmle
+
+struct qmle_plan {
+  int n = 0, n_slots = 0;
+  unsigned flags = 0;
+  std::vector<qmle_op> ops;
+  std::vector<float> consts;
+  std::vector<qmle::LoweredOp> lowered;   // after 1-q merging, global positions
+  std::vector<std::vector<int>> lowered_src;  // reference ops per lowered op
+  std::vector<qmle::LoweredOp> dev_ops;   // per stage, stage-local positions
+  std::vector<qmle::BuildOp> build_ops;
+  std::vector<qmle::BuildGroup> groups;
+  std::vector<qmle::Stage> stages;
+  uint32_t mat_floats = 0;                // per-sample matrix row length
+  bool whole_state_lds = false;
+  int tile_T = 0, tile_L = 0;
+  double algo_bytes_per_state = 0;
+  qmle::DevicePlan dev;
+};
+
+namespace qmle {
+int compile_plan(qmle_plan *p);  // qmle_plan.cpp
+std::string describe_plan(const qmle_plan *p);
+double algo_bytes(const qmle_op &op, int n);
+constexpr int kLdsMaxQubits = 14;       // 2^14 * 8 B = 128 KiB <= 160 KiB LDS/CU
+constexpr int kDefaultTileBits = 13;    // 64 KiB tile -> 2 workgroups per CU
+constexpr int kDefaultLowBits = 7;      // 128 amplitudes = 1 KiB contiguous per wave load
+}  // namespace qmle

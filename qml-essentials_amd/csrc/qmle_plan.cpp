@@ -1,0 +1,376 @@
+// Host-side plan compiler: tape validation, lowering to controlled-2x2 / 4x4
+// primitives, commutation-aware merging of 1-qubit gates, and greedy scheduling
+// of the lowered ops into HBM passes ("stages").  No HIP calls in this file, so
+// plans can be built and inspected on a machine without a GPU.
+//
+// What is being replaced: jax traces the circuit once and XLA emits one
+// out-of-place einsum per gate (qml_essentials/simulation.py:91-104).  Here the
+// tape is compiled into a few passes; each pass stages a 2^T-amplitude tile in
+// LDS and applies every gate whose wires fall inside the tile.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "qmle_internal.h"
+
+namespace qmle {
+
+namespace {
+
+struct OpInfo {
+  int n_wires;
+  int n_params;
+  bool has_const;
+};
+
+bool op_info(int opcode, OpInfo *info) {
+  switch (opcode) {
+    case QMLE_OP_ID: case QMLE_OP_X: case QMLE_OP_Y: case QMLE_OP_Z:
+    case QMLE_OP_H: case QMLE_OP_S:
+      *info = {1, 0, false}; return true;
+    case QMLE_OP_RX: case QMLE_OP_RY: case QMLE_OP_RZ:
+      *info = {1, 1, false}; return true;
+    case QMLE_OP_ROT:
+      *info = {1, 3, false}; return true;
+    case QMLE_OP_CX: case QMLE_OP_CY: case QMLE_OP_CZ: case QMLE_OP_SWAP:
+      *info = {2, 0, false}; return true;
+    case QMLE_OP_CRX: case QMLE_OP_CRY: case QMLE_OP_CRZ: case QMLE_OP_CPHASE:
+    case QMLE_OP_RXX: case QMLE_OP_RYY: case QMLE_OP_RZZ: case QMLE_OP_RZX:
+      *info = {2, 1, false}; return true;
+    case QMLE_OP_CCX: case QMLE_OP_CSWAP:
+      *info = {3, 0, false}; return true;
+    case QMLE_OP_MAT1:
+      *info = {1, 0, true}; return true;
+    case QMLE_OP_MAT2:
+      *info = {2, 0, true}; return true;
+    case QMLE_OP_DIAG_ALL:
+      *info = {-1, 1, true}; return true;
+    default:
+      return false;
+  }
+}
+
+bool is_diag_opcode(int opcode) {
+  switch (opcode) {
+    case QMLE_OP_ID: case QMLE_OP_Z: case QMLE_OP_S: case QMLE_OP_RZ:
+    case QMLE_OP_CZ: case QMLE_OP_CRZ: case QMLE_OP_CPHASE: case QMLE_OP_RZZ:
+      return true;
+    default:
+      return false;
+  }
+}
+
+inline uint64_t bit(int p) { return 1ull << p; }
+
+uint64_t op_mask(const LoweredOp &o, int n) {
+  if (o.kind == LK_DIAG_ALL) return n >= 64 ? ~0ull : (bit(n) - 1);
+  uint64_t m = bit(o.t0);
+  if (o.t1 >= 0) m |= bit(o.t1);
+  if (o.c0 >= 0) m |= bit(o.c0);
+  if (o.c1 >= 0) m |= bit(o.c1);
+  return m;
+}
+
+}  // namespace
+
+// SURVEY.md 8-d / BASELINE.md section 3: algorithmic bytes per state of one
+// reference gate (complex64, D = 2^n).
+double algo_bytes(const qmle_op &op, int n) {
+  const double D = (double)(1ull << n);
+  switch (op.opcode) {
+    case QMLE_OP_ID: return 0.0;
+    case QMLE_OP_CX: case QMLE_OP_CY: case QMLE_OP_CRX: case QMLE_OP_CRY:
+    case QMLE_OP_CRZ: return 8.0 * D;
+    case QMLE_OP_CZ: case QMLE_OP_CPHASE: case QMLE_OP_CCX: case QMLE_OP_CSWAP:
+      return 4.0 * D;
+    default: return 16.0 * D;
+  }
+}
+
+int compile_plan(qmle_plan *p) {
+  const int n = p->n;
+  if (n < 1 || n > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
+
+  // ---- 1. validate + lower -------------------------------------------------
+  std::vector<int> last_touch(n, -1);  // lowered index that last touched bit p
+  p->lowered.clear(); p->lowered_src.clear(); p->build_ops.clear(); p->groups.clear();
+  p->algo_bytes_per_state = 0;
+  p->mat_floats = 0;
+  const bool fuse = !(p->flags & QMLE_PLAN_NO_FUSION);
+  std::vector<std::vector<BuildOp>> group_ops;            // source gates per matrix
+  std::vector<std::pair<uint32_t, uint32_t>> group_meta;  // (mat_off, dim)
+  std::vector<int> group_of;                              // lowered index -> group
+
+  for (size_t i = 0; i < p->ops.size(); ++i) {
+    const qmle_op &op = p->ops[i];
+    OpInfo info;
+    if (!op_info(op.opcode, &info)) return QMLE_ERR_UNKNOWN_OP;
+    int nw = 0;
+    while (nw < 3 && op.wire[nw] >= 0) ++nw;
+    if (op.opcode == QMLE_OP_DIAG_ALL) {
+      // wires are implicitly 0..n-1 in order (operations.py:922-926)
+      if (op.mat_off < 0 || (size_t)op.mat_off + (1ull << n) > p->consts.size())
+        return QMLE_ERR_INVALID_ARG;
+    } else {
+      if (nw != info.n_wires) return QMLE_ERR_WIRE_COUNT;
+      for (int a = 0; a < nw; ++a) {
+        if (op.wire[a] >= n) return QMLE_ERR_WIRE_RANGE;
+        for (int b = a + 1; b < nw; ++b)
+          if (op.wire[a] == op.wire[b]) return QMLE_ERR_DUPLICATE_WIRES;
+      }
+      if (info.has_const) {
+        const size_t need = op.opcode == QMLE_OP_MAT1 ? 8 : 32;
+        if (op.mat_off < 0 || (size_t)op.mat_off + need > p->consts.size())
+          return QMLE_ERR_INVALID_ARG;
+      }
+    }
+    for (int a = 0; a < info.n_params; ++a)
+      if (op.slot[a] < 0 || op.slot[a] >= p->n_slots) return QMLE_ERR_SLOT_RANGE;
+
+    p->algo_bytes_per_state += algo_bytes(op, n);
+    if (op.opcode == QMLE_OP_ID) continue;  // identity: nothing to do
+
+    auto pos = [n](int w) { return (int8_t)(n - 1 - w); };
+    LoweredOp lo{};
+    lo.t1 = lo.c0 = lo.c1 = -1;
+    lo.slot = -1;
+    lo.flags = is_diag_opcode(op.opcode) ? LF_DIAG : 0;
+    BuildOp bo{};
+    bo.opcode = op.opcode;
+    for (int a = 0; a < 3; ++a) bo.slot[a] = op.slot[a];
+    bo.const_off = op.mat_off;
+
+    if (op.opcode == QMLE_OP_DIAG_ALL) {
+      lo.kind = LK_DIAG_ALL;
+      lo.t0 = 0;
+      lo.mat_off = (uint32_t)op.mat_off;
+      lo.slot = op.slot[0];
+      for (int b = 0; b < n; ++b) last_touch[b] = (int)p->lowered.size();
+      group_of.resize(p->lowered.size() + 1, -1);
+      p->lowered.push_back(lo);
+      p->lowered_src.push_back({(int)i});
+      continue;
+    }
+
+    switch (op.opcode) {
+      case QMLE_OP_CX: case QMLE_OP_CY: case QMLE_OP_CZ: case QMLE_OP_CRX:
+      case QMLE_OP_CRY: case QMLE_OP_CRZ: case QMLE_OP_CPHASE:
+        lo.kind = LK_1Q; lo.nc = 1; lo.c0 = pos(op.wire[0]); lo.t0 = pos(op.wire[1]);
+        break;
+      case QMLE_OP_CCX:
+        lo.kind = LK_1Q; lo.nc = 2; lo.c0 = pos(op.wire[0]); lo.c1 = pos(op.wire[1]);
+        lo.t0 = pos(op.wire[2]);
+        break;
+      case QMLE_OP_CSWAP:
+        lo.kind = LK_2Q; lo.nc = 1; lo.c0 = pos(op.wire[0]); lo.t0 = pos(op.wire[1]);
+        lo.t1 = pos(op.wire[2]);
+        break;
+      case QMLE_OP_SWAP: case QMLE_OP_RXX: case QMLE_OP_RYY: case QMLE_OP_RZZ:
+      case QMLE_OP_RZX: case QMLE_OP_MAT2:
+        lo.kind = LK_2Q; lo.nc = 0; lo.t0 = pos(op.wire[0]); lo.t1 = pos(op.wire[1]);
+        break;
+      default:  // uncontrolled 1-qubit
+        lo.kind = LK_1Q; lo.nc = 0; lo.t0 = pos(op.wire[0]);
+        break;
+    }
+
+    // commutation-aware merge: an uncontrolled 1-q gate multiplies onto the
+    // previous uncontrolled 1-q matrix on the same wire if nothing touched that
+    // wire in between (gates on disjoint wires commute).
+    if (fuse && lo.kind == LK_1Q && lo.nc == 0) {
+      const int prev = last_touch[lo.t0];
+      if (prev >= 0) {
+        LoweredOp &pl = p->lowered[prev];
+        if (pl.kind == LK_1Q && pl.nc == 0 && pl.t0 == lo.t0) {
+          group_ops[group_of[prev]].push_back(bo);
+          if (!(lo.flags & LF_DIAG)) pl.flags &= ~LF_DIAG;
+          p->lowered_src[prev].push_back((int)i);
+          continue;
+        }
+      }
+    }
+
+    const uint32_t dim = lo.kind == LK_2Q ? 4u : 2u;
+    lo.mat_off = p->mat_floats;
+    p->mat_floats += dim * dim * 2;
+    const int idx = (int)p->lowered.size();
+    group_of.resize(idx + 1, -1);
+    group_of[idx] = (int)group_ops.size();
+    group_ops.push_back({bo});
+    group_meta.push_back({lo.mat_off, dim});
+    const uint64_t m = op_mask(lo, n);
+    for (int b = 0; b < n; ++b)
+      if (m & bit(b)) last_touch[b] = idx;
+    p->lowered.push_back(lo);
+    p->lowered_src.push_back({(int)i});
+  }
+  // flatten the per-matrix source lists (tape order inside each group)
+  for (size_t g = 0; g < group_ops.size(); ++g) {
+    BuildGroup bg{(uint32_t)p->build_ops.size(), 0, group_meta[g].first, group_meta[g].second};
+    for (const BuildOp &b : group_ops[g]) p->build_ops.push_back(b);
+    bg.end = (uint32_t)p->build_ops.size();
+    p->groups.push_back(bg);
+  }
+
+  // ---- 2. choose regime ------------------------------------------------------
+  int T = (int)((p->flags >> 8) & 0xff);
+  int L = (int)((p->flags >> 16) & 0xff);
+  p->whole_state_lds = (n <= kLdsMaxQubits) && !(p->flags & QMLE_PLAN_FORCE_GLOBAL) &&
+                       (T == 0 || T >= n);
+  if (p->whole_state_lds) {
+    T = n;
+  } else {
+    if (T == 0) T = kDefaultTileBits;
+    if (T > kLdsMaxQubits) T = kLdsMaxQubits;
+    if (T > n) T = n;
+    if (T < 4 && T < n) return QMLE_ERR_INVALID_ARG;
+  }
+  if (L == 0) L = kDefaultLowBits;
+  if (L > T) L = T;
+  if (L < 1) L = 1;
+  p->tile_T = T;
+  p->tile_L = L;
+
+  // ---- 3. schedule into stages ------------------------------------------------
+  p->stages.clear();
+  p->dev_ops.clear();
+  const size_t nl = p->lowered.size();
+  std::vector<char> done(nl, 0);
+  size_t n_done = 0;
+  const bool no_fusion = (p->flags & QMLE_PLAN_NO_FUSION) != 0;
+  const bool force_tile = (p->flags & QMLE_PLAN_FORCE_TILE) != 0;
+  const uint64_t all_mask = n >= 64 ? ~0ull : bit(n) - 1;
+
+  auto popc = [](uint64_t x) { return __builtin_popcountll(x); };
+
+  while (n_done < nl) {
+    std::vector<int> members;
+    uint64_t Q = 0;
+    int stageL = L;
+    if (p->whole_state_lds) {
+      for (size_t i = 0; i < nl; ++i) members.push_back((int)i);
+      Q = all_mask;
+    } else {
+      // first pending op decides whether the default low-bit count fits
+      size_t first = 0;
+      while (done[first]) ++first;
+      const LoweredOp &fo = p->lowered[first];
+      if (fo.kind == LK_DIAG_ALL) {
+        Stage st;
+        st.kind = ST_DIAG_ALL;
+        st.op_begin = (int)p->dev_ops.size();
+        p->dev_ops.push_back(fo);
+        st.op_end = (int)p->dev_ops.size();
+        st.src_ops = p->lowered_src[first];
+        p->stages.push_back(st);
+        done[first] = 1;
+        ++n_done;
+        continue;
+      }
+      const uint64_t fm = op_mask(fo, n);
+      while (stageL > 1 && popc((bit(stageL) - 1) | fm) > T) --stageL;
+      Q = bit(stageL) - 1;
+      uint64_t blocked = 0;
+      for (size_t i = first; i < nl; ++i) {
+        if (done[i]) continue;
+        const LoweredOp &o = p->lowered[i];
+        const uint64_t m = op_mask(o, n);
+        if (o.kind == LK_DIAG_ALL || (m & blocked)) {
+          blocked |= m;
+        } else if (popc(Q | m) <= T) {
+          Q |= m;
+          members.push_back((int)i);
+          if (no_fusion) break;
+        } else {
+          blocked |= m;
+        }
+        if ((blocked & all_mask) == all_mask) break;
+      }
+    }
+
+    Stage st;
+    st.L = stageL;
+    st.op_begin = (int)p->dev_ops.size();
+    const LoweredOp &m0 = p->lowered[members[0]];
+    const bool direct_ok = !p->whole_state_lds && !force_tile && members.size() == 1 &&
+                           m0.kind == LK_1Q && m0.nc <= 1;
+    if (direct_ok) {
+      st.kind = ST_DIRECT;
+      p->dev_ops.push_back(m0);
+    } else {
+      st.kind = ST_TILE;
+      // pad the tile with the lowest free bit positions
+      for (int b = 0; b < n && popc(Q) < T; ++b) Q |= bit(b);
+      st.T = popc(Q);
+      int nt = 0, no = 0;
+      int8_t local_of[64];
+      for (int b = 0; b < n; ++b) {
+        if (Q & bit(b)) { local_of[b] = (int8_t)nt; st.tile_bits[nt++] = (int8_t)b; }
+        else { local_of[b] = -1; st.outer_bits[no++] = (int8_t)b; }
+      }
+      // contiguous low run actually present
+      int run = 0;
+      while (run < st.T && st.tile_bits[run] == run) ++run;
+      st.L = run < 1 ? 1 : run;
+      for (int mi : members) {
+        LoweredOp o = p->lowered[mi];
+        if (o.kind != LK_DIAG_ALL) {
+          o.t0 = local_of[(int)o.t0];
+          if (o.t1 >= 0) o.t1 = local_of[(int)o.t1];
+          if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
+          if (o.c1 >= 0) o.c1 = local_of[(int)o.c1];
+        }
+        p->dev_ops.push_back(o);
+      }
+    }
+    st.op_end = (int)p->dev_ops.size();
+    st.n_tile_ops = st.op_end - st.op_begin;
+    for (int mi : members) {
+      done[mi] = 1;
+      ++n_done;
+      for (int s : p->lowered_src[mi]) {
+        st.src_ops.push_back(s);
+        st.algo_bytes_per_state += algo_bytes(p->ops[s], n);
+      }
+    }
+    p->stages.push_back(st);
+  }
+  if (p->whole_state_lds && p->stages.empty()) {
+    // empty circuit: still need one stage to produce |0...0>
+    Stage st;
+    st.kind = ST_TILE;
+    st.T = n;
+    st.L = L;
+    for (int b = 0; b < n; ++b) st.tile_bits[b] = (int8_t)b;
+    p->stages.push_back(st);
+  }
+  return QMLE_OK;
+}
+
+std::string describe_plan(const qmle_plan *p) {
+  std::ostringstream os;
+  os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
+     << ",\"n_lowered\":" << p->lowered.size()
+     << ",\"whole_state_lds\":" << (p->whole_state_lds ? "true" : "false")
+     << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
+     << ",\"mat_floats\":" << p->mat_floats
+     << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state << ",\"stages\":[";
+  for (size_t s = 0; s < p->stages.size(); ++s) {
+    const Stage &st = p->stages[s];
+    if (s) os << ",";
+    os << "{\"kind\":\""
+       << (st.kind == ST_DIRECT ? "direct" : st.kind == ST_TILE ? "tile" : "diag_all")
+       << "\",\"n_lowered\":" << (st.op_end - st.op_begin) << ",\"T\":" << st.T
+       << ",\"L\":" << st.L << ",\"algo_bytes_per_state\":" << st.algo_bytes_per_state
+       << ",\"bits\":[";
+    for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
+    os << "],\"src_ops\":[";
+    for (size_t i = 0; i < st.src_ops.size(); ++i) os << (i ? "," : "") << st.src_ops[i];
+    os << "]}";
+  }
+  os << "]}";
+  return os.str();
+}
+
+}  // namespace qmle

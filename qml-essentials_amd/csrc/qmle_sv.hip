@@ -1,0 +1,1326 @@
+// libqmle_sv: gfx950 (MI355X / CDNA4) statevector kernels + C-ABI entry points.
+//
+// Replaces the compute of qml_essentials/simulation.py (simulate_pure :65-104,
+// measure_state :204-271) and the vmap batch dispatch of script.py:399-553.
+// Written for CDNA4 only: 64-wide wavefronts, 160 KiB LDS per CU, 16-byte
+// (float4 = 2 amplitudes) global accesses everywhere, one workgroup per LDS tile.
+//
+// Kernels
+//   k_build_matrices   per-sample 2x2 / 4x4 gate matrices from the angle table
+//   k_tile             load 2^T-amplitude tile -> LDS, apply a list of gates,
+//                      store / measure   (whole state in LDS when n <= 14)
+//   k_direct_1q        one (controlled) 2x2 gate streamed through HBM in place
+//   k_diag_all         full-register diagonal (Golomb encoding)
+//   k_expval_partial / k_expval_final   all-qubit <Z> in ONE read of the state
+//   k_probs, k_density, k_marginal, k_overlap_*, k_cross_*, k_histogram
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "qmle_internal.h"
+
+using namespace qmle;
+
+#define HIPCHK(expr)                                   \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) {                            \
+      g_last_hip_error = (int)_e;                      \
+      return QMLE_ERR_HIP;                             \
+    }                                                  \
+  } while (0)
+
+static thread_local int g_last_hip_error = 0;
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ins0(uint32_t i, int p) {
+  return ((i >> p) << (p + 1)) | (i & ((1u << p) - 1u));
+}
+__device__ __forceinline__ uint64_t ins0_64(uint64_t i, int p) {
+  return ((i >> p) << (p + 1)) | (i & ((1ull << p) - 1ull));
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {  // a*b + c
+  return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y)));
+}
+__device__ __forceinline__ float norm2(float2 a) { return a.x * a.x + a.y * a.y; }
+
+struct Mat2 {
+  float2 m00, m01, m10, m11;
+};
+__device__ __forceinline__ Mat2 load_mat2(const float *__restrict__ m) {
+  Mat2 r;
+  r.m00 = make_float2(m[0], m[1]);
+  r.m01 = make_float2(m[2], m[3]);
+  r.m10 = make_float2(m[4], m[5]);
+  r.m11 = make_float2(m[6], m[7]);
+  return r;
+}
+__device__ __forceinline__ void apply2(const Mat2 &m, float2 &a0, float2 &a1) {
+  const float2 b0 = cfma(m.m01, a1, cmul(m.m00, a0));
+  const float2 b1 = cfma(m.m11, a1, cmul(m.m10, a0));
+  a0 = b0;
+  a1 = b1;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+// Sum over the block; result valid in thread 0.  `red` holds >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// per-sample gate matrices  (operations.py:1002-1045, 1053-1100, 1171-1243,
+// 1255-1351, 1357-1487 -- matrices restated, evaluated in fp64, stored fp32)
+// ---------------------------------------------------------------------------
+struct cd {
+  double re, im;
+};
+__device__ __forceinline__ cd cdmul(cd a, cd b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+__device__ void source_matrix(const BuildOp &b, const float *__restrict__ ang,
+                              const float *__restrict__ consts, cd *M, int dim) {
+  const int nn = dim * dim;
+  for (int i = 0; i < nn; ++i) M[i] = {0.0, 0.0};
+  double th = 0.0, c = 1.0, s = 0.0;
+  if (b.slot[0] >= 0) {
+    th = (double)ang[b.slot[0]];
+    sincos(0.5 * th, &s, &c);
+  }
+  const double r2 = 0.70710678118654752440;
+  switch (b.opcode) {
+    case QMLE_OP_X: case QMLE_OP_CX: case QMLE_OP_CCX:
+      M[1] = {1, 0}; M[2] = {1, 0}; break;
+    case QMLE_OP_Y: case QMLE_OP_CY:
+      M[1] = {0, -1}; M[2] = {0, 1}; break;
+    case QMLE_OP_Z: case QMLE_OP_CZ:
+      M[0] = {1, 0}; M[3] = {-1, 0}; break;
+    case QMLE_OP_H:
+      M[0] = {r2, 0}; M[1] = {r2, 0}; M[2] = {r2, 0}; M[3] = {-r2, 0}; break;
+    case QMLE_OP_S:
+      M[0] = {1, 0}; M[3] = {0, 1}; break;
+    case QMLE_OP_RX: case QMLE_OP_CRX:  // c I - i s X
+      M[0] = {c, 0}; M[1] = {0, -s}; M[2] = {0, -s}; M[3] = {c, 0}; break;
+    case QMLE_OP_RY: case QMLE_OP_CRY:  // c I - i s Y
+      M[0] = {c, 0}; M[1] = {-s, 0}; M[2] = {s, 0}; M[3] = {c, 0}; break;
+    case QMLE_OP_RZ: case QMLE_OP_CRZ:  // diag(c - i s, c + i s)
+      M[0] = {c, -s}; M[3] = {c, s}; break;
+    case QMLE_OP_CPHASE: {              // diag(1, e^{i phi}) on the target
+      double sp, cp;
+      sincos(th, &sp, &cp);
+      M[0] = {1, 0}; M[3] = {cp, sp}; break;
+    }
+    case QMLE_OP_ROT: {  // RZ(omega) RY(theta) RZ(phi), operations.py:1234-1243
+      const double phi = (double)ang[b.slot[0]], theta = (double)ang[b.slot[1]],
+                   omega = (double)ang[b.slot[2]];
+      double st, ct, sp, cp, sm, cm;
+      sincos(0.5 * theta, &st, &ct);
+      sincos(0.5 * (phi + omega), &sp, &cp);
+      sincos(0.5 * (phi - omega), &sm, &cm);
+      M[0] = {cp * ct, -sp * ct};
+      M[1] = {-cm * st, -sm * st};
+      M[2] = {cm * st, -sm * st};
+      M[3] = {cp * ct, sp * ct};
+      break;
+    }
+    case QMLE_OP_SWAP: case QMLE_OP_CSWAP:
+      M[0] = {1, 0}; M[6] = {1, 0}; M[9] = {1, 0}; M[15] = {1, 0}; break;
+    case QMLE_OP_RXX:  // c I - i s X(x)X : anti-diagonal
+      for (int i = 0; i < 4; ++i) { M[i * 4 + i] = {c, 0}; M[i * 4 + (3 - i)] = {0, -s}; }
+      break;
+    case QMLE_OP_RYY:  // Y(x)Y = antidiag(-1, 1, 1, -1)
+      for (int i = 0; i < 4; ++i) {
+        M[i * 4 + i] = {c, 0};
+        const double sg = (i == 0 || i == 3) ? -1.0 : 1.0;
+        M[i * 4 + (3 - i)] = {0, -s * sg};
+      }
+      break;
+    case QMLE_OP_RZZ:  // diag(e^{-i t/2}, e^{+}, e^{+}, e^{-})
+      M[0] = {c, -s}; M[5] = {c, s}; M[10] = {c, s}; M[15] = {c, -s}; break;
+    case QMLE_OP_RZX:  // Z(x)X = [[X,0],[0,-X]]
+      for (int i = 0; i < 4; ++i) M[i * 4 + i] = {c, 0};
+      M[1] = {0, -s}; M[4] = {0, -s}; M[11] = {0, s}; M[14] = {0, s};
+      break;
+    case QMLE_OP_MAT1: case QMLE_OP_MAT2:
+      for (int i = 0; i < nn; ++i)
+        M[i] = {(double)consts[b.const_off + 2 * i], (double)consts[b.const_off + 2 * i + 1]};
+      break;
+    default:  // identity
+      for (int i = 0; i < dim; ++i) M[i * dim + i] = {1, 0};
+      break;
+  }
+}
+
+__global__ void k_build_matrices(const BuildOp *__restrict__ build,
+                                 const BuildGroup *__restrict__ groups, int n_groups,
+                                 const float *__restrict__ angles, int n_slots,
+                                 const float *__restrict__ consts, float *__restrict__ mats,
+                                 uint32_t mat_floats) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (g >= n_groups) return;
+  const BuildGroup grp = groups[g];
+  const float *ang = angles + (size_t)b * n_slots;
+  const int dim = (int)grp.dim;
+  cd M[16], S[16], R[16];
+  source_matrix(build[grp.begin], ang, consts, M, dim);
+  for (uint32_t k = grp.begin + 1; k < grp.end; ++k) {
+    source_matrix(build[k], ang, consts, S, dim);
+    for (int r = 0; r < dim; ++r)
+      for (int c = 0; c < dim; ++c) {
+        cd acc = {0, 0};
+        for (int x = 0; x < dim; ++x) {
+          const cd t = cdmul(S[r * dim + x], M[x * dim + c]);
+          acc.re += t.re;
+          acc.im += t.im;
+        }
+        R[r * dim + c] = acc;
+      }
+    for (int i = 0; i < dim * dim; ++i) M[i] = R[i];
+  }
+  float *out = mats + (size_t)b * mat_floats + grp.mat_off;
+  for (int i = 0; i < dim * dim; ++i) {
+    out[2 * i] = (float)M[i].re;
+    out[2 * i + 1] = (float)M[i].im;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LDS tile kernel
+// ---------------------------------------------------------------------------
+enum TileMeas : int {
+  TM_STORE = 0,   // write the tile back into the state buffer
+  TM_PROBS = 1,   // write |psi|^2 to out (float)
+  TM_EXPVAL = 2,  // whole-state only: <Z> on obs bits
+};
+
+struct TileArgs {
+  float2 *states;           // [B][2^n] (read unless init_zero; written for TM_STORE)
+  const float *mats;        // [B][mat_floats]
+  const float *angles;      // [B][n_slots]
+  const float *consts;
+  const LoweredOp *ops;     // this stage's ops, tile-local bit positions
+  void *out;                // TM_PROBS: float [B][2^n]; TM_EXPVAL: float [B][n_obs]
+  uint32_t mat_floats;
+  int n_ops, n, T, L, n_slots;
+  int init_zero, meas, n_obs;
+  int8_t tile_bits[QMLE_MAX_QUBITS];
+  int8_t outer_bits[QMLE_MAX_QUBITS];
+  int8_t obs_bits[QMLE_MAX_QUBITS];
+};
+
+__device__ __forceinline__ void sort3(int &a, int &b, int &c) {
+  int t;
+  if (a > b) { t = a; a = b; b = t; }
+  if (b > c) { t = b; b = c; c = t; }
+  if (a > b) { t = a; a = b; b = t; }
+}
+
+// Apply one lowered op to the 2^T amplitudes in LDS.  All threads participate.
+__device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
+                          const float *__restrict__ mrow, const float *__restrict__ consts,
+                          const float *__restrict__ ang) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (op.kind == LK_1Q) {
+    const Mat2 m = load_mat2(mrow + op.mat_off);
+    const uint32_t tb = 1u << op.t0;
+    if (op.nc == 0) {
+      const uint32_t cnt = 1u << (T - 1);
+      if (op.flags & LF_DIAG) {
+        for (uint32_t i = tid; i < cnt; i += nt) {
+          const uint32_t j0 = ins0(i, op.t0), j1 = j0 | tb;
+          s[j0] = cmul(m.m00, s[j0]);
+          s[j1] = cmul(m.m11, s[j1]);
+        }
+      } else {
+        for (uint32_t i = tid; i < cnt; i += nt) {
+          const uint32_t j0 = ins0(i, op.t0), j1 = j0 | tb;
+          float2 a0 = s[j0], a1 = s[j1];
+          apply2(m, a0, a1);
+          s[j0] = a0;
+          s[j1] = a1;
+        }
+      }
+    } else {
+      int p0 = op.t0, p1 = op.c0, p2 = op.nc == 2 ? op.c1 : 127;
+      sort3(p0, p1, p2);
+      const uint32_t cm = (1u << op.c0) | (op.nc == 2 ? (1u << op.c1) : 0u);
+      const uint32_t cnt = 1u << (T - 1 - op.nc);
+      const bool diag = op.flags & LF_DIAG;
+      for (uint32_t i = tid; i < cnt; i += nt) {
+        uint32_t j0 = ins0(ins0(i, p0), p1);
+        if (op.nc == 2) j0 = ins0(j0, p2);
+        j0 |= cm;
+        const uint32_t j1 = j0 | tb;
+        float2 a0 = s[j0], a1 = s[j1];
+        if (diag) {
+          a0 = cmul(m.m00, a0);
+          a1 = cmul(m.m11, a1);
+        } else {
+          apply2(m, a0, a1);
+        }
+        s[j0] = a0;
+        s[j1] = a1;
+      }
+    }
+  } else if (op.kind == LK_2Q) {
+    const float *mm = mrow + op.mat_off;
+    float2 M[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M[i] = make_float2(mm[2 * i], mm[2 * i + 1]);
+    int p0 = op.t0, p1 = op.t1, p2 = op.nc ? op.c0 : 127;
+    sort3(p0, p1, p2);
+    const uint32_t cm = op.nc ? (1u << op.c0) : 0u;
+    const uint32_t b0 = 1u << op.t0, b1 = 1u << op.t1;
+    const uint32_t cnt = 1u << (T - 2 - op.nc);
+    for (uint32_t i = tid; i < cnt; i += nt) {
+      uint32_t j = ins0(ins0(i, p0), p1);
+      if (op.nc) j = ins0(j, p2);
+      j |= cm;
+      const float2 a0 = s[j], a1 = s[j | b1], a2 = s[j | b0], a3 = s[j | b0 | b1];
+      float2 r[4];
+#pragma unroll
+      for (int row = 0; row < 4; ++row) {
+        float2 acc = cmul(M[row * 4 + 0], a0);
+        acc = cfma(M[row * 4 + 1], a1, acc);
+        acc = cfma(M[row * 4 + 2], a2, acc);
+        acc = cfma(M[row * 4 + 3], a3, acc);
+        r[row] = acc;
+      }
+      s[j] = r[0];
+      s[j | b1] = r[1];
+      s[j | b0] = r[2];
+      s[j | b0 | b1] = r[3];
+    }
+  } else {  // LK_DIAG_ALL (whole-state tile only: local index == global index)
+    const float x = ang[op.slot];
+    const float *marks = consts + op.mat_off;
+    const uint32_t cnt = 1u << T;
+    for (uint32_t j = tid; j < cnt; j += nt) {
+      float sn, cs;
+      sincosf(marks[j] * x, &sn, &cs);
+      s[j] = cmul(make_float2(cs, -sn), s[j]);
+    }
+  }
+}
+
+__global__ void k_tile(const TileArgs a) {
+  extern __shared__ float4 smem4[];
+  float2 *s = reinterpret_cast<float2 *>(smem4);
+  const int T = a.T, L = a.L;
+  uint32_t *lut = reinterpret_cast<uint32_t *>(s + (1u << T));
+  float *red = reinterpret_cast<float *>(lut + (1u << (T - L)));
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
+  const size_t D = (size_t)1 << a.n;
+
+  uint64_t base = 0;
+  for (int i = 0; i < a.n - T; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
+  for (uint32_t h = tid; h < (1u << (T - L)); h += nt) {
+    uint32_t v = 0;
+    for (int i = 0; i < T - L; ++i) v |= ((h >> i) & 1u) << a.tile_bits[L + i];
+    lut[h] = v;
+  }
+  __syncthreads();
+
+  const uint32_t half = 1u << (T - 1);
+  const uint32_t lowmask = (1u << L) - 1u;
+  float2 *st = a.states + (size_t)b * D;
+  if (a.init_zero) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t jc = tid; jc < half; jc += nt) reinterpret_cast<float4 *>(s)[jc] = z;
+    __syncthreads();
+    if (tid == 0 && base == 0) s[0] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+  } else {
+    for (uint32_t jc = tid; jc < half; jc += nt) {
+      const uint32_t j = jc * 2u;
+      const uint64_t g = base | lut[j >> L] | (j & lowmask);
+      reinterpret_cast<float4 *>(s)[jc] = *reinterpret_cast<const float4 *>(st + g);
+    }
+  }
+  __syncthreads();
+
+  const float *mrow = a.mats + (size_t)b * a.mat_floats;
+  const float *ang = a.angles + (size_t)b * a.n_slots;
+  for (int k = 0; k < a.n_ops; ++k) {
+    lds_apply(s, T, a.ops[k], mrow, a.consts, ang);
+    __syncthreads();
+  }
+
+  if (a.meas == TM_STORE) {
+    for (uint32_t jc = tid; jc < half; jc += nt) {
+      const uint32_t j = jc * 2u;
+      const uint64_t g = base | lut[j >> L] | (j & lowmask);
+      *reinterpret_cast<float4 *>(st + g) = reinterpret_cast<float4 *>(s)[jc];
+    }
+  } else if (a.meas == TM_PROBS) {
+    float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
+    for (uint32_t jc = tid; jc < half; jc += nt) {
+      const uint32_t j = jc * 2u;
+      const uint64_t g = base | lut[j >> L] | (j & lowmask);
+      const float4 v = reinterpret_cast<float4 *>(s)[jc];
+      *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+    }
+  } else {  // TM_EXPVAL, T == n
+    float *eo = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_obs;
+    const uint32_t cnt = 1u << T;
+    for (int k = 0; k < a.n_obs; ++k) {
+      const int p = a.obs_bits[k];
+      float acc = 0.f;
+      for (uint32_t j = tid; j < cnt; j += nt) {
+        const float pr = norm2(s[j]);
+        acc += ((j >> p) & 1u) ? -pr : pr;
+      }
+      const float tot = block_sum(acc, red);
+      if (tid == 0) eo[k] = tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// direct (HBM-streaming) controlled-2x2 kernel: one float4 = 2 amplitudes per
+// access, partners found by zero-bit insertion; in place.
+//   MODE 0: no control, target bit >= 1      MODE 1: no control, target bit 0
+//   MODE 2: control >= 1, target >= 1        MODE 3: control >= 1, target bit 0
+//   MODE 4: control bit 0, target >= 1
+// ---------------------------------------------------------------------------
+template <int MODE, bool DIAG>
+__global__ void __launch_bounds__(256)
+k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
+            const float *__restrict__ mats, uint32_t mat_floats, uint32_t mat_off,
+            uint64_t items) {
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  float4 *st = states + (size_t)b * chunks;
+  const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < items; k += stride) {
+    if constexpr (MODE == 0) {
+      if constexpr (DIAG) {  // items = all chunks
+        float4 v = st[k];
+        const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+        const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
+        st[k] = make_float4(x.x, x.y, y.x, y.y);
+      } else {
+        const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
+        float4 v0 = st[c0], v1 = st[c1];
+        float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
+        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+        apply2(m, a0, a1);
+        apply2(m, b0, b1);
+        st[c0] = make_float4(a0.x, a0.y, b0.x, b0.y);
+        st[c1] = make_float4(a1.x, a1.y, b1.x, b1.y);
+      }
+    } else if constexpr (MODE == 1) {
+      float4 v = st[k];
+      float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
+      if constexpr (DIAG) {
+        a0 = cmul(m.m00, a0);
+        a1 = cmul(m.m11, a1);
+      } else {
+        apply2(m, a0, a1);
+      }
+      st[k] = make_float4(a0.x, a0.y, a1.x, a1.y);
+    } else if constexpr (MODE == 2) {
+      if constexpr (DIAG) {  // items = chunks with control bit set
+        const uint64_t c = ins0_64(k, pc - 1) | (1ull << (pc - 1));
+        float4 v = st[c];
+        const float2 f = ((c >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+        const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
+        st[c] = make_float4(x.x, x.y, y.x, y.y);
+      } else {
+        const int lo = pt < pc ? pt - 1 : pc - 1, hi = pt < pc ? pc - 1 : pt - 1;
+        const uint64_t c0 = ins0_64(ins0_64(k, lo), hi) | (1ull << (pc - 1));
+        const uint64_t c1 = c0 | (1ull << (pt - 1));
+        float4 v0 = st[c0], v1 = st[c1];
+        float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
+        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+        apply2(m, a0, a1);
+        apply2(m, b0, b1);
+        st[c0] = make_float4(a0.x, a0.y, b0.x, b0.y);
+        st[c1] = make_float4(a1.x, a1.y, b1.x, b1.y);
+      }
+    } else if constexpr (MODE == 3) {
+      const uint64_t c = ins0_64(k, pc - 1) | (1ull << (pc - 1));
+      float4 v = st[c];
+      float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
+      if constexpr (DIAG) {
+        a0 = cmul(m.m00, a0);
+        a1 = cmul(m.m11, a1);
+      } else {
+        apply2(m, a0, a1);
+      }
+      st[c] = make_float4(a0.x, a0.y, a1.x, a1.y);
+    } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
+      if constexpr (DIAG) {  // items = all chunks
+        float4 v = st[k];
+        const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+        const float2 y = cmul(f, make_float2(v.z, v.w));
+        st[k] = make_float4(v.x, v.y, y.x, y.y);
+      } else {
+        const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
+        float4 v0 = st[c0], v1 = st[c1];
+        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+        apply2(m, b0, b1);
+        st[c0] = make_float4(v0.x, v0.y, b0.x, b0.y);
+        st[c1] = make_float4(v1.x, v1.y, b1.x, b1.y);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_diag_all(float4 *__restrict__ states, int n, const float *__restrict__ marks,
+           const float *__restrict__ angles, int n_slots, int slot) {
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  float4 *st = states + (size_t)b * chunks;
+  const float x = angles[(size_t)b * n_slots + slot];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+    float4 v = st[k];
+    float s0, c0, s1, c1;
+    sincosf(marks[2 * k] * x, &s0, &c0);
+    sincosf(marks[2 * k + 1] * x, &s1, &c1);
+    const float2 a = cmul(make_float2(c0, -s0), make_float2(v.x, v.y));
+    const float2 c = cmul(make_float2(c1, -s1), make_float2(v.z, v.w));
+    st[k] = make_float4(a.x, a.y, c.x, c.y);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_init_zero(float4 *__restrict__ states, int n) {
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  float4 *st = states + (size_t)b * chunks;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride)
+    st[k] = make_float4(k == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// all-qubit <Z> in one read.  Element index bits: bit0 = position inside the
+// float4 chunk, bits 1..8 = thread id, bits 9..10 = unroll slot u, bits >= 11 =
+// segment id.  Every bit gets its own signed accumulator (static indexing).
+// ---------------------------------------------------------------------------
+constexpr int kEzThreads = 256;
+constexpr int kEzUnroll = 4;
+constexpr int kEzSegBits = 11;  // 1 + 8 + 2
+constexpr int kEzMaxHigh = QMLE_MAX_QUBITS - kEzSegBits;
+
+__global__ void __launch_bounds__(kEzThreads)
+k_expval_partial(const float4 *__restrict__ states, int n, float *__restrict__ partial) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *st = states + (size_t)b * chunks;
+  const uint64_t seg_chunks = (uint64_t)kEzThreads * kEzUnroll;
+  const uint64_t n_seg = (chunks + seg_chunks - 1) / seg_chunks;
+  float acc_tot = 0.f, acc_b0 = 0.f, acc_u0 = 0.f, acc_u1 = 0.f;
+  float acc_hi[kEzMaxHigh];
+#pragma unroll
+  for (int k = 0; k < kEzMaxHigh; ++k) acc_hi[k] = 0.f;
+  for (uint64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+    float4 v[kEzUnroll];
+#pragma unroll
+    for (int u = 0; u < kEzUnroll; ++u) {
+      const uint64_t c = seg * seg_chunks + (uint64_t)u * kEzThreads + tid;
+      v[u] = c < chunks ? st[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float pe = 0.f, po = 0.f, pu[kEzUnroll];
+#pragma unroll
+    for (int u = 0; u < kEzUnroll; ++u) {
+      const float e = v[u].x * v[u].x + v[u].y * v[u].y;
+      const float o = v[u].z * v[u].z + v[u].w * v[u].w;
+      pe += e;
+      po += o;
+      pu[u] = e + o;
+    }
+    const float tot = pe + po;
+    acc_tot += tot;
+    acc_b0 += pe - po;
+    acc_u0 += (pu[0] - pu[1]) + (pu[2] - pu[3]);
+    acc_u1 += (pu[0] + pu[1]) - (pu[2] + pu[3]);
+#pragma unroll
+    for (int k = 0; k < kEzMaxHigh; ++k) acc_hi[k] += ((seg >> k) & 1ull) ? -tot : tot;
+  }
+  // partial[b][block][bit]; bit n is the plain total (norm check)
+  float *out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (QMLE_MAX_QUBITS + 1);
+  float r;
+  r = block_sum(acc_b0, red);
+  if (tid == 0) out[0] = r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r = block_sum(((tid >> i) & 1) ? -acc_tot : acc_tot, red);
+    if (tid == 0) out[1 + i] = r;
+  }
+  r = block_sum(acc_u0, red);
+  if (tid == 0) out[9] = r;
+  r = block_sum(acc_u1, red);
+  if (tid == 0) out[10] = r;
+#pragma unroll
+  for (int k = 0; k < kEzMaxHigh; ++k) {
+    r = block_sum(acc_hi[k], red);
+    if (tid == 0) out[kEzSegBits + k] = r;
+  }
+  r = block_sum(acc_tot, red);
+  if (tid == 0) out[QMLE_MAX_QUBITS] = r;
+}
+
+struct ObsBits {
+  int8_t bits[QMLE_MAX_QUBITS];
+};
+
+__global__ void k_expval_final(const float *__restrict__ partial, int n_blocks, int n_obs,
+                               ObsBits obs, float *__restrict__ out) {
+  const int b = blockIdx.x;
+  const int k = threadIdx.x;
+  if (k >= n_obs) return;
+  const int bitp = obs.bits[k];
+  double acc = 0.0;
+  const float *pp = partial + (size_t)b * n_blocks * (QMLE_MAX_QUBITS + 1);
+  for (int i = 0; i < n_blocks; ++i) acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1) + bitp];
+  out[(size_t)b * n_obs + k] = (float)acc;
+}
+
+// ---------------------------------------------------------------------------
+// simple streaming kernels
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_probs(const float4 *__restrict__ states, float2 *__restrict__ out, uint64_t total_chunks) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total_chunks; k += stride) {
+    const float4 v = states[k];
+    out[k] = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_density(const float2 *__restrict__ states, float2 *__restrict__ out, int n) {
+  const int b = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const float2 *st = states + (size_t)b * D;
+  float2 *o = out + (size_t)b * D * D;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < D * D; k += stride) {
+    const uint64_t i = k >> n, j = k & (D - 1);
+    const float2 a = st[i], c = st[j];
+    o[k] = make_float2(a.x * c.x + a.y * c.y, a.y * c.x - a.x * c.y);  // a * conj(c)
+  }
+}
+
+struct KeepBits {
+  int8_t bits[QMLE_MAX_QUBITS];  // bit positions of kept wires, LSB of output first
+  int n_keep;
+};
+
+__global__ void __launch_bounds__(256)
+k_marginal(const float2 *__restrict__ states, float *__restrict__ out, int n, KeepBits kb) {
+  const int b = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const float2 *st = states + (size_t)b * D;
+  float *o = out + ((size_t)b << kb.n_keep);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += stride) {
+    uint32_t idx = 0;
+    for (int k = 0; k < kb.n_keep; ++k) idx |= (uint32_t)((i >> kb.bits[k]) & 1ull) << k;
+    atomicAdd(o + idx, norm2(st[i]));
+  }
+}
+
+// <a|b> partial sums: partial[pair][block] = (re, im)
+__global__ void __launch_bounds__(256)
+k_overlap_partial(const float4 *__restrict__ states, int n, int n_pairs,
+                  float2 *__restrict__ partial) {
+  __shared__ float red[16];
+  const int pr = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *a = states + (size_t)pr * chunks;
+  const float4 *c = states + ((size_t)pr + n_pairs) * chunks;
+  float re = 0.f, im = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+    const float4 x = a[k], y = c[k];
+    // conj(x) * y
+    re += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    im += x.x * y.y - x.y * y.x + x.z * y.w - x.w * y.z;
+  }
+  const float r = block_sum(re, red);
+  const float i = block_sum(im, red);
+  if (threadIdx.x == 0) partial[(size_t)pr * gridDim.x + blockIdx.x] = make_float2(r, i);
+}
+
+__global__ void k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
+                                float *__restrict__ out) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= n_pairs) return;
+  double re = 0.0, im = 0.0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const float2 v = partial[(size_t)pr * n_blocks + i];
+    re += v.x;
+    im += v.y;
+  }
+  out[pr] = (float)(re * re + im * im);
+}
+
+// Meyer-Wallach cross terms c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) plus the
+// populations a_j, d_j; one launch per bit (v1: n reads of the state).
+// partial[b][bit][block] = (re c, im c, a, d)
+__global__ void __launch_bounds__(256)
+k_cross_partial(const float4 *__restrict__ states, int n, int p, float4 *__restrict__ partial,
+                int n_blocks) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *st = states + (size_t)b * chunks;
+  float cr = 0.f, ci = 0.f, pa = 0.f, pd = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  if (p == 0) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+      const float4 v = st[k];
+      cr += v.x * v.z + v.y * v.w;
+      ci += v.y * v.z - v.x * v.w;
+      pa += v.x * v.x + v.y * v.y;
+      pd += v.z * v.z + v.w * v.w;
+    }
+  } else {
+    const uint64_t items = chunks >> 1;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < items; k += stride) {
+      const uint64_t c0 = ins0_64(k, p - 1), c1 = c0 | (1ull << (p - 1));
+      const float4 x = st[c0], y = st[c1];
+      cr += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      ci += x.y * y.x - x.x * y.y + x.w * y.z - x.z * y.w;
+      pa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      pd += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    }
+  }
+  const float r0 = block_sum(cr, red), r1 = block_sum(ci, red), r2 = block_sum(pa, red),
+              r3 = block_sum(pd, red);
+  if (threadIdx.x == 0)
+    partial[((size_t)b * n + p) * n_blocks + blockIdx.x] = make_float4(r0, r1, r2, r3);
+}
+
+__global__ void k_mw_final(const float4 *__restrict__ partial, int n, int n_blocks, int batch,
+                           float *__restrict__ out, float *__restrict__ purities) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double sum = 0.0;
+  for (int p = 0; p < n; ++p) {
+    double cr = 0, ci = 0, a = 0, d = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+      const float4 v = partial[((size_t)b * n + p) * n_blocks + i];
+      cr += v.x; ci += v.y; a += v.z; d += v.w;
+    }
+    const double pur = a * a + d * d + 2.0 * (cr * cr + ci * ci);
+    if (purities) purities[(size_t)b * n + (n - 1 - p)] = (float)pur;  // index by wire
+    sum += pur;
+  }
+  out[b] = (float)(2.0 * (1.0 - sum / n));
+}
+
+__global__ void __launch_bounds__(256)
+k_histogram(const float *__restrict__ values, int64_t count, int n_bins, float lo, float hi,
+            int *__restrict__ counts) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float scale = (float)n_bins / (hi - lo);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const float v = values[i];
+    if (!(v >= lo) || !(v <= hi)) continue;  // numpy drops out-of-range and NaN
+    int bin = (int)((v - lo) * scale);
+    if (bin >= n_bins) bin = n_bins - 1;     // right edge inclusive
+    // guard against rounding across an edge: edges are lo + k*(hi-lo)/n_bins
+    const float w = (hi - lo) / (float)n_bins;
+    if (bin > 0 && v < lo + bin * w) --bin;
+    else if (bin < n_bins - 1 && v >= lo + (bin + 1) * w) ++bin;
+    atomicAdd(counts + bin, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline unsigned grid_for(uint64_t items, unsigned block, unsigned cap = 2048u * 4u) {
+  uint64_t g = (items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+int ensure_device_plan(qmle_plan *p) {
+  if (p->dev.blob) return QMLE_OK;
+  const size_t b_ops = align_up(p->dev_ops.size() * sizeof(LoweredOp) + 16, 256);
+  const size_t b_build = align_up(p->build_ops.size() * sizeof(BuildOp) + 16, 256);
+  const size_t b_groups = align_up(p->groups.size() * sizeof(BuildGroup) + 16, 256);
+  const size_t b_consts = align_up(p->consts.size() * sizeof(float) + 16, 256);
+  const size_t total = b_ops + b_build + b_groups + b_consts;
+  char *blob = nullptr;
+  HIPCHK(hipMalloc((void **)&blob, total));
+  p->dev.blob = blob;
+  p->dev.blob_bytes = total;
+  p->dev.d_ops = (LoweredOp *)blob;
+  p->dev.d_build = (BuildOp *)(blob + b_ops);
+  p->dev.d_groups = (BuildGroup *)(blob + b_ops + b_build);
+  p->dev.d_consts = (float *)(blob + b_ops + b_build + b_groups);
+  if (!p->dev_ops.empty())
+    HIPCHK(hipMemcpy(p->dev.d_ops, p->dev_ops.data(), p->dev_ops.size() * sizeof(LoweredOp),
+                     hipMemcpyHostToDevice));
+  if (!p->build_ops.empty())
+    HIPCHK(hipMemcpy(p->dev.d_build, p->build_ops.data(),
+                     p->build_ops.size() * sizeof(BuildOp), hipMemcpyHostToDevice));
+  if (!p->groups.empty())
+    HIPCHK(hipMemcpy(p->dev.d_groups, p->groups.data(), p->groups.size() * sizeof(BuildGroup),
+                     hipMemcpyHostToDevice));
+  if (!p->consts.empty())
+    HIPCHK(hipMemcpy(p->dev.d_consts, p->consts.data(), p->consts.size() * sizeof(float),
+                     hipMemcpyHostToDevice));
+  return QMLE_OK;
+}
+
+size_t tile_lds_bytes(int T, int L) {
+  return ((size_t)8 << T) + ((size_t)4 << (T - L)) + 64 * sizeof(float);
+}
+
+int tile_threads(int T) {
+  if (T >= 14) return 1024;
+  if (T >= 13) return 512;
+  if (T >= 9) return 256;
+  if (T >= 7) return 64;
+  return 64;
+}
+
+int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
+                const float *angles, int batch, bool init_zero, int meas, void *out,
+                const int8_t *obs_bits, int n_obs, hipStream_t stream) {
+  TileArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.states = states;
+  a.mats = mats;
+  a.angles = angles;
+  a.consts = p->dev.d_consts;
+  a.ops = p->dev.d_ops + st.op_begin;
+  a.out = out;
+  a.mat_floats = p->mat_floats;
+  a.n_ops = st.op_end - st.op_begin;
+  a.n = p->n;
+  a.T = st.T;
+  a.L = st.L;
+  a.n_slots = p->n_slots;
+  a.init_zero = init_zero ? 1 : 0;
+  a.meas = meas;
+  a.n_obs = n_obs;
+  std::memcpy(a.tile_bits, st.tile_bits, sizeof(a.tile_bits));
+  std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
+  if (obs_bits) std::memcpy(a.obs_bits, obs_bits, (size_t)n_obs);
+  const size_t lds = tile_lds_bytes(st.T, st.L);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    attr_set = true;
+  }
+  const unsigned tiles = 1u << (p->n - st.T);
+  dim3 grid(tiles, (unsigned)batch);
+  hipLaunchKernelGGL(k_tile, grid, dim3(tile_threads(st.T)), lds, stream, a);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+template <int MODE>
+void launch_direct_mode(bool diag, dim3 grid, hipStream_t stream, float4 *st, int n, int pt,
+                        int pc, const float *mats, uint32_t mat_floats, uint32_t mat_off,
+                        uint64_t items) {
+  if (diag)
+    hipLaunchKernelGGL((k_direct_1q<MODE, true>), grid, dim3(256), 0, stream, st, n, pt, pc, mats,
+                       mat_floats, mat_off, items);
+  else
+    hipLaunchKernelGGL((k_direct_1q<MODE, false>), grid, dim3(256), 0, stream, st, n, pt, pc,
+                       mats, mat_floats, mat_off, items);
+}
+
+int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const float *mats,
+                  int batch, hipStream_t stream) {
+  const int n = p->n;
+  const bool diag = op.flags & LF_DIAG;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const int pt = op.t0, pc = op.c0;
+  int mode;
+  uint64_t items;
+  if (op.nc == 0) {
+    if (pt >= 1) { mode = 0; items = diag ? chunks : chunks >> 1; }
+    else { mode = 1; items = chunks; }
+  } else {
+    if (pc >= 1 && pt >= 1) { mode = 2; items = diag ? chunks >> 1 : chunks >> 2; }
+    else if (pt == 0) { mode = 3; items = chunks >> 1; }
+    else { mode = 4; items = diag ? chunks : chunks >> 1; }
+  }
+  if (items == 0) items = 1;  // n too small for this mode cannot happen (validated)
+  dim3 grid(grid_for(items, 256), (unsigned)batch);
+  float4 *st = reinterpret_cast<float4 *>(states);
+  switch (mode) {
+    case 0: launch_direct_mode<0>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 1: launch_direct_mode<1>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 2: launch_direct_mode<2>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 3: launch_direct_mode<3>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    default: launch_direct_mode<4>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+  }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int expval_blocks(int n) {
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const uint64_t seg = (uint64_t)kEzThreads * kEzUnroll;
+  uint64_t n_seg = (chunks + seg - 1) / seg;
+  if (n_seg > 2048) n_seg = 2048;
+  return (int)n_seg;
+}
+
+int run_expval(const float2 *states, int n, int batch, const int32_t *obs_wires, int n_obs,
+               float *d_out, void *ws, size_t ws_bytes, hipStream_t stream) {
+  if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
+  const int nb = expval_blocks(n);
+  const size_t need = (size_t)batch * nb * (QMLE_MAX_QUBITS + 1) * sizeof(float);
+  if (ws_bytes < need) return QMLE_ERR_WORKSPACE;
+  ObsBits ob;
+  for (int k = 0; k < n_obs; ++k) {
+    if (obs_wires[k] < 0 || obs_wires[k] >= n) return QMLE_ERR_WIRE_RANGE;
+    ob.bits[k] = (int8_t)(n - 1 - obs_wires[k]);
+  }
+  hipLaunchKernelGGL(k_expval_partial, dim3(nb, batch), dim3(kEzThreads), 0, stream,
+                     reinterpret_cast<const float4 *>(states), n, (float *)ws);
+  hipLaunchKernelGGL(k_expval_final, dim3(batch), dim3(QMLE_MAX_QUBITS), 0, stream,
+                     (const float *)ws, nb, n_obs, ob, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int qmle_sv_version(void) { return QMLE_SV_VERSION; }
+
+const char *qmle_status_string(int status) {
+  switch (status) {
+    case QMLE_OK: return "ok";
+    case QMLE_ERR_INVALID_ARG: return "invalid argument";
+    case QMLE_ERR_WIRE_COUNT: return "wrong number of wires for gate";
+    case QMLE_ERR_DUPLICATE_WIRES: return "duplicate wires";
+    case QMLE_ERR_WIRE_RANGE: return "wire index out of range";
+    case QMLE_ERR_UNKNOWN_OP: return "unknown opcode";
+    case QMLE_ERR_MEAS_TYPE: return "unknown measurement type";
+    case QMLE_ERR_WORKSPACE: return "workspace too small";
+    case QMLE_ERR_HIP: return "HIP runtime error";
+    case QMLE_ERR_NO_DEVICE: return "no HIP device";
+    case QMLE_ERR_UNSUPPORTED: return "unsupported configuration";
+    case QMLE_ERR_SLOT_RANGE: return "angle slot out of range";
+    default: return "unknown status";
+  }
+}
+
+int qmle_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
+                     const float *consts, int n_consts, unsigned flags, qmle_plan **out) {
+  if (!out || n_ops < 0 || n_slots < 0 || n_consts < 0 || (n_ops > 0 && !ops))
+    return QMLE_ERR_INVALID_ARG;
+  *out = nullptr;
+  qmle_plan *p = new (std::nothrow) qmle_plan();
+  if (!p) return QMLE_ERR_INVALID_ARG;
+  p->n = n_qubits;
+  p->n_slots = n_slots;
+  p->flags = flags;
+  p->ops.assign(ops, ops + n_ops);
+  if (n_consts > 0) p->consts.assign(consts, consts + n_consts);
+  const int rc = compile_plan(p);
+  if (rc != QMLE_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return QMLE_OK;
+}
+
+int qmle_plan_destroy(qmle_plan *plan) {
+  if (!plan) return QMLE_OK;
+  if (plan->dev.blob) (void)hipFree(plan->dev.blob);
+  delete plan;
+  return QMLE_OK;
+}
+
+int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap) {
+  if (!plan) return QMLE_ERR_INVALID_ARG;
+  const std::string s = describe_plan(plan);
+  if (buf && cap > 0) {
+    const size_t nc = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), nc);
+    buf[nc] = 0;
+  }
+  return (int)s.size();
+}
+
+int qmle_plan_stats(const qmle_plan *plan, int64_t stats[8]) {
+  if (!plan || !stats) return QMLE_ERR_INVALID_ARG;
+  int direct = 0;
+  for (const Stage &s : plan->stages) direct += s.kind == ST_DIRECT;
+  stats[0] = (int64_t)plan->ops.size();
+  stats[1] = (int64_t)plan->stages.size();
+  stats[2] = plan->whole_state_lds ? 1 : 0;
+  stats[3] = plan->tile_T;
+  stats[4] = plan->mat_floats;
+  stats[5] = direct;
+  stats[6] = (int64_t)plan->lowered.size();
+  stats[7] = (int64_t)plan->algo_bytes_per_state;
+  return QMLE_OK;
+}
+
+// workspace layout: [matrices: batch * mat_floats] [states: S * D (if needed)]
+//                   [expval partials]
+static size_t ws_mats_bytes(const qmle_plan *p, int batch) {
+  return align_up((size_t)batch * (p->mat_floats ? p->mat_floats : 1) * sizeof(float), 256);
+}
+
+static int default_states_in_flight(const qmle_plan *p, int batch) {
+  // keep the in-flight working set near the 256 MiB Infinity Cache
+  const size_t sb = (size_t)8 << p->n;
+  size_t s = ((size_t)192 << 20) / sb;
+  if (s < 1) s = 1;
+  if (s > (size_t)batch) s = (size_t)batch;
+  return (int)s;
+}
+
+size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int n_obs,
+                            int states_in_flight) {
+  (void)n_obs;
+  if (!plan || batch < 1) return 0;
+  size_t total = ws_mats_bytes(plan, batch);
+  const size_t sb = (size_t)8 << plan->n;
+  const bool lds_direct_meas =
+      plan->whole_state_lds && (meas_type == QMLE_MEAS_PROBS || meas_type == QMLE_MEAS_EXPVAL_Z);
+  if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
+    int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
+    if (s > batch) s = batch;
+    total += align_up((size_t)s * sb, 256);
+    if (meas_type == QMLE_MEAS_EXPVAL_Z)
+      total += align_up((size_t)s * expval_blocks(plan->n) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+  }
+  return total + 256;
+}
+
+int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                   const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
+                   size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || !d_out || !d_workspace) return QMLE_ERR_INVALID_ARG;
+  if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_DENSITY) return QMLE_ERR_MEAS_TYPE;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int n = plan->n;
+  int8_t obs_bits[QMLE_MAX_QUBITS];
+  if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+    if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !obs_wires) return QMLE_ERR_INVALID_ARG;
+    for (int k = 0; k < n_obs; ++k) {
+      if (obs_wires[k] < 0 || obs_wires[k] >= n) return QMLE_ERR_WIRE_RANGE;
+      obs_bits[k] = (int8_t)(n - 1 - obs_wires[k]);
+    }
+  }
+  int rc = ensure_device_plan(plan);
+  if (rc != QMLE_OK) return rc;
+
+  char *ws = (char *)d_workspace;
+  {
+    const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+    ws += mis;
+    if (workspace_bytes < mis) return QMLE_ERR_WORKSPACE;
+    workspace_bytes -= mis;
+  }
+  const size_t mats_b = ws_mats_bytes(plan, batch);
+  if (workspace_bytes < mats_b) return QMLE_ERR_WORKSPACE;
+  float *d_mats = (float *)ws;
+  ws += mats_b;
+  workspace_bytes -= mats_b;
+
+  // per-sample gate matrices for the whole batch (tiny)
+  if (!plan->groups.empty()) {
+    const int ng = (int)plan->groups.size();
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+      const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
+      hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, bc), dim3(64), 0, stream,
+                         plan->dev.d_build, plan->dev.d_groups, ng,
+                         d_angles + (size_t)b0 * plan->n_slots, plan->n_slots,
+                         plan->dev.d_consts, d_mats + (size_t)b0 * plan->mat_floats,
+                         plan->mat_floats);
+    }
+    HIPCHK(hipGetLastError());
+  }
+
+  const size_t D = (size_t)1 << n;
+  const size_t sb = D * sizeof(float2);
+
+  // ---- whole state in LDS: one launch does simulate + measure ------------------
+  if (plan->whole_state_lds) {
+    const Stage &st = plan->stages[0];
+    if (meas_type == QMLE_MEAS_STATE || meas_type == QMLE_MEAS_PROBS ||
+        meas_type == QMLE_MEAS_EXPVAL_Z) {
+      for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
+        const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
+        const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
+        if (meas_type == QMLE_MEAS_STATE)
+          rc = launch_tile(plan, st, (float2 *)d_out + (size_t)b0 * D, mats, ang, bc, true,
+                           TM_STORE, nullptr, nullptr, 0, stream);
+        else if (meas_type == QMLE_MEAS_PROBS)
+          rc = launch_tile(plan, st, nullptr, mats, ang, bc, true, TM_PROBS,
+                           (float *)d_out + (size_t)b0 * D, nullptr, 0, stream);
+        else
+          rc = launch_tile(plan, st, nullptr, mats, ang, bc, true, TM_EXPVAL,
+                           (float *)d_out + (size_t)b0 * n_obs, obs_bits, n_obs, stream);
+        if (rc != QMLE_OK) return rc;
+      }
+      return QMLE_OK;
+    }
+  }
+
+  // ---- general path: states resident in HBM, sample-major chunks ----------------
+  float2 *d_states;
+  int in_flight;
+  if (meas_type == QMLE_MEAS_STATE) {
+    d_states = (float2 *)d_out;
+    in_flight = default_states_in_flight(plan, batch);  // sample-major: stay cache-resident
+  } else {
+    in_flight = (int)(workspace_bytes / (sb + (meas_type == QMLE_MEAS_EXPVAL_Z
+                          ? (size_t)expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float) + 256
+                          : 0) + 256));
+    if (in_flight < 1) return QMLE_ERR_WORKSPACE;
+    if (in_flight > batch) in_flight = batch;
+    const int dflt = default_states_in_flight(plan, batch);
+    if (in_flight > dflt) in_flight = dflt;
+    d_states = (float2 *)ws;
+    ws += align_up((size_t)in_flight * sb, 256);
+  }
+  if (in_flight > 65535) in_flight = 65535;
+  void *d_partial = ws;
+  const size_t partial_bytes =
+      (size_t)in_flight * expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float);
+
+  for (int b0 = 0; b0 < batch; b0 += in_flight) {
+    const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
+    float2 *stc = meas_type == QMLE_MEAS_STATE ? d_states + (size_t)b0 * D : d_states;
+    const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
+    const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
+    bool initialised = false;
+    for (size_t si = 0; si < plan->stages.size(); ++si) {
+      const Stage &st = plan->stages[si];
+      if (st.kind == ST_TILE) {
+        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, TM_STORE, nullptr, nullptr,
+                         0, stream);
+        initialised = true;
+      } else {
+        if (!initialised) {
+          hipLaunchKernelGGL(k_init_zero, dim3(grid_for(D / 2, 256), bc), dim3(256), 0, stream,
+                             reinterpret_cast<float4 *>(stc), n);
+          initialised = true;
+        }
+        if (st.kind == ST_DIRECT) {
+          rc = launch_direct(plan, plan->dev_ops[st.op_begin], stc, mats, bc, stream);
+        } else {
+          const LoweredOp &o = plan->dev_ops[st.op_begin];
+          hipLaunchKernelGGL(k_diag_all, dim3(grid_for(D / 2, 256), bc), dim3(256), 0, stream,
+                             reinterpret_cast<float4 *>(stc), n, plan->dev.d_consts + o.mat_off,
+                             ang, plan->n_slots, o.slot);
+          rc = QMLE_OK;
+        }
+      }
+      if (rc != QMLE_OK) return rc;
+    }
+    if (!initialised)
+      hipLaunchKernelGGL(k_init_zero, dim3(grid_for(D / 2, 256), bc), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(stc), n);
+    // measure this chunk
+    if (meas_type == QMLE_MEAS_PROBS) {
+      const uint64_t tc = (uint64_t)bc * (D / 2);
+      hipLaunchKernelGGL(k_probs, dim3(grid_for(tc, 256)), dim3(256), 0, stream,
+                         reinterpret_cast<const float4 *>(stc),
+                         reinterpret_cast<float2 *>((float *)d_out + (size_t)b0 * D), tc);
+    } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+      rc = run_expval(stc, n, bc, obs_wires, n_obs, (float *)d_out + (size_t)b0 * n_obs, d_partial,
+                      partial_bytes, stream);
+      if (rc != QMLE_OK) return rc;
+    } else if (meas_type == QMLE_MEAS_DENSITY) {
+      if (n > 15) return QMLE_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256), bc), dim3(256), 0, stream, stc,
+                         (float2 *)d_out + (size_t)b0 * D * D, n);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return QMLE_OK;
+}
+
+size_t qmle_expval_workspace_bytes(int n_qubits, int batch) {
+  if (n_qubits < 1 || batch < 1) return 0;
+  return (size_t)batch * expval_blocks(n_qubits) * (QMLE_MAX_QUBITS + 1) * sizeof(float) + 256;
+}
+
+int qmle_expval_z(const void *d_states, int n_qubits, int batch, const int32_t *obs_wires,
+                  int n_obs, float *d_out, void *d_workspace, size_t workspace_bytes,
+                  qmle_stream stream) {
+  if (!d_states || !d_out || !d_workspace || !obs_wires || n_qubits < 1 ||
+      n_qubits > QMLE_MAX_QUBITS || batch < 1 || batch > 65535)
+    return QMLE_ERR_INVALID_ARG;
+  return run_expval((const float2 *)d_states, n_qubits, batch, obs_wires, n_obs, d_out,
+                    d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qmle_probs(const void *d_states, int n_qubits, int batch, float *d_out, qmle_stream stream) {
+  if (!d_states || !d_out || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS || batch < 1)
+    return QMLE_ERR_INVALID_ARG;
+  const uint64_t tc = (uint64_t)batch << (n_qubits - 1);
+  hipLaunchKernelGGL(k_probs, dim3(grid_for(tc, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4 *)d_states, (float2 *)d_out, tc);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_density(const void *d_states, int n_qubits, int batch, void *d_out, qmle_stream stream) {
+  if (!d_states || !d_out || n_qubits < 1 || batch < 1 || batch > 65535) return QMLE_ERR_INVALID_ARG;
+  if (n_qubits > 15) return QMLE_ERR_UNSUPPORTED;
+  const uint64_t D = (uint64_t)1 << n_qubits;
+  hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256), batch), dim3(256), 0,
+                     (hipStream_t)stream, (const float2 *)d_states, (float2 *)d_out, n_qubits);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_marginal_probs(const void *d_states, int n_qubits, int batch, const int32_t *keep_wires,
+                        int n_keep, float *d_out, qmle_stream stream_) {
+  if (!d_states || !d_out || !keep_wires || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
+      batch < 1 || batch > 65535 || n_keep < 1 || n_keep > n_qubits || n_keep > 24)
+    return QMLE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  // kept wires stay in ascending wire order regardless of `keep` order
+  // (jaqsi.py:141-146): output bit k (LSB first) <- the k-th LARGEST wire.
+  uint64_t mask = 0;
+  for (int k = 0; k < n_keep; ++k) {
+    if (keep_wires[k] < 0 || keep_wires[k] >= n_qubits) return QMLE_ERR_WIRE_RANGE;
+    if (mask & (1ull << keep_wires[k])) return QMLE_ERR_DUPLICATE_WIRES;
+    mask |= 1ull << keep_wires[k];
+  }
+  KeepBits kb;
+  kb.n_keep = n_keep;
+  int k = 0;
+  for (int w = n_qubits - 1; w >= 0; --w)
+    if (mask & (1ull << w)) kb.bits[k++] = (int8_t)(n_qubits - 1 - w);
+  HIPCHK(hipMemsetAsync(d_out, 0, ((size_t)batch << n_keep) * sizeof(float), stream));
+  const uint64_t D = (uint64_t)1 << n_qubits;
+  hipLaunchKernelGGL(k_marginal, dim3(grid_for(D, 256), batch), dim3(256), 0, stream,
+                     (const float2 *)d_states, d_out, n_qubits, kb);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+static int overlap_blocks(int n) {
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  uint64_t b = (chunks + 256 * 4 - 1) / (256 * 4);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+size_t qmle_pair_fidelity_workspace_bytes(int n_qubits, int n_pairs) {
+  if (n_qubits < 1 || n_pairs < 1) return 0;
+  return (size_t)n_pairs * overlap_blocks(n_qubits) * sizeof(float2) + 256;
+}
+
+int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d_out,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!d_states || !d_out || !d_workspace || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
+      n_pairs < 1)
+    return QMLE_ERR_INVALID_ARG;
+  const int nb = overlap_blocks(n_qubits);
+  if (workspace_bytes < (size_t)n_pairs * nb * sizeof(float2)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint64_t chunks = (uint64_t)1 << (n_qubits - 1);
+  for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
+    const int pc = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
+    // pairs (i, i + n_pairs): shift both halves by p0
+    hipLaunchKernelGGL(k_overlap_partial, dim3(nb, pc), dim3(256), 0, stream,
+                       (const float4 *)d_states + (size_t)p0 * chunks, n_qubits, n_pairs,
+                       (float2 *)d_workspace + (size_t)p0 * nb);
+  }
+  hipLaunchKernelGGL(k_overlap_final, dim3((n_pairs + 255) / 256), dim3(256), 0, stream,
+                     (const float2 *)d_workspace, nb, n_pairs, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch) {
+  if (n_qubits < 1 || batch < 1) return 0;
+  return (size_t)batch * n_qubits * overlap_blocks(n_qubits) * sizeof(float4) + 256;
+}
+
+int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_out,
+                       float *d_purities, void *d_workspace, size_t workspace_bytes,
+                       qmle_stream stream_) {
+  if (!d_states || !d_out || !d_workspace || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
+      batch < 1 || batch > 65535)
+    return QMLE_ERR_INVALID_ARG;
+  const int nb = overlap_blocks(n_qubits);
+  if (workspace_bytes < (size_t)batch * n_qubits * nb * sizeof(float4)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int p = 0; p < n_qubits; ++p)
+    hipLaunchKernelGGL(k_cross_partial, dim3(nb, batch), dim3(256), 0, stream,
+                       (const float4 *)d_states, n_qubits, p, (float4 *)d_workspace, nb);
+  hipLaunchKernelGGL(k_mw_final, dim3((batch + 63) / 64), dim3(64), 0, stream,
+                     (const float4 *)d_workspace, n_qubits, nb, batch, d_out, d_purities);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_histogram(const float *d_values, int64_t count, int n_bins, float lo, float hi,
+                   int32_t *d_counts, qmle_stream stream_) {
+  if (!d_values || !d_counts || count < 0 || n_bins < 1 || !(hi > lo)) return QMLE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)n_bins * sizeof(int32_t), stream));
+  if (count > 0)
+    hipLaunchKernelGGL(k_histogram, dim3(grid_for((uint64_t)count, 256, 1024)), dim3(256), 0,
+                       stream, d_values, count, n_bins, lo, hi, d_counts);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""CPU-only: the C-ABI library loads, exports every declared symbol, and the
+host-side plan compiler validates / schedules tapes (no compute without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from qml_essentials_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    lib = N.lib()
+    assert lib.qmle_sv_version() == 100
+    header = open(os.path.join(ROOT, "include", "qmle_sv.h")).read()
+    declared = set(re.findall(r"\b(qmle_[a-z_]+)\s*\(", header))
+    declared -= {"qmle_op", "qmle_plan"}
+    bound = {name for name, _, _ in N.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_header_opcodes_match_binding():
+    header = open(os.path.join(ROOT, "include", "qmle_sv.h")).read()
+    codes = dict(re.findall(r"QMLE_OP_([A-Z0-9_]+) = (\d+)", header))
+    pairs = {"RX": "RX", "RY": "RY", "RZ": "RZ", "ROT": "Rot", "CX": "CX", "CRX": "CRX",
+             "CPHASE": "CPhase", "CCX": "CCX", "CSWAP": "CSWAP", "DIAG_ALL": "DIAG_ALL",
+             "H": "H", "X": "PauliX", "Z": "PauliZ", "SWAP": "SWAP", "RZX": "RZX"}
+    for h, p in pairs.items():
+        assert int(codes[h]) == N.OPCODES[p]
+
+
+def test_plan_validation_errors_map_to_valueerror():
+    # operations.py:140-146: wrong wire count / duplicate wires -> ValueError
+    with pytest.raises(ValueError, match="wires"):
+        N.Plan([("CX", [0], [], -1)], 2, 0)
+    with pytest.raises(ValueError, match="duplicate"):
+        N.Plan([("CX", [1, 1], [], -1)], 2, 0)
+    with pytest.raises(ValueError, match="range"):
+        N.Plan([("RX", [3], [0], -1)], 2, 1)
+    with pytest.raises(ValueError, match="slot"):
+        N.Plan([("RX", [0], [2], -1)], 2, 1)
+    with pytest.raises(ValueError):
+        N.Plan([("Nope", [0], [], -1)], 2, 0)
+
+
+def he_layer_ops(n):
+    ops, slot = [], 0
+    for g in ("RY", "RZ", "RY"):
+        for q in range(n):
+            ops.append((g, [q], [slot], -1))
+            slot += 1
+    from oracle.circuits import bricks
+    for c, t in bricks(n, mirror=False) + bricks(n, offset=-1, modulo=True, wrap=True, mirror=False):
+        ops.append(("CX", [c, t], [], -1))
+    return ops, slot
+
+
+def test_small_circuit_runs_whole_state_in_lds():
+    ops, slots = he_layer_ops(12)
+    st = N.Plan(ops, 12, slots).stats()
+    assert st["whole_state_lds"] == 1 and st["n_passes"] == 1
+    # RY.RZ.RY on each wire merge into one 2x2 (commutation-aware)
+    assert st["n_lowered"] == 12 + 12
+
+
+def test_no_fusion_is_one_pass_per_gate():
+    ops, slots = he_layer_ops(24)
+    p = N.Plan(ops, 24, slots, flags=N.plan_flags(no_fusion=True))
+    st = p.stats()
+    assert st["n_passes"] == 96 and st["direct_passes"] == 96
+    # (72*256 + 24*128) MiB per state
+    assert st["algo_bytes_per_state"] == (72 * 256 + 24 * 128) * 2**20
+
+
+def test_fused_schedule_covers_every_gate_once_and_respects_order():
+    ops, slots = he_layer_ops(24)
+    p = N.Plan(ops, 24, slots)
+    d = p.describe()
+    seen = [s for st in d["stages"] for s in st["src_ops"]]
+    assert sorted(seen) == list(range(len(ops)))
+    assert d["n_qubits"] == 24 and len(d["stages"]) <= 6
+    # dependency order: for gates sharing a wire, stage index must be non-decreasing
+    stage_of = {}
+    for si, st in enumerate(d["stages"]):
+        for s in st["src_ops"]:
+            stage_of[s] = si
+    last = {}
+    for i, (_, wires, _, _) in enumerate(ops):
+        for w in wires:
+            if w in last:
+                assert stage_of[last[w]] <= stage_of[i]
+            last[w] = i
+    for st in d["stages"]:
+        if st["kind"] == "tile":
+            assert st["T"] == 13 and st["bits"][: st["L"]] == list(range(st["L"]))
+
+
+def test_compute_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = N.Plan([("H", [0], [], -1)], 1, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p.run(None, "state")
