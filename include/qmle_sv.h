@@ -149,6 +149,12 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream);
 
+/* Apply the plan's passes in place to resident states [batch][2^n] complex64 (no
+ * initialisation, no measurement) -- the per-gate loop simulation.py:102-103 alone.
+ * Workspace: qmle_workspace_bytes(plan, batch, QMLE_MEAS_STATE, 0, 0). */
+int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+
 /* ---- stand-alone measurement / analysis kernels on resident states ---------- */
 /* d_states: [batch][2^n] complex64 */
 int qmle_expval_z(const void *d_states, int n_qubits, int batch, const int32_t *obs_wires,
@@ -170,6 +176,17 @@ int qmle_marginal_probs(const void *d_states, int n_qubits, int batch,
 int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d_out,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream);
 size_t qmle_pair_fidelity_workspace_bytes(int n_qubits, int n_pairs);
+/* <a_i|b_i> for i < count (complex64 out[count]); the matrix-free general
+ * observable path: <O> = Re <psi | O psi>  (simulation.py:263-269) */
+int qmle_overlap(const void *d_a, const void *d_b, int n_qubits, int count, void *d_out,
+                 void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+size_t qmle_overlap_workspace_bytes(int n_qubits, int count);
+/* Z (x) Z (x) ... parity observables (jaqsi.py:149-167): wire_masks[k] has bit w set
+ * iff wire w takes part in observable k (HOST array); d_out [batch][n_obs] float32 */
+int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint32_t *wire_masks,
+                       int n_obs, float *d_out, void *d_workspace, size_t workspace_bytes,
+                       qmle_stream stream);
+size_t qmle_expval_parity_workspace_bytes(int n_qubits, int batch);
 /* Meyer-Wallach: d_out[b] = 2 (1 - 1/n sum_j Tr rho_j^2), Tr rho_j^2 = a^2+d^2+2|c|^2
  * (entanglement.py:86-101 via the Schmidt identity).
  * d_purities (optional, may be NULL): [batch][n] float32 */

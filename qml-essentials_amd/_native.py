@@ -88,6 +88,7 @@ SYMBOLS = [
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_apply_inplace", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_expval_z", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_expval_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_probs", _I, [_VP, _I, _I, _VP, _VP]),
@@ -95,6 +96,10 @@ SYMBOLS = [
     ("qmle_marginal_probs", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP]),
     ("qmle_pair_fidelity", _I, [_VP, _I, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_pair_fidelity_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_overlap", _I, [_VP, _VP, _I, _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_overlap_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_expval_parity", _I, [_VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_expval_parity_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
@@ -246,6 +251,22 @@ class Plan:
         return out
 
 
+def apply_inplace(plan: Plan, angles, states, workspace=None):
+    """Apply ``plan``'s gates in place to resident ``states`` [B, 2^n] (no init)."""
+    torch = require_gpu()
+    B = int(states.shape[0])
+    if angles is None:
+        angles = torch.zeros((B, max(1, plan.n_slots)), dtype=torch.float32, device=states.device)
+    need = plan.workspace_bytes(B, "state")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_apply_inplace(plan._h, C.c_void_p(angles.data_ptr()), B,
+                                   C.c_void_p(states.data_ptr()), C.c_void_p(workspace.data_ptr()),
+                                   C.c_size_t(workspace.numel()), _stream_ptr()),
+          "qmle_apply_inplace")
+    return states
+
+
 # ---- stand-alone measurement / analysis kernels -------------------------------------
 def _states_info(states):
     torch = require_gpu()
@@ -309,6 +330,42 @@ def pair_fidelity(states):
     check(lib().qmle_pair_fidelity(C.c_void_p(states.data_ptr()), n, S, C.c_void_p(out.data_ptr()),
                                    C.c_void_p(ws.data_ptr()), wsb, _stream_ptr()),
           "qmle_pair_fidelity")
+    return out
+
+
+def overlap(a, b):
+    """<a_i|b_i> for two [B, 2^n] complex64 tensors -> complex64 [B]."""
+    torch, a, B, n = _states_info(a)
+    _, b, Bb, nb = _states_info(b)
+    if (B, n) != (Bb, nb):
+        raise ValueError("overlap: shape mismatch")
+    out = torch.empty((B,), dtype=torch.complex64, device=a.device)
+    wsb = int(lib().qmle_overlap_workspace_bytes(n, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    check(lib().qmle_overlap(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n, B,
+                             C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), wsb,
+                             _stream_ptr()), "qmle_overlap")
+    return out
+
+
+def expval_parity(states, wire_groups):
+    """<Z..Z> on each group of wires -> float32 [B, len(groups)]."""
+    torch, states, B, n = _states_info(states)
+    masks = []
+    for g in wire_groups:
+        m = 0
+        for w in g:
+            if not 0 <= int(w) < n:
+                raise ValueError(f"wire {w} out of range for {n} qubits")
+            m |= 1 << int(w)
+        masks.append(m)
+    arr = (C.c_uint32 * max(1, len(masks)))(*masks)
+    out = torch.empty((B, len(masks)), dtype=torch.float32, device=states.device)
+    wsb = int(lib().qmle_expval_parity_workspace_bytes(n, B))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_expval_parity(C.c_void_p(states.data_ptr()), n, B, arr, len(masks),
+                                   C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), wsb,
+                                   _stream_ptr()), "qmle_expval_parity")
     return out
 
 

@@ -763,6 +763,87 @@ k_histogram(const float *__restrict__ values, int64_t count, int n_bins, float l
   }
 }
 
+
+// <a_i|b_i> for separate arrays a, b: partial[i][block] = (re, im)
+__global__ void __launch_bounds__(256)
+k_overlap2_partial(const float4 *__restrict__ a_all, const float4 *__restrict__ b_all, int n,
+                   float2 *__restrict__ partial) {
+  __shared__ float red[16];
+  const int pr = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *a = a_all + (size_t)pr * chunks;
+  const float4 *c = b_all + (size_t)pr * chunks;
+  float re = 0.f, im = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+    const float4 x = a[k], y = c[k];
+    re += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    im += x.x * y.y - x.y * y.x + x.z * y.w - x.w * y.z;
+  }
+  const float r = block_sum(re, red);
+  const float i = block_sum(im, red);
+  if (threadIdx.x == 0) partial[(size_t)pr * gridDim.x + blockIdx.x] = make_float2(r, i);
+}
+
+__global__ void k_overlap2_final(const float2 *__restrict__ partial, int n_blocks, int count,
+                                 float2 *__restrict__ out) {
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= count) return;
+  double re = 0.0, im = 0.0;
+  for (int i = 0; i < n_blocks; ++i) {
+    const float2 v = partial[(size_t)pr * n_blocks + i];
+    re += v.x;
+    im += v.y;
+  }
+  out[pr] = make_float2((float)re, (float)im);
+}
+
+// Z-parity expectation: sum_i (-1)^{popcount(i & mask)} |psi_i|^2, up to 8 masks per launch.
+struct ParityMasks {
+  uint32_t m[8];
+  int count;
+};
+
+__global__ void __launch_bounds__(256)
+k_parity_partial(const float4 *__restrict__ states, int n, ParityMasks pm,
+                 float *__restrict__ partial) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *st = states + (size_t)b * chunks;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += stride) {
+    const float4 v = st[c];
+    const float pe = v.x * v.x + v.y * v.y, po = v.z * v.z + v.w * v.w;
+    const uint32_t ie = (uint32_t)(c << 1), io = ie | 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[k] += (__popc(ie & pm.m[k]) & 1) ? -pe : pe;
+      acc[k] += (__popc(io & pm.m[k]) & 1) ? -po : po;
+    }
+  }
+  float *out = partial + ((size_t)b * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float r = block_sum(acc[k], red);
+    if (threadIdx.x == 0) out[k] = r;
+  }
+}
+
+__global__ void k_parity_final(const float *__restrict__ partial, int n_blocks, int count,
+                               int n_obs_total, int obs_off, float *__restrict__ out) {
+  const int b = blockIdx.x;
+  const int k = threadIdx.x;
+  if (k >= count) return;
+  double acc = 0.0;
+  const float *pp = partial + (size_t)b * n_blocks * 8;
+  for (int i = 0; i < n_blocks; ++i) acc += (double)pp[(size_t)i * 8 + k];
+  out[(size_t)b * n_obs_total + obs_off + k] = (float)acc;
+}
+
 // ---------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------
@@ -1025,22 +1106,26 @@ static int default_states_in_flight(const qmle_plan *p, int batch) {
   return (int)s;
 }
 
+static size_t per_state_ws_bytes(int n, int meas_type) {
+  size_t b = align_up((size_t)8 << n, 256);
+  if (meas_type == QMLE_MEAS_EXPVAL_Z)
+    b += align_up((size_t)expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+  return b;
+}
+
 size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int n_obs,
                             int states_in_flight) {
   (void)n_obs;
   if (!plan || batch < 1) return 0;
-  size_t total = ws_mats_bytes(plan, batch);
-  const size_t sb = (size_t)8 << plan->n;
+  size_t total = ws_mats_bytes(plan, batch) + 512;  // + alignment slack
   const bool lds_direct_meas =
       plan->whole_state_lds && (meas_type == QMLE_MEAS_PROBS || meas_type == QMLE_MEAS_EXPVAL_Z);
   if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
     int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
     if (s > batch) s = batch;
-    total += align_up((size_t)s * sb, 256);
-    if (meas_type == QMLE_MEAS_EXPVAL_Z)
-      total += align_up((size_t)s * expval_blocks(plan->n) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+    total += (size_t)s * per_state_ws_bytes(plan->n, meas_type);
   }
-  return total + 256;
+  return total;
 }
 
 int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
@@ -1123,15 +1208,13 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
     d_states = (float2 *)d_out;
     in_flight = default_states_in_flight(plan, batch);  // sample-major: stay cache-resident
   } else {
-    in_flight = (int)(workspace_bytes / (sb + (meas_type == QMLE_MEAS_EXPVAL_Z
-                          ? (size_t)expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float) + 256
-                          : 0) + 256));
+    in_flight = (int)(workspace_bytes / per_state_ws_bytes(n, meas_type));
     if (in_flight < 1) return QMLE_ERR_WORKSPACE;
     if (in_flight > batch) in_flight = batch;
     const int dflt = default_states_in_flight(plan, batch);
     if (in_flight > dflt) in_flight = dflt;
     d_states = (float2 *)ws;
-    ws += align_up((size_t)in_flight * sb, 256);
+    ws += (size_t)in_flight * align_up(sb, 256);
   }
   if (in_flight > 65535) in_flight = 65535;
   void *d_partial = ws;
@@ -1188,6 +1271,46 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
     }
     HIPCHK(hipGetLastError());
   }
+  return QMLE_OK;
+}
+
+// Apply the plan's passes IN PLACE to resident states (no |0..0> initialisation, no
+// measurement): the gate-application hot loop on its own (simulation.py:102-103).
+int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || batch > 65535 || !d_states || !d_workspace) return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = ensure_device_plan(plan);
+  if (rc != QMLE_OK) return rc;
+  char *ws = (char *)d_workspace;
+  const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+  if (workspace_bytes < mis + ws_mats_bytes(plan, batch)) return QMLE_ERR_WORKSPACE;
+  float *d_mats = (float *)(ws + mis);
+  if (!plan->groups.empty()) {
+    const int ng = (int)plan->groups.size();
+    hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, batch), dim3(64), 0, stream,
+                       plan->dev.d_build, plan->dev.d_groups, ng, d_angles, plan->n_slots,
+                       plan->dev.d_consts, d_mats, plan->mat_floats);
+  }
+  const int n = plan->n;
+  const size_t D = (size_t)1 << n;
+  for (const Stage &st : plan->stages) {
+    if (st.kind == ST_TILE) {
+      rc = launch_tile(plan, st, (float2 *)d_states, d_mats, d_angles, batch, false, TM_STORE,
+                       nullptr, nullptr, 0, stream);
+    } else if (st.kind == ST_DIRECT) {
+      rc = launch_direct(plan, plan->dev_ops[st.op_begin], (float2 *)d_states, d_mats, batch, stream);
+    } else {
+      const LoweredOp &o = plan->dev_ops[st.op_begin];
+      hipLaunchKernelGGL(k_diag_all, dim3(grid_for(D / 2, 256), batch), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(d_states), n, plan->dev.d_consts + o.mat_off,
+                         d_angles, plan->n_slots, o.slot);
+      rc = QMLE_OK;
+    }
+    if (rc != QMLE_OK) return rc;
+  }
+  HIPCHK(hipGetLastError());
   return QMLE_OK;
 }
 
@@ -1284,6 +1407,69 @@ int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d
   }
   hipLaunchKernelGGL(k_overlap_final, dim3((n_pairs + 255) / 256), dim3(256), 0, stream,
                      (const float2 *)d_workspace, nb, n_pairs, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+size_t qmle_overlap_workspace_bytes(int n_qubits, int count) {
+  if (n_qubits < 1 || count < 1) return 0;
+  return (size_t)count * overlap_blocks(n_qubits) * sizeof(float2) + 256;
+}
+
+int qmle_overlap(const void *d_a, const void *d_b, int n_qubits, int count, void *d_out,
+                 void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!d_a || !d_b || !d_out || !d_workspace || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
+      count < 1)
+    return QMLE_ERR_INVALID_ARG;
+  const int nb = overlap_blocks(n_qubits);
+  if (workspace_bytes < (size_t)count * nb * sizeof(float2)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint64_t chunks = (uint64_t)1 << (n_qubits - 1);
+  for (int p0 = 0; p0 < count; p0 += 65535) {
+    const int pc = count - p0 < 65535 ? count - p0 : 65535;
+    hipLaunchKernelGGL(k_overlap2_partial, dim3(nb, pc), dim3(256), 0, stream,
+                       (const float4 *)d_a + (size_t)p0 * chunks,
+                       (const float4 *)d_b + (size_t)p0 * chunks, n_qubits,
+                       (float2 *)d_workspace + (size_t)p0 * nb);
+  }
+  hipLaunchKernelGGL(k_overlap2_final, dim3((count + 255) / 256), dim3(256), 0, stream,
+                     (const float2 *)d_workspace, nb, count, (float2 *)d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+size_t qmle_expval_parity_workspace_bytes(int n_qubits, int batch) {
+  if (n_qubits < 1 || batch < 1) return 0;
+  return (size_t)batch * overlap_blocks(n_qubits) * 8 * sizeof(float) + 256;
+}
+
+int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint32_t *wire_masks,
+                       int n_obs, float *d_out, void *d_workspace, size_t workspace_bytes,
+                       qmle_stream stream_) {
+  if (!d_states || !d_out || !d_workspace || !wire_masks || n_qubits < 1 ||
+      n_qubits > QMLE_MAX_QUBITS || batch < 1 || batch > 65535 || n_obs < 1)
+    return QMLE_ERR_INVALID_ARG;
+  const int nb = overlap_blocks(n_qubits);
+  if (workspace_bytes < (size_t)batch * nb * 8 * sizeof(float)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int o0 = 0; o0 < n_obs; o0 += 8) {
+    ParityMasks pm;
+    pm.count = n_obs - o0 < 8 ? n_obs - o0 : 8;
+    for (int k = 0; k < 8; ++k) {
+      uint32_t bits = 0;
+      if (k < pm.count) {
+        const uint32_t wm = wire_masks[o0 + k];  // bit w set <=> wire w in the parity
+        if (n_qubits < 32 && (wm >> n_qubits)) return QMLE_ERR_WIRE_RANGE;
+        for (int w = 0; w < n_qubits; ++w)
+          if (wm & (1u << w)) bits |= 1u << (n_qubits - 1 - w);
+      }
+      pm.m[k] = bits;
+    }
+    hipLaunchKernelGGL(k_parity_partial, dim3(nb, batch), dim3(256), 0, stream,
+                       (const float4 *)d_states, n_qubits, pm, (float *)d_workspace);
+    hipLaunchKernelGGL(k_parity_final, dim3(batch), dim3(8), 0, stream,
+                       (const float *)d_workspace, nb, pm.count, n_obs, o0, d_out);
+  }
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

@@ -1,0 +1,534 @@
+"""Data-reuploading ``Model`` on the MI355X statevector engine.
+
+API mirror of ``qml_essentials/model.py`` for the noise-free unitary path:
+constructor (``:26-210``), batching semantics (``_assimilate_batch`` ``:1414-1483``),
+gate order (``_variational`` ``:818-963``, ``_iec`` ``:746-816``), observables
+(``_build_obs`` ``:965-998``), result shaping (``_forward`` ``:1572-1737``) and
+``initialize_params`` (``:631-722``).  Results are NumPy arrays (the reference
+returns ``jnp`` arrays); the 2^n arithmetic runs in ``libqmle_sv`` via
+:class:`script.Script`.  Out of scope: noise, pulses, drawing, ``exact_spectrum``.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import jaqsi as js
+from . import operations as op
+from .ansaetze import Ansaetze, Circuit, Encoding
+from .batching import to_numpy
+from .gates import Gates
+from .utils import PRNGKey, as_key, safe_random_split, uniform
+
+log = logging.getLogger(__name__)
+
+_NOISE_KEYS = ("BitFlip", "PhaseFlip", "Depolarizing", "MultiQubitDepolarizing",
+               "AmplitudeDamping", "PhaseDamping", "GateError", "ThermalRelaxation",
+               "StatePreparation", "Measurement")
+
+
+class Model:
+    """A parametrised quantum circuit with (re-uploaded) input encoding."""
+
+    def __init__(
+        self,
+        n_qubits: int,
+        n_layers: int,
+        circuit_type: Union[str, Circuit] = "No_Ansatz",
+        data_reupload: Union[bool, List[List[bool]], List[List[List[bool]]]] = True,
+        state_preparation: Union[str, Callable, List[Union[str, Callable]], None] = None,
+        encoding: Union[Encoding, str, Callable, List[Union[str, Callable]]] = Gates.RX,
+        trainable_frequencies: bool = False,
+        initialization: str = "random",
+        initialization_domain: List[float] = [0, 2 * np.pi],
+        output_qubit: Union[List[int], int] = -1,
+        shots: Optional[int] = None,
+        random_seed: int = 1000,
+        remove_zero_encoding: bool = True,
+        repeat_batch_axis: List[bool] = [True, True, True],
+        pulse_shape: str = "gaussian",
+    ) -> None:
+        self.n_qubits = n_qubits
+        self.output_qubit = output_qubit
+        self.n_layers = n_layers
+        self.noise_params = None
+        self.shots = shots
+        self.remove_zero_encoding = remove_zero_encoding
+        self.trainable_frequencies = trainable_frequencies
+        self.execution_type = "expval"
+        self.repeat_batch_axis = list(repeat_batch_axis)
+        self.gate_mode = "unitary"
+
+        try:
+            self._sp = Gates.parse_gates(state_preparation, Gates)
+        except ValueError as e:
+            raise ValueError(f"Error parsing encodings: {e}")
+
+        self._enc = encoding if isinstance(encoding, Encoding) else Encoding("hamming", encoding)
+        if self._enc.is_golomb:
+            self._enc._n_qubits = n_qubits
+        self.n_input_feat = len(self._enc)
+
+        # trainable frequencies start at one (arXiv:2309.03279v2), model.py:150
+        self.enc_params = np.ones((n_layers, n_qubits, self.n_input_feat), dtype=np.float32)
+        self._zero_inputs = False
+        self.data_reupload = data_reupload  # also sets degree / frequencies / has_dru
+
+        impl_layers = n_layers + 1 if self.has_dru else n_layers  # Schuld et al.: L+1 blocks
+
+        if isinstance(circuit_type, str):
+            self.pqc = getattr(Ansaetze, circuit_type or "No_Ansatz")()
+        else:
+            self.pqc = circuit_type()
+        self._params_shape = (impl_layers, self.pqc.n_params_per_layer(n_qubits))
+        self._pulse_params_shape = (impl_layers, 0)
+
+        self._batch_shape = None
+        self._inialization_strategy = initialization
+        self._initialization_domain = initialization_domain
+        self.random_key = self.initialize_params(PRNGKey(random_seed))
+        self.pulse_params = np.ones((1, *self._pulse_params_shape), dtype=np.float32)
+
+        self.script = js.Script(f=self._variational, n_qubits=n_qubits)
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def noise_params(self):
+        return self._noise_params
+
+    @noise_params.setter
+    def noise_params(self, kvs) -> None:
+        if kvs is not None and all(v == 0.0 for v in kvs.values()):
+            kvs = None
+        if kvs is not None:
+            for k in kvs:
+                if k not in _NOISE_KEYS:
+                    warnings.warn(f"Noise type {k} is not supported by this package", UserWarning)
+            for k in _NOISE_KEYS:
+                kvs.setdefault(k, None if k == "ThermalRelaxation" else 0.0)
+        self._noise_params = kvs
+
+    @property
+    def output_qubit(self):
+        return self._output_qubit
+
+    @output_qubit.setter
+    def output_qubit(self, value) -> None:
+        if isinstance(value, list):
+            assert len(value) <= self.n_qubits, (
+                f"Size of output_qubit {len(value)} cannot be larger than number of qubits "
+                f"{self.n_qubits}."
+            )
+        elif isinstance(value, (int, np.integer)):
+            if value == -1:
+                value = list(range(self.n_qubits))
+            else:
+                assert value < self.n_qubits, (
+                    f"Output qubit {value} cannot be larger than {self.n_qubits}."
+                )
+                value = [int(value)]
+        self._output_qubit = value
+
+    @property
+    def execution_type(self) -> str:
+        return self._execution_type
+
+    @execution_type.setter
+    def execution_type(self, value: str) -> None:
+        k = len(self.output_qubit)
+        shapes = {"density": (2**k, 2**k), "expval": (k,), "probs": (2,) * k, "state": (2**k,)}
+        if value not in shapes:
+            raise ValueError(f"Invalid execution type: {value}.")
+        self._result_shape = shapes[value]
+        if value == "state" and not self.all_qubit_measurement:
+            warnings.warn(
+                f"{value} measurement does ignore output_qubit, which is {self.output_qubit}.",
+                UserWarning,
+            )
+        if value == "probs" and self.shots is None:
+            warnings.warn("Setting execution_type to probs without specifying shots.", UserWarning)
+        if value == "density" and self.shots is not None:
+            raise ValueError("Setting execution_type to density with shots not None.")
+        self._execution_type = value
+
+    @property
+    def shots(self) -> Optional[int]:
+        return self._shots
+
+    @shots.setter
+    def shots(self, value: Optional[int]) -> None:
+        if type(value) is int and value <= 0:
+            value = None
+        self._shots = value
+
+    @property
+    def params(self) -> np.ndarray:
+        return self._params
+
+    @params.setter
+    def params(self, value) -> None:
+        value = to_numpy(value)
+        if len(value.shape) == 2:
+            value = value.reshape(1, *value.shape)
+        self._params = value
+
+    @property
+    def enc_params(self) -> np.ndarray:
+        return self._enc_params
+
+    @enc_params.setter
+    def enc_params(self, value) -> None:
+        self._enc_params = to_numpy(value)
+
+    @property
+    def pulse_params(self) -> np.ndarray:
+        return self._pulse_params
+
+    @pulse_params.setter
+    def pulse_params(self, value) -> None:
+        self._pulse_params = value
+
+    @property
+    def data_reupload(self) -> np.ndarray:
+        return self._data_reupload
+
+    @data_reupload.setter
+    def data_reupload(self, value) -> None:
+        """Boolean mask (n_layers, n_qubits, n_input_feat); also derives the naive
+        spectrum (``model.py:466-512``).  ``False`` keeps exactly one encoding gate
+        (layer 0 / qubit 0)."""
+        full = (self.n_layers, self.n_qubits, self.n_input_feat)
+        if isinstance(value, (bool, np.bool_)):
+            mask = np.ones(full) if value else np.zeros(full)
+            if not value:
+                mask[0][0] = 1
+        else:
+            mask = np.asarray(value)
+            if mask.ndim == 2:
+                assert mask.shape == full[:2], (
+                    f"Data reuploading array has wrong shape. Expected {full[:2]} or {full}, "
+                    f"got {mask.shape}."
+                )
+                mask = np.repeat(mask[:, :, None], self.n_input_feat, axis=2)
+            assert mask.shape == full, (
+                f"Data reuploading array has wrong shape. Expected {full}, got {mask.shape}."
+            )
+        self._data_reupload = mask.astype(bool)
+        uses = [int(np.count_nonzero(self._data_reupload[..., i])) for i in range(self.n_input_feat)]
+        self.degree = tuple(self._enc.get_n_freqs(u) for u in uses)
+        self.frequencies = tuple(self._enc.get_spectrum(u) for u in uses)
+        self._has_dru = bool(max(int(np.max(f)) for f in self.frequencies) > 1)
+
+    @property
+    def degree(self) -> Tuple:
+        return self._degree
+
+    @degree.setter
+    def degree(self, value: Tuple) -> None:
+        self._degree = value
+
+    @property
+    def frequencies(self) -> Tuple:
+        return self._frequencies
+
+    @frequencies.setter
+    def frequencies(self, value: Tuple) -> None:
+        self._frequencies = value
+
+    @property
+    def has_dru(self) -> bool:
+        return self._has_dru
+
+    @property
+    def all_qubit_measurement(self) -> bool:
+        return self.output_qubit == list(range(self.n_qubits))
+
+    @property
+    def batch_shape(self) -> Tuple[int, ...]:
+        """(B_I, B_P, B_R); (1, 1, 1) before the first call."""
+        return (1, 1, 1) if self._batch_shape is None else self._batch_shape
+
+    @property
+    def eff_batch_shape(self) -> np.ndarray:
+        shape = np.array(self.batch_shape) * self.repeat_batch_axis
+        return shape[shape != 0]
+
+    # ------------------------------------------------------------------ parameters
+    def initialize_params(self, random_key=None, repeat: int = 1,
+                          initialization: Optional[str] = None,
+                          initialization_domain: Optional[List[float]] = None):
+        """(Re-)draw ``self.params`` with shape ``(repeat, layers, params_per_layer)``;
+        returns the advanced key (``model.py:631-722``)."""
+        shape = (repeat, *self._params_shape)
+        strategy = initialization or self._inialization_strategy
+        lo, hi = initialization_domain or self._initialization_domain
+        random_key, sub = safe_random_split(
+            as_key(random_key) if random_key is not None else self.random_key
+        )
+
+        def draw():
+            return uniform(sub, shape, minval=lo, maxval=hi)
+
+        def pin_controlled(params: np.ndarray, value: float) -> np.ndarray:
+            idx = self.pqc.get_control_indices(self.n_qubits)
+            if idx is None:
+                warnings.warn(
+                    f"Specified {strategy} but circuit does not contain controlled rotation "
+                    "gates. Parameters are intialized randomly.",
+                    UserWarning,
+                )
+                return params
+            params = np.array(params)
+            if len(idx) == 3 and None in idx:
+                params[:, :, idx[0]:idx[1]:idx[2]] = value
+            else:
+                params[:, :, idx] = value
+            return params
+
+        if strategy == "random":
+            self.params = draw()
+        elif strategy == "zeros":
+            self.params = np.zeros(shape, dtype=np.float32)
+        elif strategy == "pi":
+            self.params = np.full(shape, np.pi, dtype=np.float32)
+        elif strategy == "zero-controlled":
+            self.params = pin_controlled(draw(), 0.0)
+        elif strategy == "pi-controlled":
+            self.params = pin_controlled(draw(), np.pi)
+        else:
+            raise Exception("Invalid initialization method")
+        return random_key
+
+    def transform_input(self, inputs, enc_params):
+        """Scale the input by the encoding weight (arXiv:2309.03279v2)."""
+        return inputs * enc_params
+
+    # ------------------------------------------------------------------ circuit
+    def _iec(self, inputs, data_reupload: np.ndarray, enc: Encoding, enc_params,
+             noise_params=None, random_key=None) -> None:
+        """Input-encoding layer (``model.py:746-816``)."""
+        if self.remove_zero_encoding and self._zero_inputs and self.batch_shape[0] == 1:
+            return
+        if enc.is_golomb:
+            if data_reupload[:, 0].any():
+                scale = np.mean(enc_params[:, 0])
+                enc[0](self.transform_input(inputs[..., 0], scale),
+                       wires=list(range(self.n_qubits)), noise_params=noise_params,
+                       random_key=None)
+            return
+        for q in range(self.n_qubits):
+            for idx in range(inputs.shape[-1]):
+                if data_reupload[q, idx]:
+                    enc[idx](self.transform_input(inputs[..., idx], enc_params[q, idx]),
+                             wires=q, noise_params=noise_params, random_key=None)
+
+    def _variational(self, params, inputs, pulse_params=None, random_key=None, enc_params=None,
+                     gate_mode: str = "unitary", noise_params=None) -> None:
+        """Record the whole circuit: state prep; per layer ansatz then encoding; final
+        ansatz layer when re-uploading is active (``model.py:913-959``)."""
+        if len(params.shape) > 2 and params.shape[0] == 1:
+            params = params[0]
+        if len(inputs.shape) > 1 and inputs.shape[0] == 1:
+            inputs = inputs[0]
+        if enc_params is None:
+            if self.trainable_frequencies:
+                warnings.warn(
+                    "Explicit call to `_circuit` or `_variational` detected: "
+                    "`enc_params` is None, using `self.enc_params` instead.",
+                    RuntimeWarning,
+                )
+            enc_params = self.enc_params
+        if noise_params is None and self.noise_params is not None:
+            noise_params = self.noise_params
+
+        for q in range(self.n_qubits):
+            for prep in self._sp:
+                prep(wires=q, noise_params=noise_params, gate_mode=gate_mode)
+        for layer in range(self.n_layers):
+            self.pqc(params[layer], self.n_qubits, noise_params=noise_params, gate_mode=gate_mode)
+            self._iec(inputs, data_reupload=self.data_reupload[layer], enc=self._enc,
+                      enc_params=enc_params[layer], noise_params=noise_params)
+        if self.has_dru:
+            self.pqc(params[self.n_layers], self.n_qubits, noise_params=noise_params,
+                     gate_mode=gate_mode)
+
+    def _build_obs(self) -> Tuple[str, List[op.Operation]]:
+        et = self.execution_type
+        if et in ("density", "state", "probs"):
+            return et, []
+        if et == "expval":
+            obs = []
+            for spec in self.output_qubit:
+                if isinstance(spec, (int, np.integer)):
+                    obs.append(op.PauliZ(wires=int(spec), record=False))
+                else:
+                    obs.append(js.build_parity_observable(list(spec)))
+            return "expval", obs
+        raise ValueError(f"Invalid execution_type: {et}.")
+
+    # ------------------------------------------------------------------ validation
+    def _params_validation(self, params) -> np.ndarray:
+        if params is None:
+            return self.params
+        params = to_numpy(params)
+        if len(params.shape) == 2:
+            params = np.expand_dims(params, axis=0)
+        self.params = params
+        return params
+
+    def _enc_params_validation(self, enc_params) -> np.ndarray:
+        if enc_params is None:
+            enc_params = self.enc_params
+        else:
+            enc_params = to_numpy(enc_params)
+            self.enc_params = enc_params
+        if len(enc_params.shape) == 1 and self.n_input_feat == 1:
+            enc_params = enc_params.reshape(-1, 1)
+        elif len(enc_params.shape) == 1 and self.n_input_feat > 1:
+            raise ValueError(
+                f"Input dimension {self.n_input_feat} >1 but `enc_params` has shape "
+                f"{enc_params.shape}"
+            )
+        return enc_params
+
+    def _inputs_validation(self, inputs) -> np.ndarray:
+        """-> ``(batch, n_input_feat)`` float array; flags all-zero inputs."""
+        self._zero_inputs = False
+        if isinstance(inputs, list):
+            inputs = np.array(np.stack([to_numpy(i) for i in inputs]))
+        elif isinstance(inputs, (float, int)):
+            inputs = np.array([inputs])
+        elif inputs is None:
+            inputs = np.array([[0] * self.n_input_feat])
+        inputs = np.asarray(to_numpy(inputs))
+        if not inputs.any():
+            self._zero_inputs = True
+        if len(inputs.shape) <= 1:
+            if self.n_input_feat == 1:
+                inputs = inputs.reshape(-1, 1)
+            elif inputs.shape and inputs.shape[0] == self.n_input_feat:
+                inputs = inputs.reshape(1, -1)
+            else:
+                inputs = inputs.reshape(-1, 1).repeat(self.n_input_feat, axis=1)
+                warnings.warn(
+                    f"Expected {self.n_input_feat} inputs, but {inputs.shape[0]} "
+                    "was provided, replicating input for all input features.",
+                    UserWarning,
+                )
+        elif inputs.shape[1] != self.n_input_feat:
+            raise ValueError(
+                f"Wrong number of inputs provided. Expected {self.n_input_feat} "
+                f"inputs, but input has shape {inputs.shape}."
+            )
+        return inputs
+
+    def _assimilate_batch(self, inputs: np.ndarray, params: np.ndarray):
+        """Cartesian batch ``B = B_I * B_P`` with inputs slowest (``model.py:1414-1483``);
+        axes whose ``repeat_batch_axis`` flag is off are zipped instead of crossed."""
+        B_I = inputs.shape[0]
+        B_P = 1 if 0 in params.shape else params.shape[0]
+        self._batch_shape = (B_I, B_P, 1)
+        B = int(np.prod(self.eff_batch_shape))
+        rep_i, rep_p, _ = self.repeat_batch_axis
+        if B_I > 1 and rep_i:
+            x = inputs[:, None, ...]
+            if rep_p:
+                x = np.repeat(x, B_P, axis=1)
+            inputs = x.reshape(B, *inputs.shape[1:])
+        if B_P > 1 and rep_p:
+            p = params[None, ...]
+            if rep_i:
+                p = np.repeat(p, B_I, axis=0)
+            params = p.reshape(B, *params.shape[1:])
+        return inputs, params
+
+    def record_tape(self, params=None, inputs=None, enc_params=None):
+        """Validate + batch the arguments exactly like ``__call__`` and return
+        ``(tape, batch)`` without executing (host only; used by tests and tools)."""
+        from .batching import Batched
+        from .tape import recording
+
+        params = self._params_validation(params)
+        inputs = self._inputs_validation(inputs)
+        enc_params = self._enc_params_validation(enc_params)
+        inputs, params = self._assimilate_batch(inputs, params)
+        B = int(np.prod(self.eff_batch_shape))
+        if B > 1:
+            if self.batch_shape[1] > 1:
+                params = Batched(params)
+            if self.batch_shape[0] > 1:
+                inputs = Batched(inputs)
+        with recording() as tape:
+            self._variational(params, inputs, enc_params=enc_params)
+        return tape, B
+
+    # ------------------------------------------------------------------ execution
+    def __call__(self, params=None, inputs=None, pulse_params=None, enc_params=None,
+                 data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
+                 force_mean: bool = False, gate_mode: str = "unitary") -> np.ndarray:
+        return self._forward(params=params, inputs=inputs, pulse_params=pulse_params,
+                             enc_params=enc_params, data_reupload=data_reupload,
+                             noise_params=noise_params, execution_type=execution_type,
+                             force_mean=force_mean, gate_mode=gate_mode)
+
+    def _forward(self, params=None, inputs=None, pulse_params=None, enc_params=None,
+                 data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
+                 force_mean: bool = False, gate_mode: str = "unitary",
+                 as_tensor: bool = False):
+        if noise_params is not None:
+            self.noise_params = noise_params
+        if execution_type is not None:
+            self.execution_type = execution_type
+        self.gate_mode = gate_mode
+        if pulse_params is not None and gate_mode != "pulse":
+            raise ValueError(
+                "pulse_params were provided but gate_mode is not 'pulse'. "
+                "Either switch gate_mode='pulse' or do not pass pulse_params."
+            )
+        if gate_mode == "pulse":
+            raise NotImplementedError("gate_mode='pulse' is outside the MI355X hot path")
+        if data_reupload is not None:
+            self.data_reupload = data_reupload
+
+        params = self._params_validation(params)
+        inputs = self._inputs_validation(inputs)
+        enc_params = self._enc_params_validation(enc_params)
+        inputs, params = self._assimilate_batch(inputs, params)
+        self.random_key, _ = safe_random_split(self.random_key)
+
+        meas_type, obs = self._build_obs()
+        B = int(np.prod(self.eff_batch_shape))
+        kwargs = dict(noise_params=self.noise_params, gate_mode=self.gate_mode)
+        if self.shots is not None and meas_type in ("probs", "expval"):
+            raise NotImplementedError("shot sampling is a later row (SURVEY.md 8-f rank 4)")
+
+        args = (params, inputs, None, None, enc_params)
+        if B > 1:
+            in_axes = (0 if self.batch_shape[1] > 1 else None,
+                       0 if self.batch_shape[0] > 1 else None, None, None, None)
+            result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
+                                         in_axes=in_axes, as_tensor=as_tensor)
+        else:
+            result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
+                                         as_tensor=as_tensor)
+        if as_tensor:
+            return result  # raw (B, ...) device tensor for the analysis loops
+
+        if self.execution_type == "density" and not self.all_qubit_measurement:
+            result = js.partial_trace(result, self.n_qubits, self.output_qubit)
+        if self.execution_type == "probs" and not self.all_qubit_measurement:
+            if isinstance(self.output_qubit[0], (list, tuple)):
+                result = np.stack([js.marginalize_probs(result, self.n_qubits, list(g))
+                                   for g in self.output_qubit])
+            else:
+                result = js.marginalize_probs(result, self.n_qubits, self.output_qubit)
+
+        result = np.asarray(result)
+        result = result.reshape((*self.eff_batch_shape, *self._result_shape)).squeeze()
+        if (self.execution_type in ("expval", "probs") and force_mean and len(result.shape) > 0
+                and self._result_shape[0] > 1):
+            result = result.mean(axis=-1)
+        return result

@@ -1,0 +1,64 @@
+"""Splittable PRNG keys (host side).
+
+The reference draws parameters with ``jax.random`` (threefry keys,
+``model.py:687-693``; ``utils.py:9-13`` ``safe_random_split``).  Bit-identical
+samples are impossible without JAX (SURVEY.md 8-c "Not pinnable"), so this module
+only reproduces the *interface*: ``key(seed)``, ``split``, ``uniform`` -- on NumPy's
+Philox counter RNG, which like threefry is keyed and splittable.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+
+class PRNGKey:
+    """Immutable key; ``split`` derives independent children."""
+
+    __slots__ = ("_seq",)
+
+    def __init__(self, seed: Union[int, np.random.SeedSequence] = 0):
+        self._seq = seed if isinstance(seed, np.random.SeedSequence) else np.random.SeedSequence(int(seed))
+
+    def split(self, num: int = 2):
+        return [PRNGKey(s) for s in self._seq.spawn(num)]
+
+    def generator(self) -> np.random.Generator:
+        return np.random.Generator(np.random.Philox(self._seq))
+
+    def __repr__(self) -> str:
+        return f"PRNGKey(entropy={self._seq.entropy}, spawn_key={self._seq.spawn_key})"
+
+
+def key(seed: int) -> PRNGKey:
+    return PRNGKey(seed)
+
+
+def as_key(k) -> Optional[PRNGKey]:
+    if k is None or isinstance(k, PRNGKey):
+        return k
+    if isinstance(k, (int, np.integer)):
+        return PRNGKey(int(k))
+    raise TypeError(f"random_key must be an int seed or a PRNGKey, got {type(k)}")
+
+
+def safe_random_split(random_key: Optional[PRNGKey], *args, num: int = 2, **kwargs):
+    """``split`` that tolerates ``None`` (``qml_essentials/utils.py:9-13``)."""
+    if random_key is None:
+        return [None] * num if num != 2 else (None, None)
+    parts = as_key(random_key).split(num)
+    return tuple(parts) if num == 2 else parts
+
+
+def uniform(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
+            maxval: float = 1.0) -> np.ndarray:
+    g = as_key(random_key).generator()
+    return g.uniform(minval, maxval, size=tuple(shape)).astype(np.float32)
+
+
+class random:  # namespace so that ``from ...utils import random; random.key(0)`` reads like jax
+    key = staticmethod(key)
+    PRNGKey = staticmethod(key)
+    split = staticmethod(lambda k, num=2: as_key(k).split(num))
+    uniform = staticmethod(uniform)

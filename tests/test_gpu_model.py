@@ -1,0 +1,288 @@
+"""GPU parity of the Model / analysis-loop path against the oracle.
+
+Tolerance: complex64 engine vs the complex128 oracle, |diff| <= 1e-6 on
+expectation values (observables with unit norm, so this is the 1e-6 relative
+bound of BASELINE.json's north_star) unless a test states otherwise."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import analysis as OA
+from oracle import circuits as OC
+from oracle import einsum_sim as OE
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+c128 = np.complex128
+
+
+def oracle_expval(spec, params, x, wires=None, **kw):
+    tape = OC.model_tape(spec, params, np.atleast_1d(x), **kw)
+    wires = range(spec.n_qubits) if wires is None else wires
+    return OE.simulate_and_measure(tape, spec.n_qubits, "expval", [("PauliZ", [w]) for w in wires], c128)
+
+
+def test_config1_model_4q_2l_hardware_efficient():
+    """BASELINE config 1 (C1): expval for inputs 0 and 0.5."""
+    from qml_essentials_amd.model import Model
+
+    rng = np.random.default_rng(1000)
+    m = Model(4, 2, "Hardware_Efficient")
+    spec = OC.ModelSpec(4, 2, "Hardware_Efficient")
+    assert m.params.shape == (1, 3, 12)
+    p = rng.uniform(0, 2 * np.pi, (3, 12)).astype(np.float32)
+    for x in (0.0, 0.5):
+        got = m(params=p, inputs=np.array([x], dtype=np.float32))
+        assert got.shape == (4,)
+        assert np.abs(got - oracle_expval(spec, p, x)).max() < 1e-6
+
+
+@pytest.mark.parametrize("ansatz", sorted(OC.STRUCTURES) + ["GHZ"])
+def test_every_ansatz_expval_4q(ansatz):
+    from qml_essentials_amd.model import Model
+
+    rng = np.random.default_rng(7)
+    m = Model(4, 2, ansatz)
+    spec = OC.ModelSpec(4, 2, ansatz)
+    p = rng.uniform(0, 2 * np.pi, spec.params_shape).astype(np.float32)
+    got = m(params=p, inputs=np.array([0.8], dtype=np.float32))
+    assert np.abs(got - oracle_expval(spec, p, 0.8)).max() < 1e-6
+
+
+def test_batched_equals_sequential_and_shapes():
+    """test_jaqsi.py:701-725 / test_model.py:107-130: batched == sequential; B_I x B_P."""
+    from qml_essentials_amd.model import Model
+
+    rng = np.random.default_rng(3)
+    m = Model(3, 1, "Circuit_19")
+    spec = OC.ModelSpec(3, 1, "Circuit_19")
+    P = rng.uniform(0, 2 * np.pi, (4, *spec.params_shape)).astype(np.float32)
+    X = rng.uniform(0, 3, (5, 1)).astype(np.float32)
+    got = m(params=P, inputs=X)
+    assert got.shape == (5, 4, 3)
+    for i in range(5):
+        for j in range(4):
+            want = oracle_expval(spec, P[j], X[i], zero_inputs_batch1=False)
+            assert np.abs(got[i, j] - want).max() < 1e-6
+    dens = m(params=P, execution_type="density")
+    assert dens.shape == (4, 8, 8)
+    for j in range(4):
+        single = m(params=P[j], execution_type="density")
+        assert np.abs(single - dens[j]).max() < 1e-6
+    m = Model(3, 1, "Circuit_19")
+    m.params = P
+    assert m(inputs=X, force_mean=True).shape == (5, 4)
+
+
+def test_output_shapes_and_partial_measurements():
+    """tests/test_model.py:928-1053 (the shot-free rows) + test_parity :1057-1079."""
+    from qml_essentials_amd.model import Model
+    import warnings
+
+    x3 = np.array([0.1, 0.2, 0.3], dtype=np.float32)
+    cases = [(np.array(0.1), "expval", [0, 1], False, (2,)), (x3, "expval", [0, 1], False, (3, 2)),
+             (x3, "expval", [0, 1], True, (3,)), (None, "density", -1, False, (4, 4)),
+             (x3, "density", -1, False, (3, 4, 4)), (x3, "density", 0, False, (3, 2, 2)),
+             (x3, "probs", -1, False, (3, 2, 2)), (x3, "probs", 0, False, (3, 2)),
+             (x3, "state", -1, False, (3, 4))]
+    for inputs, et, oq, fm, shape in cases:
+        m = Model(2, 1, "Circuit_19", output_qubit=oq)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = m(m.params, inputs=inputs, force_mean=fm, execution_type=et)
+        assert out.shape == shape, (et, oq, out.shape)
+    # partial density / probs agree with the oracle reductions
+    rng = np.random.default_rng(5)
+    spec = OC.ModelSpec(3, 1, "Circuit_19")
+    p = rng.uniform(0, 6, spec.params_shape).astype(np.float32)
+    psi = OE.simulate_pure(OC.model_tape(spec, p, [0.4]), 3, c128)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = Model(3, 1, "Circuit_19", output_qubit=[0, 2])
+        rho = m(p, inputs=np.array([0.4]), execution_type="density")
+        assert np.abs(rho - OA.partial_trace(np.outer(psi, psi.conj()), 3, [0, 2])).max() < 1e-6
+        pr = m(p, inputs=np.array([0.4]), execution_type="probs")
+        assert np.abs(pr.reshape(-1) - OA.marginalize_probs(np.abs(psi) ** 2, 3, [0, 2])[0]).max() < 1e-6
+    # parity observable Z0 Z1 vs oracle general path
+    ma = Model(2, 1, "Circuit_1", output_qubit=[[0, 1]])
+    pa = np.asarray(ma.params[0])
+    ra = ma(params=pa, inputs=None)
+    zz = np.diag([1, -1, -1, 1]).astype(c128)
+    spec1 = OC.ModelSpec(2, 1, "Circuit_1")
+    want = OE.simulate_and_measure(OC.model_tape(spec1, pa, [0.0]), 2, "expval",
+                                   [("ZZ", [0, 1], zz)], c128)
+    assert np.abs(np.atleast_1d(ra) - want).max() < 1e-6
+
+
+def test_general_observables_x_and_hermitian():
+    """simulation.py:263-269 general path, matrix-free on the GPU; Bell <X>=<Z>=0
+    (test_jaqsi.py:358-362) and a random 2-qubit Hermitian."""
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd.script import Script
+
+    def bell():
+        op.H(wires=0)
+        op.CX(wires=[0, 1])
+
+    s = Script(bell)
+    for cls in (op.PauliX, op.PauliZ, op.PauliY):
+        r = s.execute(type="expval", obs=[cls(0, record=False), cls(1, record=False)])
+        assert np.abs(r).max() < 1e-6
+    assert np.allclose(s.execute(type="probs"), [0.5, 0, 0, 0.5], atol=1e-6)
+    rng = np.random.default_rng(9)
+    A = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    Hm = (A + A.conj().T) / 2
+
+    def circ(th):
+        op.RY(th, wires=0)
+        op.CRX(0.7, wires=[0, 2])
+        op.RX(th * 2, wires=1)
+
+    s = Script(circ, n_qubits=3)
+    th = np.linspace(0, 2, 5).astype(np.float32)
+    got = s.execute(type="expval", obs=[op.Hermitian(Hm, wires=[2, 0], record=False),
+                                        op.PauliX(1, record=False)], args=(th,), in_axes=(0,))
+    for b, t in enumerate(th):
+        tape = [("RY", [0], (float(t),)), ("CRX", [0, 2], (0.7,)), ("RX", [1], (float(2 * t),))]
+        want = OE.simulate_and_measure(tape, 3, "expval", [("H", [2, 0], Hm), ("PauliX", [1])], c128)
+        assert np.abs(got[b] - want).max() < 2e-6
+    # two-argument broadcast: cos(theta + phi)  (test_jaqsi.py:789-821)
+    s2 = Script(lambda a, b: (op.RX(a, wires=0), op.RX(b, wires=0)))
+    r = s2.execute(type="expval", obs=[op.PauliZ(0, record=False)],
+                   args=(th, np.float32(0.3)), in_axes=(0, None))
+    assert np.abs(r[:, 0] - np.cos(th + 0.3)).max() < 1e-6
+
+
+def test_config2_model_20q_4l_vs_oracle():
+    """BASELINE config 2 (C2): n=20, L=4, HE, 480 gates; <= 1e-6 vs the fp64 oracle."""
+    from qml_essentials_amd.model import Model
+
+    rng = np.random.default_rng(1000)
+    m = Model(20, 4, "Hardware_Efficient")
+    spec = OC.ModelSpec(20, 4, "Hardware_Efficient")
+    p = rng.uniform(0, 2 * np.pi, spec.params_shape).astype(np.float32)
+    got = m(params=p, inputs=np.array([0.5], dtype=np.float32))
+    want = oracle_expval(spec, p, 0.5)
+    assert got.shape == (20,)
+    assert np.abs(got - want).max() < 1e-6, np.abs(got - want).max()
+
+
+def test_golomb_model_vs_oracle():
+    from qml_essentials_amd.ansaetze import Encoding
+    from qml_essentials_amd.model import Model
+
+    m = Model(3, 1, "Circuit_19", encoding=Encoding("golomb", None))
+    spec = OC.ModelSpec(3, 1, "Circuit_19", strategy="golomb")
+    p = np.random.default_rng(2).uniform(0, 6, spec.params_shape).astype(np.float32)
+    X = np.array([[0.1], [0.45]], dtype=np.float32)
+    got = m(params=p, inputs=X)
+    for i in range(2):
+        assert np.abs(got[i] - oracle_expval(spec, p, X[i], zero_inputs_batch1=False)).max() < 5e-6
+
+
+def test_expressibility_pure_formula_equals_reference_form():
+    """F via the overlap kernel == the reference's density + sqrtm formula (n=3)."""
+    from qml_essentials_amd.expressibility import Expressibility
+    from qml_essentials_amd.model import Model
+
+    m = Model(3, 1, "Circuit_19", data_reupload=False)
+    fid = Expressibility._sample_state_fidelities(m, 12, random_key=11, kwargs={}).cpu().numpy()
+    P = np.asarray(m.params)
+    assert P.shape[0] == 24 and fid.shape == (12,)
+    spec = OC.ModelSpec(3, 1, "Circuit_19", data_reupload=False)
+    states = np.array([OE.simulate_pure(OC.model_tape(spec, P[i], [0.0]), 3, c128) for i in range(24)])
+    rhos = np.array([np.outer(s, s.conj()) for s in states])
+    assert np.abs(fid - OA.fidelities_reference_form(rhos, 12)).max() < 1e-5
+    assert np.abs(fid - OA.fidelities_pure(states, 12)).max() < 1e-6
+    y, z = Expressibility.state_fidelities(n_samples=10, n_bins=4, model=Model(2, 1, "Circuit_1"),
+                                           scale=True)
+    assert z.shape == (8,) and abs(z.sum() - 1) < 1e-6  # test_expressiblity.py:192-215
+    _, h = Expressibility.haar_integral(n_qubits=2, n_bins=4, scale=True)
+    assert h.shape == (8,)
+    assert np.allclose(Expressibility.haar_integral(4, 75)[1], OA.haar_integral(4, 75), atol=1e-10)
+    ha = Expressibility.haar_integral(2, 10)[1]
+    assert abs(Expressibility.kullback_leibler_divergence(ha, ha).mean()) < 1e-3
+
+
+@pytest.mark.parametrize("layers", [1, 3])
+def test_expressibility_sim_et_al_table(layers, golden_dir):
+    """tests/test_expressiblity.py:116-188: KL to Haar within 40 % of Sim et al."""
+    from qml_essentials_amd.expressibility import Expressibility
+    from qml_essentials_amd.model import Model
+
+    fx = json.load(open(os.path.join(golden_dir, "sim_et_al.json")))["expressibility"]
+    skip = set(fx[f"skip_layers_{layers}"])
+    got, want = [], []
+    for cid, ref in zip(fx["circuits"], fx[f"kl_layers_{layers}"]):
+        if cid in skip:
+            continue
+        m = Model(n_qubits=4, n_layers=layers, circuit_type=f"Circuit_{cid}",
+                  initialization_domain=fx["initialization_domain"], data_reupload=False)
+        kl = float(Expressibility.kl_divergence_to_haar(m, n_samples=fx["n_samples"],
+                                                        n_bins=fx["n_bins"], random_key=1000).mean())
+        assert abs(kl - ref) / ref < fx["tolerance"], (cid, kl, ref)
+        got.append(kl)
+        want.append(ref)
+    # rank agreement (the reference asserts identical order with its own RNG stream)
+    from scipy.stats import spearmanr
+    assert spearmanr(got, want).correlation > 0.9
+
+
+def test_meyer_wallach_table_and_anchors(golden_dir):
+    """tests/test_entanglement.py:100-181: within 55 % of Sim et al.; C1 -> 0, C9 -> 1."""
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+
+    fx = json.load(open(os.path.join(golden_dir, "sim_et_al.json")))["meyer_wallach"]
+    got, want = [], []
+    for cid, ref in zip(fx["circuits"], fx["mw_layers_1"]):
+        if cid in fx["skip"]:
+            continue
+        m = Model(4, 1, f"Circuit_{cid}", data_reupload=False)
+        q = Entanglement.meyer_wallach(m, n_samples=fx["n_samples"], random_key=1000)
+        if ref in (0.0, 1.0):
+            assert abs(q - ref) < 1e-5, (cid, q)
+        else:
+            assert abs(q - ref) / ref < fx["tolerance"], (cid, q, ref)
+        got.append(q)
+        want.append(ref)
+    from scipy.stats import spearmanr
+    assert spearmanr(got, want).correlation > 0.9
+    # no sampling: uses the model's current params (tests/test_entanglement.py:185-200)
+    m = Model(3, 2, "Strongly_Entangling")
+    q = Entanglement.meyer_wallach(m, n_samples=None)
+    spec = OC.ModelSpec(3, 2, "Strongly_Entangling")
+    psi = OE.simulate_pure(OC.model_tape(spec, m.params[0], [0.0]), 3, c128)
+    assert abs(q - OA.meyer_wallach_pure(psi, 3)) < 1e-6
+    rho = np.outer(psi, psi.conj())[None]
+    assert abs(Entanglement._compute_meyer_wallach_meas(rho, 3)[0] - OA.meyer_wallach_reference_form(rho[0], 3)) < 1e-10
+
+
+def test_coefficients_spectrum_vs_oracle():
+    """coefficients.py:109-150 vs the oracle FFT on the same parameters; series
+    re-evaluation (test_coefficients.py:59-70) and |c_k| = |c_-k| (:259-269)."""
+    from qml_essentials_amd.coefficients import Coefficients
+    from qml_essentials_amd.model import Model
+
+    m = Model(2, 1, "Circuit_19")
+    spec = OC.ModelSpec(2, 1, "Circuit_19")
+    p = np.asarray(m.params[0])
+    coeffs, freqs = Coefficients.get_spectrum(m)
+    axes, grid, n_freqs = OA.fourier_grid(spec.degree)
+    outs = np.array([oracle_expval(spec, p, x, zero_inputs_batch1=False).mean() for x in grid])
+    want_c, want_f = OA.fourier_transform(outs, axes, n_freqs)
+    assert np.allclose(freqs, want_f[0]) and np.abs(coeffs - want_c).max() < 1e-6
+    for x in (0.3, 2.2):
+        series = Coefficients.evaluate_Fourier_series(coeffs, freqs, np.array([x]))
+        assert abs(series - m(inputs=np.array([x], dtype=np.float32), force_mean=True)) < 1e-5
+    assert np.allclose(np.abs(coeffs[1:]), np.abs(coeffs[1:][::-1]), atol=1e-6)
+    c2, f2 = Coefficients.get_spectrum(m, mfs=3, shift=True)
+    assert len(c2) == 15 and len(f2) == 15  # test_coefficients.py:242-256
+    c3, f3 = Coefficients.get_spectrum(m, mfs=2, trim=True)
+    assert len(c3) == 9  # even spectrum loses exactly the Nyquist bin (:272-286)
+    # two input features: 2-D grid, feature 0 slowest
+    m2 = Model(2, 1, "Circuit_19", encoding=["RX", "RY"])
+    c, f = Coefficients.get_spectrum(m2)
+    assert c.shape == (5, 5) and len(f) == 2
