@@ -155,6 +155,13 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
 int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream);
 
+/* Optional per-pass HIP-event timing (bench.py's live roofline measurement): between
+ * begin and end every pass launch of this plan is bracketed by an event pair on the
+ * launch stream.  end() synchronises, fills stage_ms[i] / stage_launches[i] (i = pass
+ * index of qmle_plan_describe) and returns 1 if `capacity` pairs were not enough. */
+int qmle_profile_begin(qmle_plan *plan, int capacity);
+int qmle_profile_end(qmle_plan *plan, double *stage_ms, int64_t *stage_launches, int n_stages);
+
 /* ---- stand-alone measurement / analysis kernels on resident states ---------- */
 /* d_states: [batch][2^n] complex64 */
 int qmle_expval_z(const void *d_states, int n_qubits, int batch, const int32_t *obs_wires,

@@ -89,6 +89,8 @@ SYMBOLS = [
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_apply_inplace", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_profile_begin", _I, [_VP, _I]),
+    ("qmle_profile_end", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
     ("qmle_expval_z", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_expval_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_probs", _I, [_VP, _I, _I, _VP, _VP]),
@@ -115,6 +117,11 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7).  It must be
+        # in the process BEFORE libqmle_sv.so resolves that soname, otherwise a second
+        # HIP runtime (/opt/rocm) is loaded and torch's device pointers are foreign to it.
+        import torch  # noqa: F401
+
         handle = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(handle, name)  # AttributeError if the export is missing
@@ -211,6 +218,19 @@ class Plan:
         keys = ["n_ops", "n_passes", "whole_state_lds", "tile_bits", "mat_floats",
                 "direct_passes", "n_lowered", "algo_bytes_per_state"]
         return dict(zip(keys, [int(v) for v in arr]))
+
+    def profile_begin(self, capacity: int) -> None:
+        check(lib().qmle_profile_begin(self._h, int(capacity)), "qmle_profile_begin")
+
+    def profile_end(self):
+        """-> (ms per pass, launches per pass, pool_overflowed)."""
+        n = max(1, self.stats()["n_passes"])
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        rc = lib().qmle_profile_end(self._h, ms, cnt, n)
+        if rc < 0:
+            check(rc, "qmle_profile_end")
+        return list(ms), [int(c) for c in cnt], bool(rc)
 
     def workspace_bytes(self, batch: int, meas: str, n_obs: int = 0, states_in_flight: int = 0):
         return int(lib().qmle_workspace_bytes(self._h, batch, MEAS[meas], n_obs, states_in_flight))

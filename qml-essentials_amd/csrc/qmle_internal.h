@@ -65,6 +65,13 @@ struct Stage {
   double algo_bytes_per_state = 0;     // SURVEY 8-d bytes of the covered gates
 };
 
+struct StageProfile {  // optional HIP-event timing of every stage launch (bench.py)
+  bool on = false;
+  std::vector<void *> start, stop;  // hipEvent_t pairs
+  std::vector<int> stage;           // stage index per recorded pair
+  size_t used = 0;
+};
+
 struct DevicePlan {  // lazily created by the first run on a device
   void *blob = nullptr;
   size_t blob_bytes = 0;
@@ -92,6 +99,7 @@ struct qmle_plan {
   int tile_T = 0, tile_L = 0;
   double algo_bytes_per_state = 0;
   qmle::DevicePlan dev;
+  qmle::StageProfile prof;
 };
 
 namespace qmle {

@@ -977,6 +977,24 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
   return QMLE_OK;
 }
 
+struct ProfScope {  // records a start/stop event pair around one stage launch
+  qmle_plan *p;
+  hipStream_t stream;
+  size_t slot;
+  bool active;
+  ProfScope(qmle_plan *plan, int stage_idx, hipStream_t s) : p(plan), stream(s), slot(0), active(false) {
+    StageProfile &pr = plan->prof;
+    if (pr.on && pr.used < pr.start.size()) {
+      slot = pr.used++;
+      pr.stage[slot] = stage_idx;
+      active = hipEventRecord((hipEvent_t)pr.start[slot], stream) == hipSuccess;
+    }
+  }
+  ~ProfScope() {
+    if (active) (void)hipEventRecord((hipEvent_t)p->prof.stop[slot], stream);
+  }
+};
+
 int expval_blocks(int n) {
   const uint64_t chunks = (uint64_t)1 << (n - 1);
   const uint64_t seg = (uint64_t)kEzThreads * kEzUnroll;
@@ -1186,6 +1204,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
         const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
         const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
         const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
+        ProfScope prof_scope(plan, 0, stream);
         if (meas_type == QMLE_MEAS_STATE)
           rc = launch_tile(plan, st, (float2 *)d_out + (size_t)b0 * D, mats, ang, bc, true,
                            TM_STORE, nullptr, nullptr, 0, stream);
@@ -1229,6 +1248,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
     bool initialised = false;
     for (size_t si = 0; si < plan->stages.size(); ++si) {
       const Stage &st = plan->stages[si];
+      ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE) {
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, TM_STORE, nullptr, nullptr,
                          0, stream);
@@ -1295,7 +1315,9 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
   }
   const int n = plan->n;
   const size_t D = (size_t)1 << n;
+  int stage_idx = -1;
   for (const Stage &st : plan->stages) {
+    ProfScope prof_scope(plan, ++stage_idx, stream);
     if (st.kind == ST_TILE) {
       rc = launch_tile(plan, st, (float2 *)d_states, d_mats, d_angles, batch, false, TM_STORE,
                        nullptr, nullptr, 0, stream);
@@ -1312,6 +1334,44 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
   }
   HIPCHK(hipGetLastError());
   return QMLE_OK;
+}
+
+int qmle_profile_begin(qmle_plan *plan, int capacity) {
+  if (!plan || capacity < 1) return QMLE_ERR_INVALID_ARG;
+  StageProfile &pr = plan->prof;
+  while ((int)pr.start.size() < capacity) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    pr.start.push_back((void *)a);
+    pr.stop.push_back((void *)b);
+  }
+  pr.stage.assign(pr.start.size(), -1);
+  pr.used = 0;
+  pr.on = true;
+  return QMLE_OK;
+}
+
+int qmle_profile_end(qmle_plan *plan, double *stage_ms, int64_t *stage_launches, int n_stages) {
+  if (!plan || !stage_ms || !stage_launches || n_stages < (int)plan->stages.size())
+    return QMLE_ERR_INVALID_ARG;
+  StageProfile &pr = plan->prof;
+  pr.on = false;
+  for (int i = 0; i < n_stages; ++i) { stage_ms[i] = 0.0; stage_launches[i] = 0; }
+  for (size_t k = 0; k < pr.used; ++k) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)pr.stop[k]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)pr.start[k], (hipEvent_t)pr.stop[k]));
+    stage_ms[pr.stage[k]] += ms;
+    stage_launches[pr.stage[k]] += 1;
+  }
+  const int dropped = pr.used >= pr.start.size() ? 1 : 0;
+  for (size_t k = 0; k < pr.start.size(); ++k) {
+    (void)hipEventDestroy((hipEvent_t)pr.start[k]);
+    (void)hipEventDestroy((hipEvent_t)pr.stop[k]);
+  }
+  pr.start.clear(); pr.stop.clear(); pr.stage.clear(); pr.used = 0;
+  return dropped;  // 1 = the pool filled up (later launches were not timed)
 }
 
 size_t qmle_expval_workspace_bytes(int n_qubits, int batch) {
