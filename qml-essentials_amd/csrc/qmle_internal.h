@@ -19,7 +19,22 @@ enum LKind : uint8_t {
 };
 enum LFlag : uint8_t {
   LF_DIAG = 1,     // matrix is diagonal
+  LF_PERMX = 2,    // matrix is exactly Pauli-X (CX / CCX / X): a pure swap of amplitudes
 };
+
+// A run of ops applied in ONE LDS round trip: every thread gathers the 2^4 amplitudes
+// spanned by `bits` into registers, applies all ops of the group there, scatters back.
+enum GKind : uint8_t { GK_SWEEP = 0 /* one op, LDS sweep */, GK_REG4 = 1 };
+struct OpGroup {
+  uint8_t kind;
+  uint8_t n_ops;
+  uint8_t bits[4];    // GK_REG4: tile-local bit positions, ascending
+  uint8_t pad[2];
+  uint32_t op_begin;  // first op (index into the plan's dev_ops); ops of a GK_REG4
+                      // group carry GROUP-local bit indices 0..3 in t0 / c0
+  uint32_t pad2;
+};
+static_assert(sizeof(OpGroup) == 16, "OpGroup layout");
 
 // Device-visible lowered operation (16 bytes).
 struct LoweredOp {
@@ -57,6 +72,7 @@ enum StageKind : int { ST_DIRECT = 0, ST_TILE = 1, ST_DIAG_ALL = 2 };
 struct Stage {
   int kind = ST_TILE;
   int op_begin = 0, op_end = 0;  // range in Plan::dev_ops
+  int grp_begin = 0, grp_end = 0;  // range in Plan::op_groups (tile stages)
   int T = 0, L = 0;              // tile qubits, contiguous low bits
   int n_tile_ops = 0;
   int8_t tile_bits[QMLE_MAX_QUBITS];   // ascending global positions of local bits
@@ -76,6 +92,7 @@ struct DevicePlan {  // lazily created by the first run on a device
   void *blob = nullptr;
   size_t blob_bytes = 0;
   LoweredOp *d_ops = nullptr;
+  OpGroup *d_op_groups = nullptr;
   BuildOp *d_build = nullptr;
   BuildGroup *d_groups = nullptr;
   float *d_consts = nullptr;
@@ -91,6 +108,7 @@ struct qmle_plan {
   std::vector<qmle::LoweredOp> lowered;   // after 1-q merging, global positions
   std::vector<std::vector<int>> lowered_src;  // reference ops per lowered op
   std::vector<qmle::LoweredOp> dev_ops;   // per stage, stage-local positions
+  std::vector<qmle::OpGroup> op_groups;   // register-tile groups of the tile stages
   std::vector<qmle::BuildOp> build_ops;
   std::vector<qmle::BuildGroup> groups;
   std::vector<qmle::Stage> stages;

@@ -88,6 +88,80 @@ double algo_bytes(const qmle_op &op, int n) {
   }
 }
 
+// Partition the ops of one tile stage into register-tile groups (<= 4 tile-local bits
+// per group, dependency order preserved: an op may only move ahead of ops it shares no
+// bit with).  Rewrites dev_ops[st.op_begin, st.op_end) into group order.
+static void group_stage_ops(qmle_plan *p, Stage &st) {
+  const int nops = st.op_end - st.op_begin;
+  st.grp_begin = (int)p->op_groups.size();
+  std::vector<LoweredOp> src(p->dev_ops.begin() + st.op_begin, p->dev_ops.begin() + st.op_end);
+  std::vector<LoweredOp> out;
+  out.reserve(nops);
+  std::vector<char> done(nops, 0);
+  const bool regs_ok = st.T >= 4 && !(p->flags & QMLE_PLAN_NO_REGTILE);
+  auto groupable = [&](const LoweredOp &o) { return regs_ok && o.kind == LK_1Q && o.nc <= 1; };
+  auto mask_of = [&](const LoweredOp &o) -> uint32_t {
+    if (o.kind == LK_DIAG_ALL) return st.T >= 32 ? ~0u : ((1u << st.T) - 1u);
+    uint32_t m = 1u << o.t0;
+    if (o.t1 >= 0) m |= 1u << o.t1;
+    if (o.c0 >= 0) m |= 1u << o.c0;
+    if (o.c1 >= 0) m |= 1u << o.c1;
+    return m;
+  };
+  int n_done = 0;
+  while (n_done < nops) {
+    int first = 0;
+    while (done[first]) ++first;
+    OpGroup g{};
+    g.op_begin = (uint32_t)(st.op_begin + out.size());
+    if (!groupable(src[first])) {
+      g.kind = GK_SWEEP;
+      g.n_ops = 1;
+      out.push_back(src[first]);
+      done[first] = 1;
+      ++n_done;
+      p->op_groups.push_back(g);
+      continue;
+    }
+    g.kind = GK_REG4;
+    uint32_t G = 0, blocked = 0;
+    std::vector<int> mem;
+    for (int i = first; i < nops && mem.size() < 255; ++i) {
+      if (done[i]) continue;
+      const uint32_t m = mask_of(src[i]);
+      if ((m & blocked) || !groupable(src[i])) {
+        blocked |= m;
+      } else if (__builtin_popcount(G | m) <= 4) {
+        G |= m;
+        mem.push_back(i);
+      } else {
+        blocked |= m;
+      }
+    }
+    // pad to 4 bits: prefer positions >= 5 (bank-conflict-free gathers), then anything free
+    for (int b = 5; b < st.T && __builtin_popcount(G) < 4; ++b) G |= 1u << b;
+    for (int b = 0; b < st.T && __builtin_popcount(G) < 4; ++b) G |= 1u << b;
+    int8_t local_of[32];
+    int k = 0;
+    for (int b = 0; b < st.T; ++b) {
+      local_of[b] = -1;
+      if (G & (1u << b)) { g.bits[k] = (uint8_t)b; local_of[b] = (int8_t)k++; }
+    }
+    g.n_ops = (uint8_t)mem.size();
+    for (int i : mem) {
+      LoweredOp o = src[i];
+      o.t0 = local_of[(int)o.t0];
+      if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
+      out.push_back(o);
+      done[i] = 1;
+      ++n_done;
+    }
+    p->op_groups.push_back(g);
+  }
+  std::copy(out.begin(), out.end(), p->dev_ops.begin() + st.op_begin);
+  st.grp_end = (int)p->op_groups.size();
+}
+
 int compile_plan(qmle_plan *p) {
   const int n = p->n;
   if (n < 1 || n > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
@@ -136,6 +210,8 @@ int compile_plan(qmle_plan *p) {
     lo.t1 = lo.c0 = lo.c1 = -1;
     lo.slot = -1;
     lo.flags = is_diag_opcode(op.opcode) ? LF_DIAG : 0;
+    if (op.opcode == QMLE_OP_X || op.opcode == QMLE_OP_CX || op.opcode == QMLE_OP_CCX)
+      lo.flags |= LF_PERMX;
     BuildOp bo{};
     bo.opcode = op.opcode;
     for (int a = 0; a < 3; ++a) bo.slot[a] = op.slot[a];
@@ -185,6 +261,7 @@ int compile_plan(qmle_plan *p) {
         if (pl.kind == LK_1Q && pl.nc == 0 && pl.t0 == lo.t0) {
           group_ops[group_of[prev]].push_back(bo);
           if (!(lo.flags & LF_DIAG)) pl.flags &= ~LF_DIAG;
+          pl.flags &= ~LF_PERMX;  // a product of gates is a general 2x2
           p->lowered_src[prev].push_back((int)i);
           continue;
         }
@@ -235,6 +312,7 @@ int compile_plan(qmle_plan *p) {
   // ---- 3. schedule into stages ------------------------------------------------
   p->stages.clear();
   p->dev_ops.clear();
+  p->op_groups.clear();
   const size_t nl = p->lowered.size();
   std::vector<char> done(nl, 0);
   size_t n_done = 0;
@@ -326,6 +404,7 @@ int compile_plan(qmle_plan *p) {
     }
     st.op_end = (int)p->dev_ops.size();
     st.n_tile_ops = st.op_end - st.op_begin;
+    if (st.kind == ST_TILE) group_stage_ops(p, st);
     for (int mi : members) {
       done[mi] = 1;
       ++n_done;
@@ -362,7 +441,8 @@ std::string describe_plan(const qmle_plan *p) {
     os << "{\"kind\":\""
        << (st.kind == ST_DIRECT ? "direct" : st.kind == ST_TILE ? "tile" : "diag_all")
        << "\",\"n_lowered\":" << (st.op_end - st.op_begin) << ",\"T\":" << st.T
-       << ",\"L\":" << st.L << ",\"algo_bytes_per_state\":" << st.algo_bytes_per_state
+       << ",\"L\":" << st.L << ",\"lds_round_trips\":" << (st.grp_end - st.grp_begin)
+       << ",\"algo_bytes_per_state\":" << st.algo_bytes_per_state
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
     os << "],\"src_ops\":[";

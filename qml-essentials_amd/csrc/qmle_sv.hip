@@ -93,6 +93,25 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   return t;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+// fp64 block sum for the tiny "final" kernels; result valid in thread 0; red >= 16 doubles
+__device__ __forceinline__ double block_sum_d(double v, double *red) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int nw = (blockDim.x + kWave - 1) / kWave;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
 // ---------------------------------------------------------------------------
 // per-sample gate matrices  (operations.py:1002-1045, 1053-1100, 1171-1243,
 // 1255-1351, 1357-1487 -- matrices restated, evaluated in fp64, stored fp32)
@@ -220,12 +239,110 @@ enum TileMeas : int {
   TM_EXPVAL = 2,  // whole-state only: <Z> on obs bits
 };
 
+// LDS layout of a tile: amplitude e lives in slot sw(e).  XOR-ing bits 1..4 with bits
+// 5..8 keeps (even, odd) pairs adjacent (float4 staging) and spreads the 16-amplitude
+// register gathers of low-bit groups over the banks (<= 2-way instead of 16-way).
+__device__ __forceinline__ uint32_t sw(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }
+
+// ---- register-tile appliers: a[16] = amplitudes over 4 group bits, static indexing ----
+template <int TB, int MODE>  // MODE 0 dense, 1 diagonal, 2 Pauli-X swap
+__device__ __forceinline__ void reg_1q(float2 (&a)[16], const Mat2 &m) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c & (1 << TB)) continue;
+    if (MODE == 0) {
+      apply2(m, a[c], a[c | (1 << TB)]);
+    } else if (MODE == 1) {
+      a[c] = cmul(m.m00, a[c]);
+      a[c | (1 << TB)] = cmul(m.m11, a[c | (1 << TB)]);
+    } else {
+      const float2 t = a[c];
+      a[c] = a[c | (1 << TB)];
+      a[c | (1 << TB)] = t;
+    }
+  }
+}
+template <int CB, int TB, int MODE>
+__device__ __forceinline__ void reg_c1q(float2 (&a)[16], const Mat2 &m) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if ((c & (1 << TB)) || !(c & (1 << CB))) continue;
+    if (MODE == 0) {
+      apply2(m, a[c], a[c | (1 << TB)]);
+    } else if (MODE == 1) {
+      a[c] = cmul(m.m00, a[c]);
+      a[c | (1 << TB)] = cmul(m.m11, a[c | (1 << TB)]);
+    } else {
+      const float2 t = a[c];
+      a[c] = a[c | (1 << TB)];
+      a[c | (1 << TB)] = t;
+    }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void reg_dispatch(float2 (&a)[16], const Mat2 &m, int cb, int tb) {
+  if (cb < 0) {
+    switch (tb) {
+      case 0: reg_1q<0, MODE>(a, m); break;
+      case 1: reg_1q<1, MODE>(a, m); break;
+      case 2: reg_1q<2, MODE>(a, m); break;
+      default: reg_1q<3, MODE>(a, m); break;
+    }
+    return;
+  }
+  switch (cb * 4 + tb) {
+    case 1: reg_c1q<0, 1, MODE>(a, m); break;
+    case 2: reg_c1q<0, 2, MODE>(a, m); break;
+    case 3: reg_c1q<0, 3, MODE>(a, m); break;
+    case 4: reg_c1q<1, 0, MODE>(a, m); break;
+    case 6: reg_c1q<1, 2, MODE>(a, m); break;
+    case 7: reg_c1q<1, 3, MODE>(a, m); break;
+    case 8: reg_c1q<2, 0, MODE>(a, m); break;
+    case 9: reg_c1q<2, 1, MODE>(a, m); break;
+    case 11: reg_c1q<2, 3, MODE>(a, m); break;
+    case 12: reg_c1q<3, 0, MODE>(a, m); break;
+    case 13: reg_c1q<3, 1, MODE>(a, m); break;
+    default: reg_c1q<3, 2, MODE>(a, m); break;
+  }
+}
+
+// One GK_REG4 group: gather 16 amplitudes per work item, apply every op, scatter.
+__device__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
+                                const LoweredOp *__restrict__ ops,
+                                const float *__restrict__ mrow) {
+  const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+  uint32_t off[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    off[c] = ((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
+             ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u);
+  const uint32_t cnt = 1u << (T - 4);
+  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const uint32_t base = ins0(ins0(ins0(ins0(i, b0), b1), b2), b3);
+    float2 a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = s[sw(base | off[c])];
+    for (int k = 0; k < g.n_ops; ++k) {
+      const LoweredOp op = ops[g.op_begin + k];
+      const Mat2 m = load_mat2(mrow + op.mat_off);
+      const int cb = op.nc ? op.c0 : -1;
+      if (op.flags & LF_PERMX) reg_dispatch<2>(a, m, cb, op.t0);
+      else if (op.flags & LF_DIAG) reg_dispatch<1>(a, m, cb, op.t0);
+      else reg_dispatch<0>(a, m, cb, op.t0);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s[sw(base | off[c])] = a[c];
+  }
+}
+
 struct TileArgs {
   float2 *states;           // [B][2^n] (read unless init_zero; written for TM_STORE)
   const float *mats;        // [B][mat_floats]
   const float *angles;      // [B][n_slots]
   const float *consts;
-  const LoweredOp *ops;     // this stage's ops, tile-local bit positions
+  const LoweredOp *ops;     // the plan's op array (groups index into it)
+  const OpGroup *groups;    // this stage's groups
+  int n_groups;
   void *out;                // TM_PROBS: float [B][2^n]; TM_EXPVAL: float [B][n_obs]
   uint32_t mat_floats;
   int n_ops, n, T, L, n_slots;
@@ -255,16 +372,16 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
       if (op.flags & LF_DIAG) {
         for (uint32_t i = tid; i < cnt; i += nt) {
           const uint32_t j0 = ins0(i, op.t0), j1 = j0 | tb;
-          s[j0] = cmul(m.m00, s[j0]);
-          s[j1] = cmul(m.m11, s[j1]);
+          s[sw(j0)] = cmul(m.m00, s[sw(j0)]);
+          s[sw(j1)] = cmul(m.m11, s[sw(j1)]);
         }
       } else {
         for (uint32_t i = tid; i < cnt; i += nt) {
           const uint32_t j0 = ins0(i, op.t0), j1 = j0 | tb;
-          float2 a0 = s[j0], a1 = s[j1];
+          float2 a0 = s[sw(j0)], a1 = s[sw(j1)];
           apply2(m, a0, a1);
-          s[j0] = a0;
-          s[j1] = a1;
+          s[sw(j0)] = a0;
+          s[sw(j1)] = a1;
         }
       }
     } else {
@@ -278,15 +395,15 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
         if (op.nc == 2) j0 = ins0(j0, p2);
         j0 |= cm;
         const uint32_t j1 = j0 | tb;
-        float2 a0 = s[j0], a1 = s[j1];
+        float2 a0 = s[sw(j0)], a1 = s[sw(j1)];
         if (diag) {
           a0 = cmul(m.m00, a0);
           a1 = cmul(m.m11, a1);
         } else {
           apply2(m, a0, a1);
         }
-        s[j0] = a0;
-        s[j1] = a1;
+        s[sw(j0)] = a0;
+        s[sw(j1)] = a1;
       }
     }
   } else if (op.kind == LK_2Q) {
@@ -303,7 +420,7 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
       uint32_t j = ins0(ins0(i, p0), p1);
       if (op.nc) j = ins0(j, p2);
       j |= cm;
-      const float2 a0 = s[j], a1 = s[j | b1], a2 = s[j | b0], a3 = s[j | b0 | b1];
+      const float2 a0 = s[sw(j)], a1 = s[sw(j | b1)], a2 = s[sw(j | b0)], a3 = s[sw(j | b0 | b1)];
       float2 r[4];
 #pragma unroll
       for (int row = 0; row < 4; ++row) {
@@ -313,10 +430,10 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
         acc = cfma(M[row * 4 + 3], a3, acc);
         r[row] = acc;
       }
-      s[j] = r[0];
-      s[j | b1] = r[1];
-      s[j | b0] = r[2];
-      s[j | b0 | b1] = r[3];
+      s[sw(j)] = r[0];
+      s[sw(j | b1)] = r[1];
+      s[sw(j | b0)] = r[2];
+      s[sw(j | b0 | b1)] = r[3];
     }
   } else {  // LK_DIAG_ALL (whole-state tile only: local index == global index)
     const float x = ang[op.slot];
@@ -325,7 +442,7 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
     for (uint32_t j = tid; j < cnt; j += nt) {
       float sn, cs;
       sincosf(marks[j] * x, &sn, &cs);
-      s[j] = cmul(make_float2(cs, -sn), s[j]);
+      s[sw(j)] = cmul(make_float2(cs, -sn), s[sw(j)]);
     }
   }
 }
@@ -357,20 +474,22 @@ __global__ void k_tile(const TileArgs a) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t jc = tid; jc < half; jc += nt) reinterpret_cast<float4 *>(s)[jc] = z;
     __syncthreads();
-    if (tid == 0 && base == 0) s[0] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+    if (tid == 0 && base == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
   } else {
     for (uint32_t jc = tid; jc < half; jc += nt) {
       const uint32_t j = jc * 2u;
       const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      reinterpret_cast<float4 *>(s)[jc] = *reinterpret_cast<const float4 *>(st + g);
+      reinterpret_cast<float4 *>(s)[sw(j) >> 1] = *reinterpret_cast<const float4 *>(st + g);
     }
   }
   __syncthreads();
 
   const float *mrow = a.mats + (size_t)b * a.mat_floats;
   const float *ang = a.angles + (size_t)b * a.n_slots;
-  for (int k = 0; k < a.n_ops; ++k) {
-    lds_apply(s, T, a.ops[k], mrow, a.consts, ang);
+  for (int gi = 0; gi < a.n_groups; ++gi) {
+    const OpGroup g = a.groups[gi];
+    if (g.kind == GK_REG4) lds_apply_group(s, T, g, a.ops, mrow);
+    else lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
     __syncthreads();
   }
 
@@ -378,14 +497,14 @@ __global__ void k_tile(const TileArgs a) {
     for (uint32_t jc = tid; jc < half; jc += nt) {
       const uint32_t j = jc * 2u;
       const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      *reinterpret_cast<float4 *>(st + g) = reinterpret_cast<float4 *>(s)[jc];
+      *reinterpret_cast<float4 *>(st + g) = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
     }
   } else if (a.meas == TM_PROBS) {
     float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
     for (uint32_t jc = tid; jc < half; jc += nt) {
       const uint32_t j = jc * 2u;
       const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      const float4 v = reinterpret_cast<float4 *>(s)[jc];
+      const float4 v = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
       *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
     }
   } else {  // TM_EXPVAL, T == n
@@ -395,7 +514,7 @@ __global__ void k_tile(const TileArgs a) {
       const int p = a.obs_bits[k];
       float acc = 0.f;
       for (uint32_t j = tid; j < cnt; j += nt) {
-        const float pr = norm2(s[j]);
+        const float pr = norm2(s[sw(j)]);
         acc += ((j >> p) & 1u) ? -pr : pr;
       }
       const float tot = block_sum(acc, red);
@@ -598,16 +717,20 @@ struct ObsBits {
   int8_t bits[QMLE_MAX_QUBITS];
 };
 
-__global__ void k_expval_final(const float *__restrict__ partial, int n_blocks, int n_obs,
-                               ObsBits obs, float *__restrict__ out) {
+__global__ void __launch_bounds__(256)
+k_expval_final(const float *__restrict__ partial, int n_blocks, int n_obs, ObsBits obs,
+               float *__restrict__ out) {
+  __shared__ double red[16];
   const int b = blockIdx.x;
-  const int k = threadIdx.x;
-  if (k >= n_obs) return;
-  const int bitp = obs.bits[k];
-  double acc = 0.0;
   const float *pp = partial + (size_t)b * n_blocks * (QMLE_MAX_QUBITS + 1);
-  for (int i = 0; i < n_blocks; ++i) acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1) + bitp];
-  out[(size_t)b * n_obs + k] = (float)acc;
+  for (int k = 0; k < n_obs; ++k) {
+    const int bitp = obs.bits[k];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x)
+      acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1) + bitp];
+    const double tot = block_sum_d(acc, red);
+    if (threadIdx.x == 0) out[(size_t)b * n_obs + k] = (float)tot;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -677,17 +800,20 @@ k_overlap_partial(const float4 *__restrict__ states, int n, int n_pairs,
   if (threadIdx.x == 0) partial[(size_t)pr * gridDim.x + blockIdx.x] = make_float2(r, i);
 }
 
-__global__ void k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
-                                float *__restrict__ out) {
-  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pr >= n_pairs) return;
+__global__ void __launch_bounds__(256)
+k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
+                float *__restrict__ out) {
+  __shared__ double red[16];
+  const int pr = blockIdx.x;
   double re = 0.0, im = 0.0;
-  for (int i = 0; i < n_blocks; ++i) {
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
     const float2 v = partial[(size_t)pr * n_blocks + i];
     re += v.x;
     im += v.y;
   }
-  out[pr] = (float)(re * re + im * im);
+  re = block_sum_d(re, red);
+  im = block_sum_d(im, red);
+  if (threadIdx.x == 0) out[pr] = (float)(re * re + im * im);
 }
 
 // Meyer-Wallach cross terms c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) plus the
@@ -727,22 +853,29 @@ k_cross_partial(const float4 *__restrict__ states, int n, int p, float4 *__restr
     partial[((size_t)b * n + p) * n_blocks + blockIdx.x] = make_float4(r0, r1, r2, r3);
 }
 
-__global__ void k_mw_final(const float4 *__restrict__ partial, int n, int n_blocks, int batch,
-                           float *__restrict__ out, float *__restrict__ purities) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
+__global__ void __launch_bounds__(256)
+k_mw_final(const float4 *__restrict__ partial, int n, int n_blocks, int batch,
+           float *__restrict__ out, float *__restrict__ purities) {
+  __shared__ double red[16];
+  const int b = blockIdx.x;
   double sum = 0.0;
   for (int p = 0; p < n; ++p) {
     double cr = 0, ci = 0, a = 0, d = 0;
-    for (int i = 0; i < n_blocks; ++i) {
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
       const float4 v = partial[((size_t)b * n + p) * n_blocks + i];
       cr += v.x; ci += v.y; a += v.z; d += v.w;
     }
-    const double pur = a * a + d * d + 2.0 * (cr * cr + ci * ci);
-    if (purities) purities[(size_t)b * n + (n - 1 - p)] = (float)pur;  // index by wire
-    sum += pur;
+    cr = block_sum_d(cr, red);
+    ci = block_sum_d(ci, red);
+    a = block_sum_d(a, red);
+    d = block_sum_d(d, red);
+    if (threadIdx.x == 0) {
+      const double pur = a * a + d * d + 2.0 * (cr * cr + ci * ci);
+      if (purities) purities[(size_t)b * n + (n - 1 - p)] = (float)pur;  // index by wire
+      sum += pur;
+    }
   }
-  out[b] = (float)(2.0 * (1.0 - sum / n));
+  if (threadIdx.x == 0) out[b] = (float)(2.0 * (1.0 - sum / n));
 }
 
 __global__ void __launch_bounds__(256)
@@ -785,17 +918,20 @@ k_overlap2_partial(const float4 *__restrict__ a_all, const float4 *__restrict__ 
   if (threadIdx.x == 0) partial[(size_t)pr * gridDim.x + blockIdx.x] = make_float2(r, i);
 }
 
-__global__ void k_overlap2_final(const float2 *__restrict__ partial, int n_blocks, int count,
-                                 float2 *__restrict__ out) {
-  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pr >= count) return;
+__global__ void __launch_bounds__(256)
+k_overlap2_final(const float2 *__restrict__ partial, int n_blocks, int count,
+                 float2 *__restrict__ out) {
+  __shared__ double red[16];
+  const int pr = blockIdx.x;
   double re = 0.0, im = 0.0;
-  for (int i = 0; i < n_blocks; ++i) {
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
     const float2 v = partial[(size_t)pr * n_blocks + i];
     re += v.x;
     im += v.y;
   }
-  out[pr] = make_float2((float)re, (float)im);
+  re = block_sum_d(re, red);
+  im = block_sum_d(im, red);
+  if (threadIdx.x == 0) out[pr] = make_float2((float)re, (float)im);
 }
 
 // Z-parity expectation: sum_i (-1)^{popcount(i & mask)} |psi_i|^2, up to 8 masks per launch.
@@ -833,15 +969,18 @@ k_parity_partial(const float4 *__restrict__ states, int n, ParityMasks pm,
   }
 }
 
-__global__ void k_parity_final(const float *__restrict__ partial, int n_blocks, int count,
-                               int n_obs_total, int obs_off, float *__restrict__ out) {
+__global__ void __launch_bounds__(256)
+k_parity_final(const float *__restrict__ partial, int n_blocks, int count, int n_obs_total,
+               int obs_off, float *__restrict__ out) {
+  __shared__ double red[16];
   const int b = blockIdx.x;
-  const int k = threadIdx.x;
-  if (k >= count) return;
-  double acc = 0.0;
   const float *pp = partial + (size_t)b * n_blocks * 8;
-  for (int i = 0; i < n_blocks; ++i) acc += (double)pp[(size_t)i * 8 + k];
-  out[(size_t)b * n_obs_total + obs_off + k] = (float)acc;
+  for (int k = 0; k < count; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) acc += (double)pp[(size_t)i * 8 + k];
+    const double tot = block_sum_d(acc, red);
+    if (threadIdx.x == 0) out[(size_t)b * n_obs_total + obs_off + k] = (float)tot;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -862,7 +1001,8 @@ int ensure_device_plan(qmle_plan *p) {
   const size_t b_build = align_up(p->build_ops.size() * sizeof(BuildOp) + 16, 256);
   const size_t b_groups = align_up(p->groups.size() * sizeof(BuildGroup) + 16, 256);
   const size_t b_consts = align_up(p->consts.size() * sizeof(float) + 16, 256);
-  const size_t total = b_ops + b_build + b_groups + b_consts;
+  const size_t b_opg = align_up(p->op_groups.size() * sizeof(OpGroup) + 16, 256);
+  const size_t total = b_ops + b_build + b_groups + b_consts + b_opg;
   char *blob = nullptr;
   HIPCHK(hipMalloc((void **)&blob, total));
   p->dev.blob = blob;
@@ -871,6 +1011,10 @@ int ensure_device_plan(qmle_plan *p) {
   p->dev.d_build = (BuildOp *)(blob + b_ops);
   p->dev.d_groups = (BuildGroup *)(blob + b_ops + b_build);
   p->dev.d_consts = (float *)(blob + b_ops + b_build + b_groups);
+  p->dev.d_op_groups = (OpGroup *)(blob + b_ops + b_build + b_groups + b_consts);
+  if (!p->op_groups.empty())
+    HIPCHK(hipMemcpy(p->dev.d_op_groups, p->op_groups.data(),
+                     p->op_groups.size() * sizeof(OpGroup), hipMemcpyHostToDevice));
   if (!p->dev_ops.empty())
     HIPCHK(hipMemcpy(p->dev.d_ops, p->dev_ops.data(), p->dev_ops.size() * sizeof(LoweredOp),
                      hipMemcpyHostToDevice));
@@ -890,12 +1034,11 @@ size_t tile_lds_bytes(int T, int L) {
   return ((size_t)8 << T) + ((size_t)4 << (T - L)) + 64 * sizeof(float);
 }
 
-int tile_threads(int T) {
-  if (T >= 14) return 1024;
-  if (T >= 13) return 512;
-  if (T >= 9) return 256;
-  if (T >= 7) return 64;
-  return 64;
+int tile_threads(int T) {  // one register-tile work item (16 amplitudes) per thread
+  int t = T >= 4 ? 1 << (T - 4) : 64;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return t;
 }
 
 int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
@@ -907,7 +1050,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   a.mats = mats;
   a.angles = angles;
   a.consts = p->dev.d_consts;
-  a.ops = p->dev.d_ops + st.op_begin;
+  a.ops = p->dev.d_ops;
+  a.groups = p->dev.d_op_groups + st.grp_begin;
+  a.n_groups = st.grp_end - st.grp_begin;
   a.out = out;
   a.mat_floats = p->mat_floats;
   a.n_ops = st.op_end - st.op_begin;
@@ -1016,7 +1161,7 @@ int run_expval(const float2 *states, int n, int batch, const int32_t *obs_wires,
   }
   hipLaunchKernelGGL(k_expval_partial, dim3(nb, batch), dim3(kEzThreads), 0, stream,
                      reinterpret_cast<const float4 *>(states), n, (float *)ws);
-  hipLaunchKernelGGL(k_expval_final, dim3(batch), dim3(QMLE_MAX_QUBITS), 0, stream,
+  hipLaunchKernelGGL(k_expval_final, dim3(batch), dim3(256), 0, stream,
                      (const float *)ws, nb, n_obs, ob, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1465,7 +1610,7 @@ int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d
                        (const float4 *)d_states + (size_t)p0 * chunks, n_qubits, n_pairs,
                        (float2 *)d_workspace + (size_t)p0 * nb);
   }
-  hipLaunchKernelGGL(k_overlap_final, dim3((n_pairs + 255) / 256), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_overlap_final, dim3(n_pairs), dim3(nb >= 256 ? 256 : 64), 0, stream,
                      (const float2 *)d_workspace, nb, n_pairs, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1492,7 +1637,7 @@ int qmle_overlap(const void *d_a, const void *d_b, int n_qubits, int count, void
                        (const float4 *)d_b + (size_t)p0 * chunks, n_qubits,
                        (float2 *)d_workspace + (size_t)p0 * nb);
   }
-  hipLaunchKernelGGL(k_overlap2_final, dim3((count + 255) / 256), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_overlap2_final, dim3(count), dim3(nb >= 256 ? 256 : 64), 0, stream,
                      (const float2 *)d_workspace, nb, count, (float2 *)d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1527,7 +1672,7 @@ int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint
     }
     hipLaunchKernelGGL(k_parity_partial, dim3(nb, batch), dim3(256), 0, stream,
                        (const float4 *)d_states, n_qubits, pm, (float *)d_workspace);
-    hipLaunchKernelGGL(k_parity_final, dim3(batch), dim3(8), 0, stream,
+    hipLaunchKernelGGL(k_parity_final, dim3(batch), dim3(nb >= 256 ? 256 : 64), 0, stream,
                        (const float *)d_workspace, nb, pm.count, n_obs, o0, d_out);
   }
   HIPCHK(hipGetLastError());
@@ -1551,7 +1696,7 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
   for (int p = 0; p < n_qubits; ++p)
     hipLaunchKernelGGL(k_cross_partial, dim3(nb, batch), dim3(256), 0, stream,
                        (const float4 *)d_states, n_qubits, p, (float4 *)d_workspace, nb);
-  hipLaunchKernelGGL(k_mw_final, dim3((batch + 63) / 64), dim3(64), 0, stream,
+  hipLaunchKernelGGL(k_mw_final, dim3(batch), dim3(nb >= 256 ? 256 : 64), 0, stream,
                      (const float4 *)d_workspace, n_qubits, nb, batch, d_out, d_purities);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
