@@ -51,6 +51,7 @@ PLAN_DEFAULT = 0
 PLAN_NO_FUSION = 1
 PLAN_FORCE_GLOBAL = 2
 PLAN_FORCE_TILE = 4
+PLAN_NO_REGTILE = 8
 
 
 def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0):

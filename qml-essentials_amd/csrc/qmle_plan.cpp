@@ -172,6 +172,7 @@ int compile_plan(qmle_plan *p) {
   p->algo_bytes_per_state = 0;
   p->mat_floats = 0;
   const bool fuse = !(p->flags & QMLE_PLAN_NO_FUSION);
+  const bool no_fusion_flag = !fuse;
   std::vector<std::vector<BuildOp>> group_ops;            // source gates per matrix
   std::vector<std::pair<uint32_t, uint32_t>> group_meta;  // (mat_off, dim)
   std::vector<int> group_of;                              // lowered index -> group
@@ -291,138 +292,162 @@ int compile_plan(qmle_plan *p) {
   }
 
   // ---- 2. choose regime ------------------------------------------------------
-  int T = (int)((p->flags >> 8) & 0xff);
-  int L = (int)((p->flags >> 16) & 0xff);
+  const int forced_T = (int)((p->flags >> 8) & 0xff);
+  const int forced_L = (int)((p->flags >> 16) & 0xff);
   p->whole_state_lds = (n <= kLdsMaxQubits) && !(p->flags & QMLE_PLAN_FORCE_GLOBAL) &&
-                       (T == 0 || T >= n);
-  if (p->whole_state_lds) {
-    T = n;
-  } else {
-    if (T == 0) T = kDefaultTileBits;
+                       (forced_T == 0 || forced_T >= n);
+  if (!p->whole_state_lds && forced_T != 0 && forced_T < 4 && forced_T < n)
+    return QMLE_ERR_INVALID_ARG;
+
+  // ---- 3. schedule into stages (for one tile geometry) ---------------------------
+  auto schedule = [&](int T, int L) {
+    if (p->whole_state_lds) T = n;
     if (T > kLdsMaxQubits) T = kLdsMaxQubits;
     if (T > n) T = n;
-    if (T < 4 && T < n) return QMLE_ERR_INVALID_ARG;
-  }
-  if (L == 0) L = kDefaultLowBits;
-  if (L > T) L = T;
-  if (L < 1) L = 1;
-  p->tile_T = T;
-  p->tile_L = L;
+    if (L > T) L = T;
+    if (L < 1) L = 1;
+    p->tile_T = T;
+    p->tile_L = L;
+    p->stages.clear();
+    p->dev_ops.clear();
+    p->op_groups.clear();
+    const size_t nl = p->lowered.size();
+    std::vector<char> done(nl, 0);
+    size_t n_done = 0;
+    const bool no_fusion = (p->flags & QMLE_PLAN_NO_FUSION) != 0;
+    const bool force_tile = (p->flags & QMLE_PLAN_FORCE_TILE) != 0;
+    const uint64_t all_mask = n >= 64 ? ~0ull : bit(n) - 1;
 
-  // ---- 3. schedule into stages ------------------------------------------------
-  p->stages.clear();
-  p->dev_ops.clear();
-  p->op_groups.clear();
-  const size_t nl = p->lowered.size();
-  std::vector<char> done(nl, 0);
-  size_t n_done = 0;
-  const bool no_fusion = (p->flags & QMLE_PLAN_NO_FUSION) != 0;
-  const bool force_tile = (p->flags & QMLE_PLAN_FORCE_TILE) != 0;
-  const uint64_t all_mask = n >= 64 ? ~0ull : bit(n) - 1;
+    auto popc = [](uint64_t x) { return __builtin_popcountll(x); };
 
-  auto popc = [](uint64_t x) { return __builtin_popcountll(x); };
-
-  while (n_done < nl) {
-    std::vector<int> members;
-    uint64_t Q = 0;
-    int stageL = L;
-    if (p->whole_state_lds) {
-      for (size_t i = 0; i < nl; ++i) members.push_back((int)i);
-      Q = all_mask;
-    } else {
-      // first pending op decides whether the default low-bit count fits
-      size_t first = 0;
-      while (done[first]) ++first;
-      const LoweredOp &fo = p->lowered[first];
-      if (fo.kind == LK_DIAG_ALL) {
-        Stage st;
-        st.kind = ST_DIAG_ALL;
-        st.op_begin = (int)p->dev_ops.size();
-        p->dev_ops.push_back(fo);
-        st.op_end = (int)p->dev_ops.size();
-        st.src_ops = p->lowered_src[first];
-        p->stages.push_back(st);
-        done[first] = 1;
-        ++n_done;
-        continue;
-      }
-      const uint64_t fm = op_mask(fo, n);
-      while (stageL > 1 && popc((bit(stageL) - 1) | fm) > T) --stageL;
-      Q = bit(stageL) - 1;
-      uint64_t blocked = 0;
-      for (size_t i = first; i < nl; ++i) {
-        if (done[i]) continue;
-        const LoweredOp &o = p->lowered[i];
-        const uint64_t m = op_mask(o, n);
-        if (o.kind == LK_DIAG_ALL || (m & blocked)) {
-          blocked |= m;
-        } else if (popc(Q | m) <= T) {
-          Q |= m;
-          members.push_back((int)i);
-          if (no_fusion) break;
-        } else {
-          blocked |= m;
+    while (n_done < nl) {
+      std::vector<int> members;
+      uint64_t Q = 0;
+      int stageL = L;
+      if (p->whole_state_lds) {
+        for (size_t i = 0; i < nl; ++i) members.push_back((int)i);
+        Q = all_mask;
+      } else {
+        // first pending op decides whether the default low-bit count fits
+        size_t first = 0;
+        while (done[first]) ++first;
+        const LoweredOp &fo = p->lowered[first];
+        if (fo.kind == LK_DIAG_ALL) {
+          Stage st;
+          st.kind = ST_DIAG_ALL;
+          st.op_begin = (int)p->dev_ops.size();
+          p->dev_ops.push_back(fo);
+          st.op_end = (int)p->dev_ops.size();
+          st.src_ops = p->lowered_src[first];
+          p->stages.push_back(st);
+          done[first] = 1;
+          ++n_done;
+          continue;
         }
-        if ((blocked & all_mask) == all_mask) break;
+        const uint64_t fm = op_mask(fo, n);
+        while (stageL > 1 && popc((bit(stageL) - 1) | fm) > T) --stageL;
+        Q = bit(stageL) - 1;
+        uint64_t blocked = 0;
+        for (size_t i = first; i < nl; ++i) {
+          if (done[i]) continue;
+          const LoweredOp &o = p->lowered[i];
+          const uint64_t m = op_mask(o, n);
+          if (o.kind == LK_DIAG_ALL || (m & blocked)) {
+            blocked |= m;
+          } else if (popc(Q | m) <= T) {
+            Q |= m;
+            members.push_back((int)i);
+            if (no_fusion) break;
+          } else {
+            blocked |= m;
+          }
+          if ((blocked & all_mask) == all_mask) break;
+        }
       }
-    }
 
-    Stage st;
-    st.L = stageL;
-    st.op_begin = (int)p->dev_ops.size();
-    const LoweredOp &m0 = p->lowered[members[0]];
-    const bool direct_ok = !p->whole_state_lds && !force_tile && members.size() == 1 &&
-                           m0.kind == LK_1Q && m0.nc <= 1;
-    if (direct_ok) {
-      st.kind = ST_DIRECT;
-      p->dev_ops.push_back(m0);
-    } else {
-      st.kind = ST_TILE;
-      // pad the tile with the lowest free bit positions
-      for (int b = 0; b < n && popc(Q) < T; ++b) Q |= bit(b);
-      st.T = popc(Q);
-      int nt = 0, no = 0;
-      int8_t local_of[64];
-      for (int b = 0; b < n; ++b) {
-        if (Q & bit(b)) { local_of[b] = (int8_t)nt; st.tile_bits[nt++] = (int8_t)b; }
-        else { local_of[b] = -1; st.outer_bits[no++] = (int8_t)b; }
+      Stage st;
+      st.L = stageL;
+      st.op_begin = (int)p->dev_ops.size();
+      const LoweredOp &m0 = p->lowered[members[0]];
+      const bool direct_ok = !p->whole_state_lds && !force_tile && members.size() == 1 &&
+                             m0.kind == LK_1Q && m0.nc <= 1;
+      if (direct_ok) {
+        st.kind = ST_DIRECT;
+        p->dev_ops.push_back(m0);
+      } else {
+        st.kind = ST_TILE;
+        // pad the tile with the lowest free bit positions
+        for (int b = 0; b < n && popc(Q) < T; ++b) Q |= bit(b);
+        st.T = popc(Q);
+        int nt = 0, no = 0;
+        int8_t local_of[64];
+        for (int b = 0; b < n; ++b) {
+          if (Q & bit(b)) { local_of[b] = (int8_t)nt; st.tile_bits[nt++] = (int8_t)b; }
+          else { local_of[b] = -1; st.outer_bits[no++] = (int8_t)b; }
+        }
+        // contiguous low run actually present
+        int run = 0;
+        while (run < st.T && st.tile_bits[run] == run) ++run;
+        st.L = run < 1 ? 1 : run;
+        for (int mi : members) {
+          LoweredOp o = p->lowered[mi];
+          if (o.kind != LK_DIAG_ALL) {
+            o.t0 = local_of[(int)o.t0];
+            if (o.t1 >= 0) o.t1 = local_of[(int)o.t1];
+            if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
+            if (o.c1 >= 0) o.c1 = local_of[(int)o.c1];
+          }
+          p->dev_ops.push_back(o);
+        }
       }
-      // contiguous low run actually present
-      int run = 0;
-      while (run < st.T && st.tile_bits[run] == run) ++run;
-      st.L = run < 1 ? 1 : run;
+      st.op_end = (int)p->dev_ops.size();
+      st.n_tile_ops = st.op_end - st.op_begin;
+      if (st.kind == ST_TILE) group_stage_ops(p, st);
       for (int mi : members) {
-        LoweredOp o = p->lowered[mi];
-        if (o.kind != LK_DIAG_ALL) {
-          o.t0 = local_of[(int)o.t0];
-          if (o.t1 >= 0) o.t1 = local_of[(int)o.t1];
-          if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
-          if (o.c1 >= 0) o.c1 = local_of[(int)o.c1];
+        done[mi] = 1;
+        ++n_done;
+        for (int s : p->lowered_src[mi]) {
+          st.src_ops.push_back(s);
+          st.algo_bytes_per_state += algo_bytes(p->ops[s], n);
         }
-        p->dev_ops.push_back(o);
       }
+      p->stages.push_back(st);
     }
-    st.op_end = (int)p->dev_ops.size();
-    st.n_tile_ops = st.op_end - st.op_begin;
-    if (st.kind == ST_TILE) group_stage_ops(p, st);
-    for (int mi : members) {
-      done[mi] = 1;
-      ++n_done;
-      for (int s : p->lowered_src[mi]) {
-        st.src_ops.push_back(s);
-        st.algo_bytes_per_state += algo_bytes(p->ops[s], n);
-      }
+    if (p->whole_state_lds && p->stages.empty()) {
+      // empty circuit: still need one stage to produce |0...0>
+      Stage st;
+      st.kind = ST_TILE;
+      st.T = n;
+      st.L = L;
+      for (int b = 0; b < n; ++b) st.tile_bits[b] = (int8_t)b;
+      p->stages.push_back(st);
     }
-    p->stages.push_back(st);
-  }
-  if (p->whole_state_lds && p->stages.empty()) {
-    // empty circuit: still need one stage to produce |0...0>
-    Stage st;
-    st.kind = ST_TILE;
-    st.T = n;
-    st.L = L;
-    for (int b = 0; b < n; ++b) st.tile_bits[b] = (int8_t)b;
-    p->stages.push_back(st);
+
+  };
+
+  // pass-cost model (microseconds at n = 24, scaled by 2^(n-24); measured on MI355X,
+  // profiles/): HBM round trip of a tile pass ~35, each LDS round trip ~14, direct ~33
+  auto cost = [&]() {
+    double c = 0;
+    for (const Stage &st : p->stages) {
+      if (st.kind == ST_TILE) c += 35.0 + 14.0 * (st.grp_end - st.grp_begin);
+      else c += 33.0;
+    }
+    return c;
+  };
+  if (p->whole_state_lds || forced_T != 0 || forced_L != 0 || no_fusion_flag) {
+    schedule(forced_T ? forced_T : kDefaultTileBits, forced_L ? forced_L : kDefaultLowBits);
+  } else {
+    static const int cand[][2] = {{13, 7}, {13, 5}, {12, 4}, {13, 4}, {12, 5}, {13, 6}};
+    int best = 0;
+    double best_cost = 1e300;
+    for (int k = 0; k < 6; ++k) {
+      if (cand[k][0] >= n) continue;
+      schedule(cand[k][0], cand[k][1]);
+      const double c = cost();
+      if (c < best_cost) { best_cost = c; best = k; }
+    }
+    schedule(cand[best][0], cand[best][1]);
   }
   return QMLE_OK;
 }

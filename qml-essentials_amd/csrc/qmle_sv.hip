@@ -237,6 +237,8 @@ enum TileMeas : int {
   TM_STORE = 0,   // write the tile back into the state buffer
   TM_PROBS = 1,   // write |psi|^2 to out (float)
   TM_EXPVAL = 2,  // whole-state only: <Z> on obs bits
+  TM_EXPVAL_PARTIAL = 3,  // last pass of a tiled state: per-tile signed sums for EVERY bit
+                          // -> out[b][tile][33] (k_expval_final reduces); state not stored
 };
 
 // LDS layout of a tile: amplitude e lives in slot sw(e).  XOR-ing bits 1..4 with bits
@@ -306,10 +308,20 @@ __device__ __forceinline__ void reg_dispatch(float2 (&a)[16], const Mat2 &m, int
   }
 }
 
+// Op descriptor + its per-sample 2x2 matrix, staged in LDS by the tile prologue so the
+// gate loop never waits on dependent scalar loads from global memory.
+struct OpSlot {
+  LoweredOp op;
+  float m[8];
+};
+static_assert(sizeof(OpSlot) == 48, "OpSlot layout");
+
 // One GK_REG4 group: gather 16 amplitudes per work item, apply every op, scatter.
-__device__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
-                                const LoweredOp *__restrict__ ops,
-                                const float *__restrict__ mrow) {
+template <bool SLOTS>
+__device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
+                                                const LoweredOp *__restrict__ ops,
+                                                const float *__restrict__ mrow,
+                                                const OpSlot *__restrict__ slots, int op_base) {
   const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
   uint32_t off[16];
 #pragma unroll
@@ -323,8 +335,16 @@ __device__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = s[sw(base | off[c])];
     for (int k = 0; k < g.n_ops; ++k) {
-      const LoweredOp op = ops[g.op_begin + k];
-      const Mat2 m = load_mat2(mrow + op.mat_off);
+      LoweredOp op;
+      Mat2 m;
+      if (SLOTS) {
+        const OpSlot *sl = slots + (g.op_begin - op_base + k);
+        op = sl->op;
+        m = load_mat2(sl->m);
+      } else {
+        op = ops[g.op_begin + k];
+        m = load_mat2(mrow + op.mat_off);
+      }
       const int cb = op.nc ? op.c0 : -1;
       if (op.flags & LF_PERMX) reg_dispatch<2>(a, m, cb, op.t0);
       else if (op.flags & LF_DIAG) reg_dispatch<1>(a, m, cb, op.t0);
@@ -343,6 +363,8 @@ struct TileArgs {
   const LoweredOp *ops;     // the plan's op array (groups index into it)
   const OpGroup *groups;    // this stage's groups
   int n_groups;
+  int op_begin;             // first op of this stage in `ops`
+  int slots_in_lds;         // 1: prologue stages op descriptors + matrices in LDS
   void *out;                // TM_PROBS: float [B][2^n]; TM_EXPVAL: float [B][n_obs]
   uint32_t mat_floats;
   int n_ops, n, T, L, n_slots;
@@ -452,7 +474,9 @@ __global__ void k_tile(const TileArgs a) {
   float2 *s = reinterpret_cast<float2 *>(smem4);
   const int T = a.T, L = a.L;
   uint32_t *lut = reinterpret_cast<uint32_t *>(s + (1u << T));
-  float *red = reinterpret_cast<float *>(lut + (1u << (T - L)));
+  const uint32_t lut_n = (1u << (T - L)) < 4u ? 4u : (1u << (T - L));
+  float *red = reinterpret_cast<float *>(lut + lut_n);
+  OpSlot *slots = reinterpret_cast<OpSlot *>(red + 288);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.y;
   const uint32_t tile = blockIdx.x;
@@ -465,6 +489,19 @@ __global__ void k_tile(const TileArgs a) {
     for (int i = 0; i < T - L; ++i) v |= ((h >> i) & 1u) << a.tile_bits[L + i];
     lut[h] = v;
   }
+  if (a.slots_in_lds) {
+    const float *mrow0 = a.mats + (size_t)b * a.mat_floats;
+    for (int k = tid; k < a.n_ops; k += nt) {
+      const LoweredOp o = a.ops[a.op_begin + k];
+      slots[k].op = o;
+      if (o.kind == LK_1Q) {
+        const float4 lo4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off);
+        const float4 hi4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off + 4);
+        *reinterpret_cast<float4 *>(slots[k].m) = lo4;
+        *reinterpret_cast<float4 *>(slots[k].m + 4) = hi4;
+      }
+    }
+  }
   __syncthreads();
 
   const uint32_t half = 1u << (T - 1);
@@ -476,10 +513,25 @@ __global__ void k_tile(const TileArgs a) {
     __syncthreads();
     if (tid == 0 && base == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
   } else {
-    for (uint32_t jc = tid; jc < half; jc += nt) {
-      const uint32_t j = jc * 2u;
-      const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      reinterpret_cast<float4 *>(s)[sw(j) >> 1] = *reinterpret_cast<const float4 *>(st + g);
+    // stage the tile through registers, 8 independent 16-byte loads in flight per lane
+    if ((half % (8u * nt)) == 0) {
+      for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = (j0 + u * nt) * 2u;
+          v[u] = *reinterpret_cast<const float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          reinterpret_cast<float4 *>(s)[sw((j0 + u * nt) * 2u) >> 1] = v[u];
+      }
+    } else {
+      for (uint32_t jc = tid; jc < half; jc += nt) {
+        const uint32_t j = jc * 2u;
+        reinterpret_cast<float4 *>(s)[sw(j) >> 1] =
+            *reinterpret_cast<const float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+      }
     }
   }
   __syncthreads();
@@ -488,16 +540,33 @@ __global__ void k_tile(const TileArgs a) {
   const float *ang = a.angles + (size_t)b * a.n_slots;
   for (int gi = 0; gi < a.n_groups; ++gi) {
     const OpGroup g = a.groups[gi];
-    if (g.kind == GK_REG4) lds_apply_group(s, T, g, a.ops, mrow);
-    else lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
+    if (g.kind == GK_REG4) {
+      if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin);
+      else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin);
+    } else {
+      lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
+    }
     __syncthreads();
   }
 
   if (a.meas == TM_STORE) {
-    for (uint32_t jc = tid; jc < half; jc += nt) {
-      const uint32_t j = jc * 2u;
-      const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      *reinterpret_cast<float4 *>(st + g) = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
+    if ((half % (8u * nt)) == 0) {
+      for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sw((j0 + u * nt) * 2u) >> 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = (j0 + u * nt) * 2u;
+          *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = v[u];
+        }
+      }
+    } else {
+      for (uint32_t jc = tid; jc < half; jc += nt) {
+        const uint32_t j = jc * 2u;
+        *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) =
+            reinterpret_cast<float4 *>(s)[sw(j) >> 1];
+      }
     }
   } else if (a.meas == TM_PROBS) {
     float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
@@ -506,6 +575,68 @@ __global__ void k_tile(const TileArgs a) {
       const uint64_t g = base | lut[j >> L] | (j & lowmask);
       const float4 v = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
       *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+    }
+  } else if (a.meas == TM_EXPVAL_PARTIAL) {
+    // element e = tid + it * nt: bits [0, tb) come from tid, the top bits from `it`
+    float *po = reinterpret_cast<float *>(a.out) +
+                ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
+    const uint32_t cnt = 1u << T;
+    if (cnt == 16u * nt) {
+      float tot = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const float pr = norm2(s[sw(tid + it * nt)]);
+        tot += pr;
+        h0 += (it & 1) ? -pr : pr;
+        h1 += (it & 2) ? -pr : pr;
+        h2 += (it & 4) ? -pr : pr;
+        h3 += (it & 8) ? -pr : pr;
+      }
+      // 15 values per thread: 10 thread-bit sums (unused ones are harmless), 4 iteration-bit
+      // sums, the total.  One multi-value block reduction = 2 barriers, then ONE coalesced
+      // store of the 33-float row (no global store may sit in front of a barrier).
+      float v[15];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = ((tid >> j) & 1) ? -tot : tot;
+      v[10] = h0; v[11] = h1; v[12] = h2; v[13] = h3; v[14] = tot;
+      const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const float r = wave_sum(v[k]);
+        if (lane == 0) red[w * 15 + k] = r;
+      }
+      __syncthreads();
+      float *row = red + 240;  // 33 floats
+      if (tid < 15) {
+        float r = 0.f;
+        for (int i = 0; i < nw; ++i) r += red[i * 15 + tid];
+        const int tb = T - 4;
+        if (tid < 10) { if (tid < tb) row[a.tile_bits[tid]] = r; }
+        else if (tid < 14) row[a.tile_bits[tb + tid - 10]] = r;
+        else {
+          row[QMLE_MAX_QUBITS] = r;
+          for (int i = 0; i < a.n - T; ++i) row[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
+        }
+      }
+      __syncthreads();
+      if (tid <= QMLE_MAX_QUBITS) po[tid] = (tid < a.n || tid == QMLE_MAX_QUBITS) ? row[tid] : 0.f;
+    } else {  // small tiles (forced geometries in tests): one reduction per local bit
+      float acc_t = 0.f;
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.f;
+        for (uint32_t e = tid; e < cnt; e += nt) {
+          const float pr = norm2(s[sw(e)]);
+          acc += ((e >> j) & 1u) ? -pr : pr;
+          if (j == 0) acc_t += pr;
+        }
+        const float r = block_sum(acc, red);
+        if (tid == 0) po[a.tile_bits[j]] = r;
+      }
+      const float r = block_sum(acc_t, red);
+      if (tid == 0) {
+        po[QMLE_MAX_QUBITS] = r;
+        for (int i = 0; i < a.n - T; ++i) po[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
+      }
     }
   } else {  // TM_EXPVAL, T == n
     float *eo = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_obs;
@@ -717,20 +848,18 @@ struct ObsBits {
   int8_t bits[QMLE_MAX_QUBITS];
 };
 
+// one block per (state, observable): fp64 sum of that bit's column over all partial rows
 __global__ void __launch_bounds__(256)
 k_expval_final(const float *__restrict__ partial, int n_blocks, int n_obs, ObsBits obs,
                float *__restrict__ out) {
   __shared__ double red[16];
-  const int b = blockIdx.x;
-  const float *pp = partial + (size_t)b * n_blocks * (QMLE_MAX_QUBITS + 1);
-  for (int k = 0; k < n_obs; ++k) {
-    const int bitp = obs.bits[k];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x)
-      acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1) + bitp];
-    const double tot = block_sum_d(acc, red);
-    if (threadIdx.x == 0) out[(size_t)b * n_obs + k] = (float)tot;
-  }
+  const int b = blockIdx.x, k = blockIdx.y;
+  const float *pp = partial + (size_t)b * n_blocks * (QMLE_MAX_QUBITS + 1) + obs.bits[k];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x)
+    acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1)];
+  const double tot = block_sum_d(acc, red);
+  if (threadIdx.x == 0) out[(size_t)b * n_obs + k] = (float)tot;
 }
 
 // ---------------------------------------------------------------------------
@@ -1030,8 +1159,9 @@ int ensure_device_plan(qmle_plan *p) {
   return QMLE_OK;
 }
 
-size_t tile_lds_bytes(int T, int L) {
-  return ((size_t)8 << T) + ((size_t)4 << (T - L)) + 64 * sizeof(float);
+size_t tile_lds_bytes(int T, int L, int n_slots) {
+  const size_t lut_n = ((size_t)1 << (T - L)) < 4 ? 4 : ((size_t)1 << (T - L));
+  return ((size_t)8 << T) + 4 * lut_n + 288 * sizeof(float) + (size_t)n_slots * sizeof(OpSlot);
 }
 
 int tile_threads(int T) {  // one register-tile work item (16 amplitudes) per thread
@@ -1066,7 +1196,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   std::memcpy(a.tile_bits, st.tile_bits, sizeof(a.tile_bits));
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
   if (obs_bits) std::memcpy(a.obs_bits, obs_bits, (size_t)n_obs);
-  const size_t lds = tile_lds_bytes(st.T, st.L);
+  a.op_begin = st.op_begin;
+  a.slots_in_lds = tile_lds_bytes(st.T, st.L, a.n_ops) <= 160 * 1024 ? 1 : 0;
+  const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1161,7 +1293,7 @@ int run_expval(const float2 *states, int n, int batch, const int32_t *obs_wires,
   }
   hipLaunchKernelGGL(k_expval_partial, dim3(nb, batch), dim3(kEzThreads), 0, stream,
                      reinterpret_cast<const float4 *>(states), n, (float *)ws);
-  hipLaunchKernelGGL(k_expval_final, dim3(batch), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_expval_final, dim3(batch, n_obs), dim3(256), 0, stream,
                      (const float *)ws, nb, n_obs, ob, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1269,10 +1401,19 @@ static int default_states_in_flight(const qmle_plan *p, int batch) {
   return (int)s;
 }
 
-static size_t per_state_ws_bytes(int n, int meas_type) {
-  size_t b = align_up((size_t)8 << n, 256);
+static size_t expval_partial_rows(const qmle_plan *p) {
+  size_t rows = (size_t)expval_blocks(p->n);
+  if (!p->stages.empty() && p->stages.back().kind == ST_TILE && !p->whole_state_lds) {
+    const size_t tiles = (size_t)1 << (p->n - p->stages.back().T);
+    if (tiles > rows) rows = tiles;
+  }
+  return rows;
+}
+
+static size_t per_state_ws_bytes(const qmle_plan *p, int meas_type) {
+  size_t b = align_up((size_t)8 << p->n, 256);
   if (meas_type == QMLE_MEAS_EXPVAL_Z)
-    b += align_up((size_t)expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+    b += align_up(expval_partial_rows(p) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
   return b;
 }
 
@@ -1286,7 +1427,7 @@ size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int
   if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
     int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
     if (s > batch) s = batch;
-    total += (size_t)s * per_state_ws_bytes(plan->n, meas_type);
+    total += (size_t)s * per_state_ws_bytes(plan, meas_type);
   }
   return total;
 }
@@ -1372,7 +1513,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
     d_states = (float2 *)d_out;
     in_flight = default_states_in_flight(plan, batch);  // sample-major: stay cache-resident
   } else {
-    in_flight = (int)(workspace_bytes / per_state_ws_bytes(n, meas_type));
+    in_flight = (int)(workspace_bytes / per_state_ws_bytes(plan, meas_type));
     if (in_flight < 1) return QMLE_ERR_WORKSPACE;
     if (in_flight > batch) in_flight = batch;
     const int dflt = default_states_in_flight(plan, batch);
@@ -1383,7 +1524,10 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
   if (in_flight > 65535) in_flight = 65535;
   void *d_partial = ws;
   const size_t partial_bytes =
-      (size_t)in_flight * expval_blocks(n) * (QMLE_MAX_QUBITS + 1) * sizeof(float);
+      (size_t)in_flight * expval_partial_rows(plan) * (QMLE_MAX_QUBITS + 1) * sizeof(float);
+  // <Z> straight out of the last tile pass (no store of the final state, no extra read)
+  const bool fuse_expval = meas_type == QMLE_MEAS_EXPVAL_Z && !plan->stages.empty() &&
+                           plan->stages.back().kind == ST_TILE;
 
   for (int b0 = 0; b0 < batch; b0 += in_flight) {
     const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
@@ -1395,8 +1539,10 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
       const Stage &st = plan->stages[si];
       ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE) {
-        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, TM_STORE, nullptr, nullptr,
-                         0, stream);
+        const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
+        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised,
+                         last_fused ? TM_EXPVAL_PARTIAL : TM_STORE, last_fused ? d_partial : nullptr,
+                         nullptr, 0, stream);
         initialised = true;
       } else {
         if (!initialised) {
@@ -1425,6 +1571,12 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
       hipLaunchKernelGGL(k_probs, dim3(grid_for(tc, 256)), dim3(256), 0, stream,
                          reinterpret_cast<const float4 *>(stc),
                          reinterpret_cast<float2 *>((float *)d_out + (size_t)b0 * D), tc);
+    } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
+      ObsBits ob;
+      for (int k = 0; k < n_obs; ++k) ob.bits[k] = obs_bits[k];
+      const int tiles = 1 << (n - plan->stages.back().T);
+      hipLaunchKernelGGL(k_expval_final, dim3(bc, n_obs), dim3(256), 0, stream, (const float *)d_partial,
+                         tiles, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {
       rc = run_expval(stc, n, bc, obs_wires, n_obs, (float *)d_out + (size_t)b0 * n_obs, d_partial,
                       partial_bytes, stream);
