@@ -369,8 +369,12 @@ int compile_plan(qmle_plan *p) {
       st.L = stageL;
       st.op_begin = (int)p->dev_ops.size();
       const LoweredOp &m0 = p->lowered[members[0]];
+      // a control on bits 1..3 selects 16/32/64-byte runs inside every 128-byte line: the
+      // streaming kernel would move whole lines for half the work (measured 2-4x slower
+      // than a tile pass at n = 28), so those go through the LDS tile instead
       const bool direct_ok = !p->whole_state_lds && !force_tile && members.size() == 1 &&
-                             m0.kind == LK_1Q && m0.nc <= 1;
+                             m0.kind == LK_1Q &&
+                             (m0.nc == 0 || (m0.nc == 1 && (m0.c0 == 0 || m0.c0 >= 4)));
       if (direct_ok) {
         st.kind = ST_DIRECT;
         p->dev_ops.push_back(m0);

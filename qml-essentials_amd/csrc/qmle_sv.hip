@@ -661,7 +661,28 @@ __global__ void k_tile(const TileArgs a) {
 //   MODE 2: control >= 1, target >= 1        MODE 3: control >= 1, target bit 0
 //   MODE 4: control bit 0, target >= 1
 // ---------------------------------------------------------------------------
-template <int MODE, bool DIAG>
+typedef float vf4 __attribute__((ext_vector_type(4)));
+// NT: non-temporal accesses for states far larger than the 256 MiB Infinity Cache
+// (measured on MI355X, tools/k1_tune.hip: +5..11 % at n = 28, harmful when cache-resident)
+template <bool NT> __device__ __forceinline__ float4 ld4(const float4 *p) {
+  if (NT) {
+    const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+template <bool NT> __device__ __forceinline__ void st4(float4 *p, float4 v) {
+  if (NT) {
+    const vf4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<vf4 *>(p));
+  } else {
+    *p = v;
+  }
+}
+
+// One work item per thread and an exact grid: a persistent grid-stride loop measured
+// 15-20 % slower for this in-place two-stream pattern (tools/k1_tune.hip).
+template <int MODE, bool DIAG, bool NT>
 __global__ void __launch_bounds__(256)
 k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
             const float *__restrict__ mats, uint32_t mat_floats, uint32_t mat_off,
@@ -669,79 +690,78 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
   const int b = blockIdx.y;
   const uint64_t chunks = (uint64_t)1 << (n - 1);
   float4 *st = states + (size_t)b * chunks;
+  const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (k >= items) return;
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < items; k += stride) {
-    if constexpr (MODE == 0) {
-      if constexpr (DIAG) {  // items = all chunks
-        float4 v = st[k];
-        const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
-        const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
-        st[k] = make_float4(x.x, x.y, y.x, y.y);
-      } else {
-        const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
-        float4 v0 = st[c0], v1 = st[c1];
-        float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
-        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
-        apply2(m, a0, a1);
-        apply2(m, b0, b1);
-        st[c0] = make_float4(a0.x, a0.y, b0.x, b0.y);
-        st[c1] = make_float4(a1.x, a1.y, b1.x, b1.y);
-      }
-    } else if constexpr (MODE == 1) {
-      float4 v = st[k];
-      float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
-      if constexpr (DIAG) {
-        a0 = cmul(m.m00, a0);
-        a1 = cmul(m.m11, a1);
-      } else {
-        apply2(m, a0, a1);
-      }
-      st[k] = make_float4(a0.x, a0.y, a1.x, a1.y);
-    } else if constexpr (MODE == 2) {
-      if constexpr (DIAG) {  // items = chunks with control bit set
-        const uint64_t c = ins0_64(k, pc - 1) | (1ull << (pc - 1));
-        float4 v = st[c];
-        const float2 f = ((c >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
-        const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
-        st[c] = make_float4(x.x, x.y, y.x, y.y);
-      } else {
-        const int lo = pt < pc ? pt - 1 : pc - 1, hi = pt < pc ? pc - 1 : pt - 1;
-        const uint64_t c0 = ins0_64(ins0_64(k, lo), hi) | (1ull << (pc - 1));
-        const uint64_t c1 = c0 | (1ull << (pt - 1));
-        float4 v0 = st[c0], v1 = st[c1];
-        float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
-        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
-        apply2(m, a0, a1);
-        apply2(m, b0, b1);
-        st[c0] = make_float4(a0.x, a0.y, b0.x, b0.y);
-        st[c1] = make_float4(a1.x, a1.y, b1.x, b1.y);
-      }
-    } else if constexpr (MODE == 3) {
+  if constexpr (MODE == 0) {
+    if constexpr (DIAG) {  // items = all chunks
+      float4 v = ld4<NT>(st + k);
+      const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+      const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
+      st4<NT>(st + k, make_float4(x.x, x.y, y.x, y.y));
+    } else {
+      const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
+      float4 v0 = ld4<NT>(st + c0), v1 = ld4<NT>(st + c1);
+      float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
+      float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+      apply2(m, a0, a1);
+      apply2(m, b0, b1);
+      st4<NT>(st + c0, make_float4(a0.x, a0.y, b0.x, b0.y));
+      st4<NT>(st + c1, make_float4(a1.x, a1.y, b1.x, b1.y));
+    }
+  } else if constexpr (MODE == 1) {
+    float4 v = ld4<NT>(st + k);
+    float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
+    if constexpr (DIAG) {
+      a0 = cmul(m.m00, a0);
+      a1 = cmul(m.m11, a1);
+    } else {
+      apply2(m, a0, a1);
+    }
+    st4<NT>(st + k, make_float4(a0.x, a0.y, a1.x, a1.y));
+  } else if constexpr (MODE == 2) {
+    if constexpr (DIAG) {  // items = chunks with control bit set
       const uint64_t c = ins0_64(k, pc - 1) | (1ull << (pc - 1));
-      float4 v = st[c];
-      float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
-      if constexpr (DIAG) {
-        a0 = cmul(m.m00, a0);
-        a1 = cmul(m.m11, a1);
-      } else {
-        apply2(m, a0, a1);
-      }
-      st[c] = make_float4(a0.x, a0.y, a1.x, a1.y);
-    } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
-      if constexpr (DIAG) {  // items = all chunks
-        float4 v = st[k];
-        const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
-        const float2 y = cmul(f, make_float2(v.z, v.w));
-        st[k] = make_float4(v.x, v.y, y.x, y.y);
-      } else {
-        const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
-        float4 v0 = st[c0], v1 = st[c1];
-        float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
-        apply2(m, b0, b1);
-        st[c0] = make_float4(v0.x, v0.y, b0.x, b0.y);
-        st[c1] = make_float4(v1.x, v1.y, b1.x, b1.y);
-      }
+      float4 v = ld4<NT>(st + c);
+      const float2 f = ((c >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+      const float2 x = cmul(f, make_float2(v.x, v.y)), y = cmul(f, make_float2(v.z, v.w));
+      st4<NT>(st + c, make_float4(x.x, x.y, y.x, y.y));
+    } else {
+      const int lo = pt < pc ? pt - 1 : pc - 1, hi = pt < pc ? pc - 1 : pt - 1;
+      const uint64_t c0 = ins0_64(ins0_64(k, lo), hi) | (1ull << (pc - 1));
+      const uint64_t c1 = c0 | (1ull << (pt - 1));
+      float4 v0 = ld4<NT>(st + c0), v1 = ld4<NT>(st + c1);
+      float2 a0 = make_float2(v0.x, v0.y), a1 = make_float2(v1.x, v1.y);
+      float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+      apply2(m, a0, a1);
+      apply2(m, b0, b1);
+      st4<NT>(st + c0, make_float4(a0.x, a0.y, b0.x, b0.y));
+      st4<NT>(st + c1, make_float4(a1.x, a1.y, b1.x, b1.y));
+    }
+  } else if constexpr (MODE == 3) {
+    const uint64_t c = ins0_64(k, pc - 1) | (1ull << (pc - 1));
+    float4 v = ld4<NT>(st + c);
+    float2 a0 = make_float2(v.x, v.y), a1 = make_float2(v.z, v.w);
+    if constexpr (DIAG) {
+      a0 = cmul(m.m00, a0);
+      a1 = cmul(m.m11, a1);
+    } else {
+      apply2(m, a0, a1);
+    }
+    st4<NT>(st + c, make_float4(a0.x, a0.y, a1.x, a1.y));
+  } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
+    if constexpr (DIAG) {  // items = all chunks
+      float4 v = ld4<NT>(st + k);
+      const float2 f = ((k >> (pt - 1)) & 1ull) ? m.m11 : m.m00;
+      const float2 y = cmul(f, make_float2(v.z, v.w));
+      st4<NT>(st + k, make_float4(v.x, v.y, y.x, y.y));
+    } else {
+      const uint64_t c0 = ins0_64(k, pt - 1), c1 = c0 | (1ull << (pt - 1));
+      float4 v0 = ld4<NT>(st + c0), v1 = ld4<NT>(st + c1);
+      float2 b0 = make_float2(v0.z, v0.w), b1 = make_float2(v1.z, v1.w);
+      apply2(m, b0, b1);
+      st4<NT>(st + c0, make_float4(v0.x, v0.y, b0.x, b0.y));
+      st4<NT>(st + c1, make_float4(v1.x, v1.y, b1.x, b1.y));
     }
   }
 }
@@ -1117,7 +1137,8 @@ k_parity_final(const float *__restrict__ partial, int n_blocks, int count, int n
 // ---------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-inline unsigned grid_for(uint64_t items, unsigned block, unsigned cap = 2048u * 4u) {
+// exact grids by default: grid-stride persistence measured slower for pure streaming
+inline unsigned grid_for(uint64_t items, unsigned block, unsigned cap = 1u << 30) {
   uint64_t g = (items + block - 1) / block;
   if (g < 1) g = 1;
   if (g > cap) g = cap;
@@ -1213,15 +1234,15 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
 }
 
 template <int MODE>
-void launch_direct_mode(bool diag, dim3 grid, hipStream_t stream, float4 *st, int n, int pt,
-                        int pc, const float *mats, uint32_t mat_floats, uint32_t mat_off,
-                        uint64_t items) {
-  if (diag)
-    hipLaunchKernelGGL((k_direct_1q<MODE, true>), grid, dim3(256), 0, stream, st, n, pt, pc, mats,
-                       mat_floats, mat_off, items);
-  else
-    hipLaunchKernelGGL((k_direct_1q<MODE, false>), grid, dim3(256), 0, stream, st, n, pt, pc,
-                       mats, mat_floats, mat_off, items);
+void launch_direct_mode(bool diag, bool nt, dim3 grid, hipStream_t stream, float4 *st, int n,
+                        int pt, int pc, const float *mats, uint32_t mat_floats,
+                        uint32_t mat_off, uint64_t items) {
+#define QMLE_LAUNCH_DIRECT(D, N)                                                              \
+  hipLaunchKernelGGL((k_direct_1q<MODE, D, N>), grid, dim3(256), 0, stream, st, n, pt, pc, mats, \
+                     mat_floats, mat_off, items)
+  if (diag) { if (nt) QMLE_LAUNCH_DIRECT(true, true); else QMLE_LAUNCH_DIRECT(true, false); }
+  else { if (nt) QMLE_LAUNCH_DIRECT(false, true); else QMLE_LAUNCH_DIRECT(false, false); }
+#undef QMLE_LAUNCH_DIRECT
 }
 
 int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const float *mats,
@@ -1240,15 +1261,17 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     else if (pt == 0) { mode = 3; items = chunks >> 1; }
     else { mode = 4; items = diag ? chunks : chunks >> 1; }
   }
-  if (items == 0) items = 1;  // n too small for this mode cannot happen (validated)
-  dim3 grid(grid_for(items, 256), (unsigned)batch);
+  if (items == 0) items = 1;
+  // streaming (non-temporal) accesses once the working set dwarfs the Infinity Cache
+  const bool nt = ((size_t)batch << n) * sizeof(float2) >= ((size_t)1 << 30);
+  dim3 grid((unsigned)((items + 255) / 256), (unsigned)batch);
   float4 *st = reinterpret_cast<float4 *>(states);
   switch (mode) {
-    case 0: launch_direct_mode<0>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 1: launch_direct_mode<1>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 2: launch_direct_mode<2>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 3: launch_direct_mode<3>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    default: launch_direct_mode<4>(diag, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 0: launch_direct_mode<0>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 1: launch_direct_mode<1>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 2: launch_direct_mode<2>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 3: launch_direct_mode<3>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
   }
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1583,7 +1606,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
       if (rc != QMLE_OK) return rc;
     } else if (meas_type == QMLE_MEAS_DENSITY) {
       if (n > 15) return QMLE_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256), bc), dim3(256), 0, stream, stc,
+      hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256, 1u << 20), bc), dim3(256), 0, stream, stc,
                          (float2 *)d_out + (size_t)b0 * D * D, n);
     }
     HIPCHK(hipGetLastError());
@@ -1700,7 +1723,7 @@ int qmle_density(const void *d_states, int n_qubits, int batch, void *d_out, qml
   if (!d_states || !d_out || n_qubits < 1 || batch < 1 || batch > 65535) return QMLE_ERR_INVALID_ARG;
   if (n_qubits > 15) return QMLE_ERR_UNSUPPORTED;
   const uint64_t D = (uint64_t)1 << n_qubits;
-  hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256), batch), dim3(256), 0,
+  hipLaunchKernelGGL(k_density, dim3(grid_for(D * D, 256, 1u << 20), batch), dim3(256), 0,
                      (hipStream_t)stream, (const float2 *)d_states, (float2 *)d_out, n_qubits);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
@@ -1727,7 +1750,7 @@ int qmle_marginal_probs(const void *d_states, int n_qubits, int batch, const int
     if (mask & (1ull << w)) kb.bits[k++] = (int8_t)(n_qubits - 1 - w);
   HIPCHK(hipMemsetAsync(d_out, 0, ((size_t)batch << n_keep) * sizeof(float), stream));
   const uint64_t D = (uint64_t)1 << n_qubits;
-  hipLaunchKernelGGL(k_marginal, dim3(grid_for(D, 256), batch), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_marginal, dim3(grid_for(D, 256, 4096), batch), dim3(256), 0, stream,
                      (const float2 *)d_states, d_out, n_qubits, kb);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
