@@ -196,6 +196,8 @@ def main():
         moved = 16.0 * D if st["kind"] != "direct" else st["algo_bytes_per_state"]
         if i == 0 and st["kind"] == "tile":
             moved = 8.0 * D  # first pass starts from |0..0> in LDS: write only
+        if i == len(desc["stages"]) - 1 and st["kind"] == "tile" and i > 0:
+            moved = 8.0 * D  # last pass feeds <Z> straight from LDS: read only
         f["moved"] += moved * per_launch_states * stage_cnt[i]
     dom_name = max(fam, key=lambda k: fam[k]["ms"])
     dom = fam[dom_name]
