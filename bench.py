@@ -168,7 +168,8 @@ def main():
     distributed.barrier()
     elapsed = time.perf_counter() - t0
     if size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (B * size, n) and np.all(np.isfinite(out))

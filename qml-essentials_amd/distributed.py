@@ -77,8 +77,9 @@ def init_from_env(backend: str = None) -> Tuple[int, int]:
     if use_gpu:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist = _dist()
-    dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"),
-                            rank=int(os.environ["RANK"]), world_size=size)
+    # QMLE_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box)
+    backend = backend or os.environ.get("QMLE_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=size)
     return world()
 
 
@@ -109,6 +110,8 @@ def all_gather_rows(local, n_total: int):
     dist = _dist()
     if dist.get_backend() == "nccl" and not t.is_cuda:
         t = t.cuda()
+    elif dist.get_backend() == "gloo" and t.is_cuda:
+        t = t.cpu()
     per = -(-n_total // size)
     pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
@@ -122,6 +125,8 @@ def all_gather_rows(local, n_total: int):
     full = torch.cat(pieces, dim=0)
     if is_np:
         return full.cpu().numpy()
+    if local.is_cuda and not full.is_cuda:
+        return full.to(local.device)
     return full if local.is_cuda or not full.is_cuda else full.cpu()
 
 
