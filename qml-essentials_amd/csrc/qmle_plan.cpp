@@ -474,6 +474,13 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"algo_bytes_per_state\":" << st.algo_bytes_per_state
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
+    os << "],\"groups\":[";
+    for (int g = st.grp_begin; g < st.grp_end; ++g) {
+      const OpGroup &og = p->op_groups[g];
+      os << (g > st.grp_begin ? "," : "") << "{\"kind\":" << (int)og.kind << ",\"n_ops\":"
+         << (int)og.n_ops << ",\"bits\":[" << (int)og.bits[0] << "," << (int)og.bits[1] << ","
+         << (int)og.bits[2] << "," << (int)og.bits[3] << "]}";
+    }
     os << "],\"src_ops\":[";
     for (size_t i = 0; i < st.src_ops.size(); ++i) os << (i ? "," : "") << st.src_ops[i];
     os << "]}";

@@ -324,17 +324,19 @@ __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, c
                                                 const float *__restrict__ mrow,
                                                 const OpSlot *__restrict__ slots, int op_base) {
   const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+  // sw() is linear over XOR and base & off == 0, so slot(base | off[c]) = sw(base) ^ sw(off[c]):
+  // 16 wave-uniform constants + ONE v_xor per gathered amplitude
   uint32_t off[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c)
-    off[c] = ((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
-             ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u);
+    off[c] = sw(((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
+                ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
   const uint32_t cnt = 1u << (T - 4);
   for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const uint32_t base = ins0(ins0(ins0(ins0(i, b0), b1), b2), b3);
+    const uint32_t base = sw(ins0(ins0(ins0(ins0(i, b0), b1), b2), b3));
     float2 a[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = s[sw(base | off[c])];
+    for (int c = 0; c < 16; ++c) a[c] = s[base ^ off[c]];
     for (int k = 0; k < g.n_ops; ++k) {
       LoweredOp op;
       Mat2 m;
@@ -352,7 +354,7 @@ __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, c
       else reg_dispatch<0>(a, m, cb, op.t0);
     }
 #pragma unroll
-    for (int c = 0; c < 16; ++c) s[sw(base | off[c])] = a[c];
+    for (int c = 0; c < 16; ++c) s[base ^ off[c]] = a[c];
   }
 }
 

@@ -505,17 +505,39 @@ class Model:
         if self.shots is not None and meas_type in ("probs", "expval"):
             raise NotImplementedError("shot sampling is a later row (SURVEY.md 8-f rank 4)")
 
+        # probs on a subset of wires: marginalise on the GPU (jaqsi.py:106-146) instead of
+        # shipping B x 2^n probabilities to the host
+        native_marginal = (meas_type == "probs" and not self.all_qubit_measurement
+                           and not as_tensor and self.n_qubits > 10)
+        if native_marginal:
+            meas_type, as_tensor_call = "state", True
+        else:
+            as_tensor_call = as_tensor
+
         args = (params, inputs, None, None, enc_params)
         if B > 1:
             in_axes = (0 if self.batch_shape[1] > 1 else None,
                        0 if self.batch_shape[0] > 1 else None, None, None, None)
             result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
-                                         in_axes=in_axes, as_tensor=as_tensor)
+                                         in_axes=in_axes, as_tensor=as_tensor_call)
         else:
             result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
-                                         as_tensor=as_tensor)
+                                         as_tensor=as_tensor_call)
         if as_tensor:
             return result  # raw (B, ...) device tensor for the analysis loops
+        if native_marginal:
+            from . import _native
+
+            states = result.reshape(-1, 2**self.n_qubits)
+            groups = (self.output_qubit if isinstance(self.output_qubit[0], (list, tuple))
+                      else [self.output_qubit])
+            parts = [_native.marginal_probs(states, list(g)).cpu().numpy() for g in groups]
+            result = np.stack(parts) if len(parts) > 1 else parts[0]
+            result = np.asarray(result)
+            result = result.reshape((*self.eff_batch_shape, *self._result_shape)).squeeze()
+            if force_mean and len(result.shape) > 0 and self._result_shape[0] > 1:
+                result = result.mean(axis=-1)
+            return result
 
         if self.execution_type == "density" and not self.all_qubit_measurement:
             result = js.partial_trace(result, self.n_qubits, self.output_qubit)
