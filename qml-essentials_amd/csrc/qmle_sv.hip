@@ -1135,6 +1135,151 @@ k_parity_final(const float *__restrict__ partial, int n_blocks, int count, int n
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Meyer-Wallach via LDS-staged tiles: one read of the state covers the cross terms
+// c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) and the signed populations of EVERY
+// tile-local bit (12 per pass) -- entanglement.py:86-101 with Tr rho_j^2 = a^2+d^2+2|c|^2.
+// Pass p stages bits {0..L-1} + the p-th chunk of T-L high bits; ceil((n-L)/(T-L)) passes
+// instead of n.  Row layout per tile: [3 * local bit + {cr, ci, z}], [36] = total.
+// ---------------------------------------------------------------------------
+constexpr int kMwT = 12, kMwL = 4, kMwRow = 40, kMwThreads = 256;
+
+struct MwArgs {
+  const float2 *states;
+  float *partial;  // [batch][tiles][kMwRow] for this pass
+  int n;
+  int8_t tile_bits[kMwT];
+  int8_t outer_bits[QMLE_MAX_QUBITS];
+};
+
+__global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t n_tiles) {
+  extern __shared__ float4 smem4[];
+  float2 *s = reinterpret_cast<float2 *>(smem4);
+  uint32_t *lut = reinterpret_cast<uint32_t *>(s + (1u << kMwT));
+  float *red = reinterpret_cast<float *>(lut + (1u << (kMwT - kMwL)));
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (uint32_t h = tid; h < (1u << (kMwT - kMwL)); h += kMwThreads) {
+    uint32_t v = 0;
+    for (int i = 0; i < kMwT - kMwL; ++i) v |= ((h >> i) & 1u) << a.tile_bits[kMwL + i];
+    lut[h] = v;
+  }
+  const float2 *st = a.states + ((size_t)b << a.n);
+  constexpr uint32_t half = 1u << (kMwT - 1), lowmask = (1u << kMwL) - 1u;
+  static_assert(half == 8u * kMwThreads, "one staging round");
+  float acc[37];
+#pragma unroll
+  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
+
+  // One tile per workgroup.  (A persistent variant that keeps the 37 sums in registers across
+  // tiles was tried: hipcc then needs 256 VGPRs -> 1 wave/SIMD and runs 2x slower.)
+  (void)n_tiles;
+  {
+    const uint32_t tile = blockIdx.x;
+    uint64_t base = 0;
+    for (int i = 0; i < a.n - kMwT; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
+    __syncthreads();  // LUT ready / previous tile fully consumed
+    {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t j = (tid + u * kMwThreads) * 2u;
+        v[u] = *reinterpret_cast<const float4 *>(st + (base | lut[j >> kMwL] | (j & lowmask)));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        reinterpret_cast<float4 *>(s)[sw((tid + u * kMwThreads) * 2u) >> 1] = v[u];
+    }
+    __syncthreads();
+    const uint32_t tidv = (uint32_t)tid;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
+      const uint32_t bs =
+          sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3));
+      float2 r[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = s[bs ^ sw((uint32_t)c << (4 * g))];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float cr = 0.f, ci = 0.f, z = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c & (1 << t)) continue;
+          const float2 x = r[c], y = r[c | (1 << t)];
+          cr += x.x * y.x + x.y * y.y;
+          ci += x.y * y.x - x.x * y.y;
+          z += (x.x * x.x + x.y * x.y) - (y.x * y.x + y.y * y.y);
+        }
+        acc[3 * (4 * g + t)] += cr;
+        acc[3 * (4 * g + t) + 1] += ci;
+        acc[3 * (4 * g + t) + 2] += z;
+      }
+      if (g == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tot += r[c].x * r[c].x + r[c].y * r[c].y;
+        acc[36] += tot;
+      }
+    }
+  }
+  const int lane = tid & (kWave - 1), w = tid / kWave;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 37; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) red[w * 37 + k] = v;
+  }
+  __syncthreads();
+  if (tid < 37) {
+    float v = 0.f;
+    for (int i = 0; i < kMwThreads / kWave; ++i) v += red[i * 37 + tid];
+    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = v;
+  }
+}
+
+// purity of one wire from the per-tile rows: one block per (state, bit)
+__global__ void __launch_bounds__(1024)
+k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_passes, int batch,
+                 float *__restrict__ pur_out /* [batch][n] by bit position */) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, p = blockIdx.y;
+  const size_t pass_stride = (size_t)batch * n_tiles * kMwRow;
+  // chunk k covers bits [L + k*(T-L), ...); the last chunk is shifted down to stay full
+  int pass = 0, local = p;
+  if (p >= kMwL) {
+    pass = (p - kMwL) / (kMwT - kMwL);
+    local = kMwL + (p - kMwL) % (kMwT - kMwL);
+    if (pass == n_passes - 1 && n > kMwT) local = kMwL + (p - (n - (kMwT - kMwL)));
+  }
+  const float *pp = partial + pass * pass_stride + (size_t)b * n_tiles * kMwRow;
+  double cr = 0, ci = 0, z = 0, tot = 0;
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+    const float *row = pp + (size_t)i * kMwRow;
+    cr += row[3 * local]; ci += row[3 * local + 1]; z += row[3 * local + 2]; tot += row[36];
+  }
+  cr = block_sum_d(cr, red);
+  ci = block_sum_d(ci, red);
+  z = block_sum_d(z, red);
+  tot = block_sum_d(tot, red);
+  if (threadIdx.x == 0) {
+    const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
+    pur_out[(size_t)b * n + p] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
+  }
+}
+
+__global__ void k_mw_tile_q(const float *__restrict__ pur, int n, int batch,
+                            float *__restrict__ out, float *__restrict__ purities) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double sum = 0.0;
+  for (int p = 0; p < n; ++p) {
+    const float v = pur[(size_t)b * n + p];
+    sum += v;
+    if (purities) purities[(size_t)b * n + (n - 1 - p)] = v;  // index by wire
+  }
+  out[b] = (float)(2.0 * (1.0 - sum / n));
+}
+
 // ---------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------
@@ -1864,8 +2009,13 @@ int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint
   return QMLE_OK;
 }
 
+static int mw_passes(int n) { return n <= kMwT ? 1 : (n - kMwL + (kMwT - kMwL) - 1) / (kMwT - kMwL); }
+
 size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch) {
   if (n_qubits < 1 || batch < 1) return 0;
+  if (n_qubits >= kMwT)
+    return ((size_t)mw_passes(n_qubits) * batch * ((size_t)1 << (n_qubits - kMwT)) * kMwRow +
+            (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) + 256;
   return (size_t)batch * n_qubits * overlap_blocks(n_qubits) * sizeof(float4) + 256;
 }
 
@@ -1875,9 +2025,42 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
   if (!d_states || !d_out || !d_workspace || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
       batch < 1 || batch > 65535)
     return QMLE_ERR_INVALID_ARG;
-  const int nb = overlap_blocks(n_qubits);
-  if (workspace_bytes < (size_t)batch * n_qubits * nb * sizeof(float4)) return QMLE_ERR_WORKSPACE;
+  if (workspace_bytes + 256 < qmle_meyer_wallach_workspace_bytes(n_qubits, batch))
+    return QMLE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  const int n = n_qubits;
+  if (n >= kMwT) {  // LDS-staged tiles: ceil((n-4)/8) reads of the state
+    const int passes = mw_passes(n);
+    const uint32_t n_tiles = 1u << (n - kMwT);
+    const int tiles = (int)n_tiles;
+    const size_t lds = ((size_t)8 << kMwT) + ((size_t)4 << (kMwT - kMwL)) + 160 * sizeof(float);
+    for (int p = 0; p < passes; ++p) {
+      MwArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.states = (const float2 *)d_states;
+      a.partial = (float *)d_workspace + (size_t)p * batch * tiles * kMwRow;
+      a.n = n;
+      uint32_t mask = (1u << kMwL) - 1u;
+      // high chunk p; the last chunk is shifted down so that it still holds T-L bits
+      int lo = kMwL + p * (kMwT - kMwL);
+      if (lo + (kMwT - kMwL) > n) lo = n - (kMwT - kMwL);
+      for (int i = 0; i < kMwT - kMwL; ++i) mask |= 1u << (lo + i);
+      int nt = 0, no = 0;
+      for (int bit = 0; bit < n; ++bit) {
+        if (mask & (1u << bit)) a.tile_bits[nt++] = (int8_t)bit;
+        else a.outer_bits[no++] = (int8_t)bit;
+      }
+      hipLaunchKernelGGL(k_mw_tile, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
+    }
+    float *d_pur = (float *)d_workspace + (size_t)passes * batch * tiles * kMwRow;
+    hipLaunchKernelGGL(k_mw_tile_purity, dim3(batch, n), dim3(tiles >= 1024 ? 1024 : 64), 0,
+                       stream, (const float *)d_workspace, n, tiles, passes, batch, d_pur);
+    hipLaunchKernelGGL(k_mw_tile_q, dim3((batch + 63) / 64), dim3(64), 0, stream,
+                       (const float *)d_pur, n, batch, d_out, d_purities);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
+  const int nb = overlap_blocks(n_qubits);
   for (int p = 0; p < n_qubits; ++p)
     hipLaunchKernelGGL(k_cross_partial, dim3(nb, batch), dim3(256), 0, stream,
                        (const float4 *)d_states, n_qubits, p, (float4 *)d_workspace, nb);

@@ -187,3 +187,24 @@ def test_large_state_direct_and_tiled_agree_n22():
     e1 = N.Plan(ops, n, slots).run(ang, "expval", list(range(n)))
     e2 = N.expval_z(b, list(range(n)))
     assert float((e1 - e2).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("n", [12, 13, 17, 21])
+def test_meyer_wallach_lds_tile_path(n):
+    """n >= 12 takes the LDS-staged tile kernel (ceil((n-4)/8) reads): every wire's purity
+    against the oracle, including the shifted last chunk (n = 13, 17, 21)."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(n)
+    B = 3
+    st = rng.normal(size=(B, 2**n)) + 1j * rng.normal(size=(B, 2**n))
+    st /= np.linalg.norm(st, axis=1, keepdims=True)
+    # make it less uniform: entangle-ish structure via a phase ramp and amplitude decay
+    st *= np.exp(-np.arange(2**n) / 2**n)[None, :]
+    st /= np.linalg.norm(st, axis=1, keepdims=True)
+    dev = torch.from_numpy(st.astype(np.complex64)).cuda()
+    q, pur = N.meyer_wallach(dev, return_purities=True)
+    want_p = np.stack([OA.qubit_purities_pure(s, n) for s in st])
+    assert np.abs(pur.cpu().numpy() - want_p).max() < 2e-6
+    want_q = np.array([OA.meyer_wallach_pure(s, n) for s in st])
+    assert np.abs(q.cpu().numpy() - want_q).max() < 2e-6

@@ -84,6 +84,14 @@ def lds(n, B, layers=3):
               f"{len(ops) * B / med * 1e3:12.0f} gate-applies/s", flush=True)
 
 
+def mw(n, B=1):
+    D = 1 << n
+    st = torch.randn((B, D, 2), device="cuda", dtype=torch.float32)
+    st = torch.view_as_complex(st / st.norm() * (B ** 0.5)).contiguous()
+    med, best = timeit(lambda: N.meyer_wallach(st))
+    print(f"MW n={n} B={B} {med:8.3f} ms  {8.0 * D * B / med / 1e6:8.1f} GB/s (algorithmic 8*D)", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="k1,k2,lds")
@@ -100,6 +108,8 @@ if __name__ == "__main__":
         k2(a.k2n, a.k2b, fused=True)
         k2(a.k2n, min(a.k2b, 2), fused=False)
         k2(20, 64, fused=True)
+    if "mw" in what:
+        mw(28); mw(24, 8); mw(20, 64); mw(16, 256)
     if "lds" in what:
         lds(12, 2048)
         lds(10, 4096, layers=7)
