@@ -7,9 +7,11 @@ at a time from full density matrices (``jaqsi.partial_trace``) and squares
 (Schmidt decomposition) and ``rho_j`` is 2x2, so the HIP kernel only needs, per
 wire, the two populations and one cross term: ``a^2 + d^2 + 2|c|^2``.
 
-The multi-register measures (Bell measurement, relative entropy, entanglement of
-formation, concentratable entanglement; ``entanglement.py:106-712``) are later rows
-(SURVEY.md 8-f rank 1).
+``bell_measurements`` (``entanglement.py:106-219``) and ``concentratable_entanglement``
+(``:471-576``) build 2n- / 3n-qubit circuits from shifted copies of the model circuit
+(``tape.copy_to_tape``) and read marginal probabilities -- same kernels at a larger
+register.  ``relative_entropy`` / ``entanglement_of_formation``
+need matrix logarithms / eigendecompositions of density matrices and stay out of scope.
 """
 from __future__ import annotations
 
@@ -21,7 +23,9 @@ import numpy as np
 from . import _native as N
 from . import distributed
 from . import jaqsi as js
+from . import operations as op
 from .model import Model
+from .tape import copy_to_tape
 
 log = logging.getLogger(__name__)
 
@@ -76,3 +80,84 @@ class Entanglement:
             states = torch.from_numpy(np.ascontiguousarray(states, dtype=np.complex64)).cuda()
         vals = [N.meyer_wallach(states[b0:b0 + 65535]) for b0 in range(0, states.shape[0], 65535)]
         return torch.cat(vals)
+
+    # ------------------------------------------------------------------ multi-register
+    @staticmethod
+    def _sample_params(model: Model, n_samples, random_key):
+        if n_samples is not None and n_samples > 0:
+            model.initialize_params(random_key, repeat=int(n_samples))
+        params = np.asarray(model.params)
+        return params.reshape(1, *params.shape) if params.ndim <= 2 else params
+
+    @staticmethod
+    def _register_states(script: js.Script, params, inputs, kwargs):
+        """States of the multi-register circuit for every parameter set: (S, 2^m) on device."""
+        kwargs = {k: v for k, v in kwargs.items() if k not in ("inputs", "execution_type")}
+        with distributed.local_only():
+            if params.shape[0] > 1:
+                return script.execute(type="state", args=(params, inputs, None, None),
+                                      kwargs=kwargs, in_axes=(0, None, None, None),
+                                      as_tensor=True)
+            return script.execute(type="state", args=(params, inputs, None, None), kwargs=kwargs,
+                                  as_tensor=True).reshape(1, -1)
+
+    @classmethod
+    def bell_measurements(cls, model: Model, n_samples: int, random_key=None,
+                          scale: bool = False, **kwargs: Any) -> float:
+        """Entangling capability from Bell measurements on two copies of the state
+        (``entanglement.py:106-219``): CX(q, q+n), H(q), then 1 - 2 P(|11>) per pair."""
+        if kwargs.get("noise_params"):
+            log.warning("Bell Measurements not suitable for noisy circuits. "
+                        "Consider 'concentratable entanglement' instead.")
+        n = model.n_qubits
+        if scale:
+            n_samples = (2**n) * n_samples
+
+        def bell_circuit(params, inputs, pulse_params=None, random_key=None, **kw):
+            def vari():
+                model._variational(params, inputs, **kw)
+
+            vari()
+            copy_to_tape(vari, offset=n)
+            for q in range(n):
+                op.CX(wires=[q, q + n])
+                op.H(wires=q)
+
+        params = cls._sample_params(model, n_samples, random_key)
+        inputs = model._inputs_validation(kwargs.get("inputs", None))
+        states = cls._register_states(js.Script(f=bell_circuit, n_qubits=2 * n), params, inputs,
+                                      kwargs)
+        # P(|11>) of wires (q, q+n) = last entry of the 2-wire marginal (jaqsi.py:141-146)
+        exp = np.stack([1 - 2 * N.marginal_probs(states, [q, q + n])[:, -1].cpu().numpy()
+                        for q in range(n)], axis=-1)  # (S, n)
+        measure = 2 * (1 - exp.mean(axis=0))
+        return min(max(float(measure.mean()), 0.0), 1.0)
+
+    @classmethod
+    def concentratable_entanglement(cls, model: Model, n_samples: int, random_key=None,
+                                    scale: bool = False, **kwargs: Any) -> float:
+        """Concentratable entanglement (arXiv:2104.06923) by a swap test on 3n qubits
+        (``entanglement.py:471-576``): 1 - P(ancilla register = 0...0)."""
+        n = model.n_qubits
+        if scale:
+            n_samples = (2**n) * n_samples
+
+        def swap_test(params, inputs, pulse_params=None, random_key=None, **kw):
+            def vari():
+                model._variational(params, inputs, **kw)
+
+            copy_to_tape(vari, offset=n)
+            copy_to_tape(vari, offset=2 * n)
+            for i in range(n):
+                op.H(wires=i)
+            for i in range(n):
+                op.CSWAP(wires=[i, i + n, i + 2 * n])
+            for i in range(n):
+                op.H(wires=i)
+
+        params = cls._sample_params(model, n_samples, random_key)
+        inputs = model._inputs_validation(kwargs.get("inputs", None))
+        states = cls._register_states(js.Script(f=swap_test, n_qubits=3 * n), params, inputs,
+                                      kwargs)
+        p0 = N.marginal_probs(states, list(range(n)))[:, 0].cpu().numpy()
+        return float((1 - p0).mean())

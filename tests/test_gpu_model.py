@@ -356,3 +356,53 @@ def test_baseline_sizes_by_properties():
     st = ghz.run(None, "state")
     assert abs(float(N.meyer_wallach(st)[0]) - 1) < 1e-5
     assert abs(float(st[0, 0].abs() ** 2) - 0.5) < 1e-6 and abs(float(st[0, -1].abs() ** 2) - 0.5) < 1e-6
+
+
+def test_bell_measurement_equals_meyer_wallach():
+    """tests/test_entanglement.py:288-313: MW == Bell measurement (abs 1e-5) on the same
+    parameter samples; plus the 2n-qubit circuit against the oracle for fixed parameters."""
+    from copy import deepcopy
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+
+    for nq in (2, 4):
+        model = Model(n_qubits=nq, n_layers=1, circuit_type="Circuit_4", data_reupload=False)
+        mw = Entanglement.meyer_wallach(deepcopy(model), n_samples=1000, random_key=1000)
+        bell = Entanglement.bell_measurements(deepcopy(model), n_samples=1000, random_key=1000)
+        assert abs(mw - bell) < 1e-5, (nq, mw, bell)
+    # explicit oracle for one parameter set, n = 3
+    m = Model(3, 1, "Circuit_19", data_reupload=False)
+    p = np.asarray(m.params[0])
+    spec = OC.ModelSpec(3, 1, "Circuit_19", data_reupload=False)
+    base = [g for g in OC.model_tape(spec, p, [0.0]) if g[0] != "Barrier"]
+    shifted = [(g[0], [w + 3 for w in g[1]], g[2]) for g in base]
+    tape = base + shifted + [x for q in range(3) for x in (("CX", [q, q + 3], ()), ("H", [q], ()))]
+    pr = np.abs(OE.simulate_pure(tape, 6, c128)) ** 2
+    exp = np.array([1 - 2 * OA.marginalize_probs(pr, 6, [q, q + 3])[0][-1] for q in range(3)])
+    want = min(max(float((2 * (1 - exp)).mean()), 0.0), 1.0)
+    got = Entanglement.bell_measurements(m, n_samples=None)
+    assert abs(got - want) < 1e-6
+
+
+def test_concentratable_entanglement_vs_oracle():
+    """entanglement.py:471-576 swap test on 3n qubits (CSWAP path) for fixed parameters."""
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+
+    n = 2
+    m = Model(n, 1, "Circuit_19", data_reupload=False)
+    p = np.asarray(m.params[0])
+    spec = OC.ModelSpec(n, 1, "Circuit_19", data_reupload=False)
+    base = [g for g in OC.model_tape(spec, p, [0.0]) if g[0] != "Barrier"]
+    tape = [(g[0], [w + n for w in g[1]], g[2]) for g in base]
+    tape += [(g[0], [w + 2 * n for w in g[1]], g[2]) for g in base]
+    tape += [("H", [i], ()) for i in range(n)]
+    tape += [("CSWAP", [i, i + n, i + 2 * n], ()) for i in range(n)]
+    tape += [("H", [i], ()) for i in range(n)]
+    pr = np.abs(OE.simulate_pure(tape, 3 * n, c128)) ** 2
+    want = 1 - OA.marginalize_probs(pr, 3 * n, list(range(n)))[0][0]
+    got = Entanglement.concentratable_entanglement(m, n_samples=None)
+    assert abs(got - want) < 1e-6
+    # product state (no entangler) -> 0;  sampling path runs
+    m0 = Model(2, 1, "Circuit_1", data_reupload=False)
+    assert abs(Entanglement.concentratable_entanglement(m0, n_samples=8, random_key=3)) < 1e-6
