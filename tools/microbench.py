@@ -43,9 +43,9 @@ def k1(n, which, flags_extra=0):
             plan = N.Plan(ops, n, 1, flags=N.plan_flags(no_fusion=True) | flags_extra)
             ws = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
             med, best = timeit(lambda: N.apply_inplace(plan, ang, st, ws))
-            rows.append((gate, w, med, nbytes * D / med / 1e9))
+            rows.append((gate, w, med, nbytes * D / med / 1e6))
             print(f"K1 n={n} {gate:4s} wire={w:2d} bit={n-1-w:2d} {med:8.3f} ms  "
-                  f"{nbytes * D / med / 1e9:8.1f} GB/s (algorithmic)", flush=True)
+                  f"{nbytes * D / med / 1e6:8.1f} GB/s (algorithmic)", flush=True)
     return rows
 
 
