@@ -18,13 +18,35 @@ import numpy as np
 
 
 class Batched:
-    """Array with a hidden leading batch axis (``data.shape == (B, *shape)``)."""
+    """Array with a hidden leading batch axis (``data.shape == (B, *shape)``).
+
+    Optionally carries *tangents* -- forward-mode derivatives with respect to leaf
+    arguments of the circuit function -- as a list of terms ``(leaf_id, index, coef)``:
+    element ``e`` of this value depends on element ``index[e]`` (flat index into the leaf's
+    per-sample array) with coefficient ``coef[:, e]``.  Gate angles are (bi)linear in the
+    leaves (``params[l][j]``, ``inputs[f] * enc_params[q, f] * 2**q``), so tracking sums,
+    constant scaling and products is enough; any other transformation drops the tangents
+    (:meth:`Script.gradient` then refuses to differentiate through that gate).
+    """
 
     __array_priority__ = 1000.0
-    __slots__ = ("data",)
+    __slots__ = ("data", "tan")
 
-    def __init__(self, data: np.ndarray):
+    def __init__(self, data: np.ndarray, tan=None):
         self.data = np.asarray(data)
+        self.tan = tan
+
+    @classmethod
+    def leaf(cls, data: np.ndarray, leaf_id: int) -> "Batched":
+        """Differentiable leaf: every element depends on itself with coefficient 1."""
+        data = np.asarray(data)
+        idx = np.arange(int(np.prod(data.shape[1:], dtype=np.int64))).reshape(data.shape[1:])
+        return cls(data, [(leaf_id, idx, np.ones_like(data, dtype=np.float64))])
+
+    def _map_tan(self, f_idx, f_coef):
+        if self.tan is None:
+            return None
+        return [(lid, f_idx(idx), f_coef(coef)) for lid, idx, coef in self.tan]
 
     # --- what circuit code may ask -------------------------------------------------
     @property
@@ -51,7 +73,8 @@ class Batched:
     def __getitem__(self, idx) -> "Batched":
         if not isinstance(idx, tuple):
             idx = (idx,)
-        return Batched(self.data[(slice(None),) + idx])
+        return Batched(self.data[(slice(None),) + idx],
+                       self._map_tan(lambda i: i[idx], lambda c: c[(slice(None),) + idx]))
 
     def __iter__(self):
         for i in range(len(self)):
@@ -60,11 +83,14 @@ class Batched:
     def reshape(self, *shape) -> "Batched":
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
-        return Batched(self.data.reshape((self.batch,) + tuple(shape)))
+        shape = tuple(shape)
+        return Batched(self.data.reshape((self.batch,) + shape),
+                       self._map_tan(lambda i: i.reshape(shape),
+                                     lambda c: c.reshape((self.batch,) + shape)))
 
     def squeeze(self) -> "Batched":
-        keep = [self.batch] + [s for s in self.shape if s != 1]
-        return Batched(self.data.reshape(keep))
+        keep = tuple(s for s in self.shape if s != 1)
+        return self.reshape(keep)
 
     def any(self) -> bool:
         return bool(self.data.any())
@@ -77,7 +103,7 @@ class Batched:
         return Batched(self.data.mean(axis=axis))
 
     def astype(self, dt) -> "Batched":
-        return Batched(self.data.astype(dt))
+        return Batched(self.data.astype(dt), self.tan)
 
     # --- arithmetic (right-aligned broadcasting on the visible shape) --------------
     def _align(self, other: Any):
@@ -95,25 +121,66 @@ class Batched:
             a = a.reshape((a.shape[0],) + (1,) * (b.ndim - self.ndim) + a.shape[1:])
         return a, b
 
-    def _bin(self, other, fn, swap=False):
-        a, b = self._align(other)
-        return Batched(fn(b, a) if swap else fn(a, b))
+    @staticmethod
+    def _scaled(tan, factor, out_shape):
+        """tangent terms times ``factor`` (broadcast to ``out_shape`` = (B, *shape))."""
+        if tan is None:
+            return []
+        out = []
+        for lid, idx, coef in tan:
+            c = np.broadcast_to(coef.reshape((coef.shape[0],) + (1,) * (len(out_shape) - coef.ndim)
+                                             + coef.shape[1:]) * factor, out_shape)
+            i = np.broadcast_to(idx.reshape((1,) * (len(out_shape) - 1 - idx.ndim) + idx.shape),
+                                out_shape[1:])
+            out.append((lid, i, np.array(c, dtype=np.float64)))
+        return out
 
-    def __add__(self, o): return self._bin(o, np.add)
-    def __radd__(self, o): return self._bin(o, np.add, True)
-    def __sub__(self, o): return self._bin(o, np.subtract)
-    def __rsub__(self, o): return self._bin(o, np.subtract, True)
-    def __mul__(self, o): return self._bin(o, np.multiply)
-    def __rmul__(self, o): return self._bin(o, np.multiply, True)
-    def __truediv__(self, o): return self._bin(o, np.divide)
+    def _bin(self, other, fn, swap=False, kind=None):
+        a, b = self._align(other)
+        res = fn(b, a) if swap else fn(a, b)
+        tan = None  # None = derivative unknown; [] = known to be constant
+        o_tan = other.tan if isinstance(other, Batched) else []
+        if self.tan is not None and o_tan is not None and kind is not None:
+            shp = res.shape
+            if kind == "add":
+                tan = self._scaled(self.tan, 1.0, shp) + self._scaled(o_tan, 1.0, shp)
+            elif kind == "sub":
+                sa, sb = (-1.0, 1.0) if swap else (1.0, -1.0)
+                tan = self._scaled(self.tan, sa, shp) + self._scaled(o_tan, sb, shp)
+            elif kind == "mul":  # product rule; a constant `other` has no tangent
+                tan = self._scaled(self.tan, b, shp) + self._scaled(o_tan, a, shp)
+            elif kind == "div" and not swap and not o_tan:
+                tan = self._scaled(self.tan, 1.0 / b, shp)
+            elif kind == "div":
+                tan = None
+        return Batched(res, tan)
+
+    def __add__(self, o): return self._bin(o, np.add, kind="add")
+    def __radd__(self, o): return self._bin(o, np.add, True, kind="add")
+    def __sub__(self, o): return self._bin(o, np.subtract, kind="sub")
+    def __rsub__(self, o): return self._bin(o, np.subtract, True, kind="sub")
+    def __mul__(self, o): return self._bin(o, np.multiply, kind="mul")
+    def __rmul__(self, o): return self._bin(o, np.multiply, True, kind="mul")
+    def __truediv__(self, o): return self._bin(o, np.divide, kind="div")
     def __rtruediv__(self, o): return self._bin(o, np.divide, True)
     def __pow__(self, o): return self._bin(o, np.power)
-    def __neg__(self): return Batched(-self.data)
+    def __neg__(self):
+        return Batched(-self.data,
+                       None if self.tan is None else self._scaled(self.tan, -1.0, self.data.shape))
     def __pos__(self): return self
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if method != "__call__" or kwargs.get("out") is not None:
             return NotImplemented
+        table = {np.add: "__add__", np.subtract: "__sub__", np.multiply: "__mul__",
+                 np.true_divide: "__truediv__", np.negative: "__neg__"}
+        if ufunc in table and len(inputs) <= 2 and not kwargs:
+            if len(inputs) == 1:
+                return -inputs[0]
+            x, y = inputs
+            if isinstance(x, Batched):
+                return getattr(x, table[ufunc])(y)
+            return getattr(y, "__r" + table[ufunc][2:])(x)
         batch = self.batch
         arrs = []
         nd = max((x.ndim if isinstance(x, Batched) else np.ndim(x)) for x in inputs)
@@ -123,10 +190,12 @@ class Batched:
                 arrs.append(d.reshape((batch,) + (1,) * (nd - x.ndim) + d.shape[1:]))
             else:
                 arrs.append(np.asarray(x))
-        return Batched(ufunc(*arrs, **kwargs))
+        const = all((x.tan == [] if isinstance(x, Batched) else True) for x in inputs)
+        return Batched(ufunc(*arrs, **kwargs), [] if const else None)  # non-linear: unknown
 
     def __repr__(self) -> str:
-        return f"Batched(batch={self.batch}, shape={self.shape})"
+        state = "unknown" if self.tan is None else ("const" if not self.tan else "tracked")
+        return f"Batched(batch={self.batch}, shape={self.shape}, tan={state})"
 
 
 def is_batched(x: Any) -> bool:
@@ -149,6 +218,20 @@ def as_param(x: Any):
     if arr.size != 1:
         raise ValueError(f"gate parameter must be scalar, got shape {arr.shape}")
     return float(arr.reshape(()))
+
+
+def param_tangent(x: Any):
+    """Tangent terms of a scalar gate parameter: list of (leaf_id, flat_index, coef (B,)),
+    ``[]`` for constants, ``None`` if the value is batched but its derivative is unknown."""
+    if not isinstance(x, Batched):
+        return []
+    if x.tan is None:
+        return None
+    out = []
+    for lid, idx, coef in x.tan:
+        out.append((lid, int(np.asarray(idx).reshape(-1)[0]),
+                    np.asarray(coef, dtype=np.float64).reshape(coef.shape[0], -1)[:, 0]))
+    return out
 
 
 def to_numpy(x: Any):

@@ -445,6 +445,50 @@ class Model:
             params = p.reshape(B, *params.shape[1:])
         return inputs, params
 
+    def gradient(self, params=None, inputs=None, enc_params=None, wrt: str = "params",
+                 force_mean: bool = False) -> np.ndarray:
+        """d<Z_q>/d``wrt`` for every output qubit by the parameter-shift rule
+        (:meth:`script.Script.gradient`); ``wrt`` in {"params", "inputs", "enc_params"}.
+
+        The reference differentiates ``model(...)`` with ``jax.grad``
+        (``tests/test_model.py:1097-1145``, ``docs/training.md``); without an autodiff
+        framework this method returns the Jacobian of the expectation values instead, from
+        which any cost gradient follows by the chain rule on the host.  Shape:
+        ``(*eff_batch_shape, n_outputs, *shape_of(wrt))`` (batch axes of size 1 dropped;
+        ``force_mean`` averages over the outputs like ``__call__``).
+        """
+        if wrt not in ("params", "inputs", "enc_params"):
+            raise ValueError(f"wrt must be 'params', 'inputs' or 'enc_params', got {wrt!r}")
+        self.execution_type = "expval"
+        params = self._params_validation(params)
+        inputs = self._inputs_validation(inputs)
+        enc_params = self._enc_params_validation(enc_params)
+        inputs, params = self._assimilate_batch(inputs, params)
+        if self.remove_zero_encoding and self._zero_inputs and self.batch_shape[0] == 1 \
+                and wrt != "params":
+            raise ValueError("inputs are all zero and remove_zero_encoding=True: the encoding "
+                             "gates are not on the tape; pass remove_zero_encoding=False")
+        _, obs = self._build_obs()
+        B = int(np.prod(self.eff_batch_shape))
+        args = (params, inputs, None, None, np.asarray(enc_params, dtype=np.float64))
+        in_axes = (0 if self.batch_shape[1] > 1 else None, 0 if self.batch_shape[0] > 1 else None,
+                   None, None, None)
+        argnum = {"params": 0, "inputs": 1, "enc_params": 4}[wrt]
+        kwargs = dict(noise_params=self.noise_params, gate_mode="unitary")
+        (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
+                                      in_axes=in_axes if B > 1 else None, argnums=(argnum,))
+        if B == 1:
+            jac = jac[None]
+        leaf = jac.shape[2:]
+        if wrt in ("params", "inputs") and in_axes[argnum] is None and leaf and leaf[0] == 1:
+            jac = jac.reshape(jac.shape[:2] + leaf[1:])  # drop the dummy batch axis of the arg
+        jac = jac.reshape(*self.eff_batch_shape, *jac.shape[1:])
+        jac = jac.reshape([d for i, d in enumerate(jac.shape)
+                           if not (i < len(self.eff_batch_shape) and d == 1)])
+        if force_mean:
+            jac = jac.mean(axis=len([d for d in self.eff_batch_shape if d != 1]))
+        return jac
+
     def record_tape(self, params=None, inputs=None, enc_params=None):
         """Validate + batch the arguments exactly like ``__call__`` and return
         ``(tape, batch)`` without executing (host only; used by tests and tools)."""

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
-from .batching import Batched, as_param
+from .batching import Batched, as_param, param_tangent
 from .tape import active_tape, recording  # noqa: F401  (re-export, like the reference)
 
 CDTYPE = np.complex64  # reference default: JAX x64 off (operations.py:12-16)
@@ -78,6 +78,22 @@ class Operation:
     _num_wires: Optional[int] = None
     _param_names: Tuple[str, ...] = ()
     _native: Optional[str] = None  # engine opcode name (include/qmle_sv.h)
+    # parameter-shift rule of the gate parameters: "two" = generator spectrum {-1/2, +1/2} or
+    # {0, 1}; "four" = controlled rotation (spectrum {0, +-1/2}); None = not differentiable
+    _shift_rule: Optional[str] = None
+
+    def _store_param(self, name: str, value) -> None:
+        """Keep the numeric value (float / (B,) column) and, when the value came from a
+        differentiable leaf, its tangent terms (see :mod:`batching`)."""
+        setattr(self, name, as_param(value))
+        if "_tangents" not in self.__dict__:
+            self._tangents = {}
+        self._tangents[name] = param_tangent(value)
+
+    @property
+    def parameter_tangents(self) -> list:
+        t = self.__dict__.get("_tangents", {})
+        return [t.get(n, []) for n in self._param_names]
 
     def __init__(self, wires: Union[int, Sequence[int]] = 0, matrix=None, record: bool = True,
                  name: Optional[str] = None) -> None:
@@ -307,8 +323,10 @@ class _Rotation(Operation):
     _param_names = ("theta",)
     _axis = "X"
 
+    _shift_rule = "two"
+
     def __init__(self, theta, wires=0, **kw) -> None:
-        self.theta = as_param(theta)
+        self._store_param("theta", theta)
         super().__init__(wires=wires, **kw)
 
     def _build_matrix(self):
@@ -329,9 +347,12 @@ class Rot(Operation):
     _num_wires = 1
     _param_names = ("phi", "theta", "omega")
     _native = "Rot"
+    _shift_rule = "two"
 
     def __init__(self, phi, theta, omega, wires=0, **kw) -> None:
-        self.phi, self.theta, self.omega = as_param(phi), as_param(theta), as_param(omega)
+        self._store_param("phi", phi)
+        self._store_param("theta", theta)
+        self._store_param("omega", omega)
         super().__init__(wires=wires, **kw)
 
     def _build_matrix(self):
@@ -350,9 +371,10 @@ class ControlledPhaseShift(Operation):
     _param_names = ("phi",)
     _native = "CPhase"
     is_controlled = True
+    _shift_rule = "two"  # generator |11><11| has spectrum {0, 1}
 
     def __init__(self, phi, wires=(0, 1), **kw) -> None:
-        self.phi = as_param(phi)
+        self._store_param("phi", phi)
         super().__init__(wires=wires, **kw)
 
     def _build_matrix(self):
@@ -370,8 +392,10 @@ class PauliRot(Operation):
     _NATIVE_WORDS = {"X": "RX", "Y": "RY", "Z": "RZ", "XX": "RXX", "YY": "RYY", "ZZ": "RZZ",
                      "ZX": "RZX"}
 
+    _shift_rule = "two"
+
     def __init__(self, theta, pauli_word: str, wires=0, **kw) -> None:
-        self.theta = as_param(theta)
+        self._store_param("theta", theta)
         self.pauli_word = pauli_word
         super().__init__(wires=wires, **kw)
         if len(self.wires) != len(pauli_word):
@@ -414,8 +438,10 @@ class ControlledPauliRot(Operation):
     _param_names = ("theta",)
     is_controlled = True
 
+    _shift_rule = "four"
+
     def __init__(self, theta, pauli_word: str, wires, n_controls: int = 1, **kw) -> None:
-        self.theta = as_param(theta)
+        self._store_param("theta", theta)
         self.pauli_word = pauli_word
         self.n_controls = n_controls
         wl = _wire_list(wires)

@@ -165,3 +165,24 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
     if as_tensor:
         return res
     return res.cpu().numpy()
+
+
+def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], n_qubits: int,
+                     max_rows: int = 1 << 16) -> np.ndarray:
+    """Expectation values for every row of an explicit angle table (parameter-shift batches)."""
+    torch = N.require_gpu()
+    masks = [z_parity_mask(o) for o in obs]
+    single_z = bool(obs) and all(m is not None and len(m) == 1 for m in masks)
+    out = []
+    from . import memory
+    chunk = memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]),
+                                      "expval" if single_z else "state", False, len(obs),
+                                      n_ops=plan.n_ops)
+    for r0 in range(0, table.shape[0], chunk):
+        ang = torch.from_numpy(np.ascontiguousarray(table[r0:r0 + chunk])).cuda()
+        if single_z:
+            res = plan.run(ang, "expval", [m[0] for m in masks])
+        else:
+            res = _general_expval(plan.run(ang, "state"), n_qubits, list(obs))
+        out.append(res.cpu().numpy())
+    return np.concatenate(out, axis=0)

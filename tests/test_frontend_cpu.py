@@ -201,3 +201,26 @@ def test_script_in_axes_validation_and_tape_copy():
     with recording() as t:
         copy_to_tape(lambda: (op.H(wires=0), op.CX(wires=[0, 1])), offset=2)
     assert [(o.name, o.wires) for o in t] == [("H", [2]), ("CX", [2, 3])]
+
+
+def test_tangent_tracking_of_gate_angles():
+    """Forward-mode tangents of the batch tracer (used by Script.gradient): sums, constant
+    scaling and products are tracked; non-linear maps are flagged unknown, constants known."""
+    from qml_essentials_amd.batching import param_tangent
+
+    x = Batched.leaf(np.array([[1.0, 2.0], [3.0, 4.0]]), 7)   # B = 2, leaf shape (2,)
+    c = Batched(np.array([10.0, 20.0]), [])                    # batched constant
+    y = 3.0 * x[1] + x[0] * c - x[1] / 2.0
+    t = param_tangent(y)
+    got = {}
+    for lid, flat, coef in t:
+        assert lid == 7
+        got[flat] = got.get(flat, 0) + coef
+    assert np.allclose(got[1], [2.5, 2.5]) and np.allclose(got[0], [10.0, 20.0])
+    assert np.allclose(y.data, [3 * 2 + 1 * 10 - 1, 3 * 4 + 3 * 20 - 2])
+    assert param_tangent(np.sin(x[0])) is None          # unknown derivative
+    assert param_tangent(np.sin(c)) == []               # still a constant
+    assert param_tangent(0.3) == [] and param_tangent(Batched(np.zeros(2))) is None
+    prod = x[0] * x[1]                                    # product rule
+    tt = {flat: coef for _, flat, coef in param_tangent(prod)}
+    assert np.allclose(tt[0], [2.0, 4.0]) and np.allclose(tt[1], [1.0, 3.0])
