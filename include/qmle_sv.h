@@ -150,6 +150,18 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream);
 
+/* Angle table from DEVICE-resident arguments: out[b][s] = const[s] + sum_t coef[t] *
+ * leaf_{arg[t]}[row_k(b)][idx[t]], terms of slot s = [ptr[s], ptr[s+1]); row_k(b) =
+ * ((b + batch_offset) / div_k) % mod_k  (cartesian inputs x params batch, model.py:1449-1481).
+ * d_leaves / strides / div / mod are HOST arrays of n_leaves <= 8 entries; everything d_* is
+ * device memory.  Replaces the host-side angle arithmetic when params / inputs already
+ * live in HBM. */
+int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
+                      const int32_t *leaf_div, const int32_t *leaf_mod, int n_leaves,
+                      const int32_t *d_ptr, const int32_t *d_arg, const int32_t *d_idx,
+                      const float *d_coef, const float *d_const, int n_slots, int64_t batch,
+                      int64_t batch_offset, float *d_out, qmle_stream stream);
+
 /* Apply the plan's passes in place to resident states [batch][2^n] complex64 (no
  * initialisation, no measurement) -- the per-gate loop simulation.py:102-103 alone.
  * Workspace: qmle_workspace_bytes(plan, batch, QMLE_MEAS_STATE, 0, 0). */

@@ -89,6 +89,9 @@ SYMBOLS = [
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_build_angles", _I, [C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int32), _I, _VP, _VP, _VP, _VP, _VP, _I, C.c_int64,
+                               C.c_int64, _VP, _VP]),
     ("qmle_apply_inplace", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_profile_begin", _I, [_VP, _I]),
     ("qmle_profile_end", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
@@ -270,6 +273,28 @@ class Plan:
         )
         check(rc, "qmle_run_batch")
         return out
+
+
+def build_angles(leaves, strides, divs, mods, d_ptr, d_arg, d_idx, d_coef, d_const, n_slots,
+                 batch, batch_offset=0, out=None):
+    """Angle table [batch, n_slots] on device from device-resident leaf tensors."""
+    torch = require_gpu()
+    k = len(leaves)
+    dev = d_const.device
+    if out is None:
+        out = torch.empty((batch, max(n_slots, 0)), dtype=torch.float32, device=dev)
+    if n_slots == 0:
+        return out
+    lp = (_VP * max(1, k))(*[t.data_ptr() for t in leaves])
+    ls = (C.c_int64 * max(1, k))(*[int(v) for v in strides])
+    ld = (C.c_int32 * max(1, k))(*[int(v) for v in divs])
+    lm = (C.c_int32 * max(1, k))(*[int(v) for v in mods])
+    check(lib().qmle_build_angles(lp, ls, ld, lm, k, C.c_void_p(d_ptr.data_ptr()),
+                                  C.c_void_p(d_arg.data_ptr()), C.c_void_p(d_idx.data_ptr()),
+                                  C.c_void_p(d_coef.data_ptr()), C.c_void_p(d_const.data_ptr()),
+                                  int(n_slots), int(batch), int(batch_offset),
+                                  C.c_void_p(out.data_ptr()), _stream_ptr()), "qmle_build_angles")
+    return out
 
 
 def apply_inplace(plan: Plan, angles, states, workspace=None):

@@ -1280,6 +1280,38 @@ __global__ void k_mw_tile_q(const float *__restrict__ pur, int n, int batch,
   out[b] = (float)(2.0 * (1.0 - sum / n));
 }
 
+
+// ---------------------------------------------------------------------------
+// angle table from device-resident leaves:  table[b][s] = c[s] + sum_t coef[t] * leaf_{arg[t]}[row][idx[t]]
+// (gate angles are affine in params / inputs, ansaetze.py:323-371, model.py:804-816); the row
+// of leaf k for flattened sample b is (b / div_k) % mod_k -- the cartesian batch of
+// model.py:1449-1481 without materialising the repeats.
+// ---------------------------------------------------------------------------
+struct AngleLeaves {
+  const float *ptr[8];
+  long long stride[8];  // floats per row
+  int div[8], mod[8];
+};
+
+__global__ void __launch_bounds__(256)
+k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restrict__ arg,
+               const int *__restrict__ idx, const float *__restrict__ coef,
+               const float *__restrict__ cst, int n_slots, long long batch, long long b_offset,
+               float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * n_slots) return;
+  const long long b = i / n_slots;
+  const int s = (int)(i - b * n_slots);
+  const long long gb = b + b_offset;
+  float acc = cst[s];
+  for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
+    const int k = arg[t];
+    const long long row = (gb / lv.div[k]) % lv.mod[k];
+    acc = fmaf(coef[t], lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
+  }
+  out[i] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------
@@ -1807,6 +1839,31 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
     }
     if (rc != QMLE_OK) return rc;
   }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
+                      const int32_t *leaf_div, const int32_t *leaf_mod, int n_leaves,
+                      const int32_t *d_ptr, const int32_t *d_arg, const int32_t *d_idx,
+                      const float *d_coef, const float *d_const, int n_slots, int64_t batch,
+                      int64_t batch_offset, float *d_out, qmle_stream stream) {
+  if (n_leaves < 0 || n_leaves > 8 || n_slots < 0 || batch < 1 || !d_out || !d_ptr || !d_const)
+    return QMLE_ERR_INVALID_ARG;
+  if (n_slots == 0) return QMLE_OK;
+  AngleLeaves lv;
+  std::memset(&lv, 0, sizeof(lv));
+  for (int k = 0; k < n_leaves; ++k) {
+    if (!d_leaves[k] || leaf_div[k] < 1 || leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
+    lv.ptr[k] = d_leaves[k];
+    lv.stride[k] = leaf_strides[k];
+    lv.div[k] = leaf_div[k];
+    lv.mod[k] = leaf_mod[k];
+  }
+  const uint64_t total = (uint64_t)batch * (uint64_t)n_slots;
+  hipLaunchKernelGGL(k_build_angles, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     lv, d_ptr, d_arg, d_idx, d_coef, d_const, n_slots, (long long)batch,
+                     (long long)batch_offset, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

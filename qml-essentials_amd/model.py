@@ -518,10 +518,121 @@ class Model:
                              noise_params=noise_params, execution_type=execution_type,
                              force_mean=force_mean, gate_mode=gate_mode)
 
+    # ------------------------------------------------------------------ device-resident path
+    @staticmethod
+    def _is_cuda(x) -> bool:
+        return hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+    def _forward_device(self, params, inputs, enc_params, execution_type, force_mean):
+        """``__call__`` for CUDA-tensor ``params`` / ``inputs``: nothing per sample happens on
+        the host and the result stays on the GPU (a ``torch`` tensor).  Falls back to the host
+        path (returns ``NotImplemented``) for partial-wire density / probs or non-affine angles."""
+        import hashlib
+
+        import torch
+
+        from . import distributed
+        from .script import NotAffine
+
+        if execution_type is not None:
+            self.execution_type = execution_type
+        et = self.execution_type
+        if et in ("density", "probs") and not self.all_qubit_measurement:
+            return NotImplemented
+        enc = self._enc_params_validation(enc_params)
+        dev_params, dev_inputs = self._is_cuda(params), self._is_cuda(inputs)
+        # --- shapes (mirrors _params_validation / _inputs_validation, shapes only) ----------
+        if dev_params:
+            p = params.to(torch.float32)
+            p = p.unsqueeze(0) if p.dim() == 2 else p
+            p = p.contiguous()
+            B_P = int(p.shape[0])
+        else:
+            p = self._params_validation(params)
+            B_P = 1 if 0 in p.shape else int(p.shape[0])
+            if B_P > 1:
+                p, dev_params = torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).cuda(), True
+        if dev_inputs:
+            x = inputs.to(torch.float32)
+            if x.dim() <= 1:
+                if self.n_input_feat == 1:
+                    x = x.reshape(-1, 1)
+                elif x.numel() == self.n_input_feat:
+                    x = x.reshape(1, -1)
+                else:
+                    return NotImplemented
+            if x.shape[1] != self.n_input_feat:
+                raise ValueError(
+                    f"Wrong number of inputs provided. Expected {self.n_input_feat} "
+                    f"inputs, but input has shape {tuple(x.shape)}."
+                )
+            x = x.contiguous()
+            B_I = int(x.shape[0])
+            self._zero_inputs = False
+        else:
+            x = self._inputs_validation(inputs)
+            B_I = int(x.shape[0])
+            if B_I > 1:
+                x, dev_inputs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(), True
+        self._batch_shape = (B_I, B_P, 1)
+        B = int(np.prod(self.eff_batch_shape))
+        rep_i, rep_p, _ = self.repeat_batch_axis
+        cross = B_I > 1 and B_P > 1 and rep_i and rep_p
+        if B_I > 1 and B_P > 1 and not cross and B_I != B_P:
+            raise ValueError("zipped batch axes must have equal length")
+        # --- compiled call ------------------------------------------------------------------
+        meas_type, obs = self._build_obs()
+        leaf_ids = tuple(k for k, d in ((0, dev_params), (1, dev_inputs)) if d)
+        host_p = p[0].detach().cpu().numpy() if dev_params else np.asarray(p)
+        host_x = x[0].detach().cpu().numpy() if dev_inputs else np.asarray(x)
+        if not dev_params and host_p.ndim == 3 and host_p.shape[0] == 1:
+            host_p = host_p[0]
+        if not dev_inputs and host_x.ndim == 2 and host_x.shape[0] == 1:
+            host_x = host_x[0]
+        h = hashlib.blake2b(digest_size=12)
+        for a in (np.asarray(enc, dtype=np.float64), self.data_reupload,
+                  None if dev_params else host_p, None if dev_inputs else host_x):
+            h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
+        key = (meas_type, tuple((type(o).__name__, tuple(o.wires)) for o in obs), leaf_ids,
+               tuple(host_p.shape), tuple(host_x.shape), self._zero_inputs, B_I == 1,
+               self.remove_zero_encoding, h.hexdigest())
+        try:
+            cc = self.script.compiled(key, meas_type, obs, (host_p, host_x, None, None, enc),
+                                      leaf_ids, dict(noise_params=None, gate_mode="unitary"))
+        except NotAffine:
+            return NotImplemented
+        leaves, divs, mods = [], [], []
+        if dev_params:
+            leaves.append(p); divs.append(1); mods.append(B_P if B_P > 1 else 1)
+        if dev_inputs:
+            leaves.append(x); divs.append(B_P if cross else 1); mods.append(B_I if B_I > 1 else 1)
+        lo, hi = 0, B
+        sharded = distributed.enabled() and B >= distributed.world()[1]
+        if sharded:
+            lo, hi = distributed.shard_bounds(B)
+        result = cc.run(leaves, divs, mods, hi - lo, lo)
+        if sharded:
+            result = distributed.all_gather_rows(result, B)
+        result = result.reshape((*[int(d) for d in self.eff_batch_shape], *self._result_shape))
+        result = result.squeeze()
+        if et in ("expval", "probs") and force_mean and result.dim() > 0 and self._result_shape[0] > 1:
+            result = result.mean(dim=-1)
+        return result
+
     def _forward(self, params=None, inputs=None, pulse_params=None, enc_params=None,
                  data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
                  force_mean: bool = False, gate_mode: str = "unitary",
                  as_tensor: bool = False):
+        if (self._is_cuda(params) or self._is_cuda(inputs)) and not as_tensor \
+                and noise_params is None and self.noise_params is None and gate_mode == "unitary" \
+                and pulse_params is None and self.shots is None:
+            if data_reupload is not None:
+                self.data_reupload = data_reupload
+            out = self._forward_device(params, inputs, enc_params, execution_type, force_mean)
+            if out is not NotImplemented:
+                return out
+            params = params.detach().cpu().numpy() if self._is_cuda(params) else params
+            inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
         if noise_params is not None:
             self.noise_params = noise_params
         if execution_type is not None:

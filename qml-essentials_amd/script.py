@@ -13,10 +13,92 @@ from typing import Any, Callable, List, Optional, Tuple
 
 import numpy as np
 
+from . import _native as N
 from . import distributed, memory, simulation
 from .batching import Batched, to_numpy
-from .operations import Operation
+from .operations import Operation, z_parity_mask
 from .tape import recording
+
+
+class NotAffine(Exception):
+    """A gate angle is not an affine function of the device-resident arguments."""
+
+
+class CompiledCall:
+    """One traced circuit whose gate angles are affine in its device-resident arguments.
+
+    Counterpart of the reference's cached ``jit(vmap(...))`` executable
+    (``script.py:272-329,469-553``): tracing happens once on a two-row probe; afterwards a
+    call is three kernels' worth of work on the GPU -- ``qmle_build_angles`` (angle table
+    from the resident ``params`` / ``inputs`` tensors), the plan's passes, the measurement --
+    and nothing per sample on the host.
+    """
+
+    def __init__(self, script: "Script", type: str, obs, args: tuple, leaf_ids: Tuple[int, ...],
+                 kwargs: dict):
+        import torch
+
+        self.type, self.obs = type, list(obs)
+        rng = np.random.default_rng(12345)
+        probes, wrapped = {}, list(args)
+        for k in leaf_ids:  # args[k]: one host row of the device tensor, per-sample shape
+            row = np.asarray(args[k], dtype=np.float64)
+            pr = np.stack([row, row + rng.uniform(0.1, 1.0, row.shape)])
+            probes[k] = pr
+            wrapped[k] = Batched.leaf(pr, k)
+        tape = script._record(*wrapped, **kwargs)
+        self.n_qubits = script._n_qubits or simulation.infer_n_qubits(tape, obs)
+        low = simulation.LoweredTape(tape, self.n_qubits)
+        self.plan = simulation.get_plan(low)
+        self.n_slots = low.n_slots
+        values = np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), (2,))
+                           for v in low.values], axis=1) if low.values else np.zeros((2, 0))
+        ptr, arg, idx, coef, const = [0], [], [], [], []
+        slot = 0
+        order = {k: i for i, k in enumerate(leaf_ids)}
+        for op_ in tape:
+            if op_.lower(self.n_qubits) is None:
+                continue
+            tans = op_.parameter_tangents
+            for j, _ in enumerate(op_.parameters):
+                t = tans[j] if j < len(tans) else []
+                if t is None:
+                    raise NotAffine(op_.name)
+                c0 = values[0, slot]
+                c1 = values[1, slot]
+                for lid, flat, cf in t:
+                    cf = np.broadcast_to(np.asarray(cf, dtype=np.float64), (2,))
+                    if abs(cf[0] - cf[1]) > 1e-12 * max(1.0, abs(cf[0])):
+                        raise NotAffine(op_.name)
+                    arg.append(order[lid]); idx.append(int(flat)); coef.append(float(cf[0]))
+                    c0 -= cf[0] * probes[lid][0].reshape(-1)[flat]
+                    c1 -= cf[0] * probes[lid][1].reshape(-1)[flat]
+                if abs(c0 - c1) > 1e-9 * max(1.0, abs(c0), abs(values[0, slot])):
+                    raise NotAffine(op_.name)
+                const.append(c0)
+                ptr.append(len(arg))
+                slot += 1
+        dev = torch.device("cuda", torch.cuda.current_device())
+        i32 = lambda v: torch.tensor(v if len(v) else [0], dtype=torch.int32, device=dev)
+        f32 = lambda v: torch.tensor(v if len(v) else [0.0], dtype=torch.float32, device=dev)
+        self.d_ptr, self.d_arg, self.d_idx = i32(ptr), i32(arg), i32(idx)
+        self.d_coef, self.d_const = f32(coef), f32(const)
+        self.leaf_ids = leaf_ids
+
+    def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0):
+        """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order."""
+        strides = [int(np.prod(t.shape[1:], dtype=np.int64)) for t in leaves]
+        angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
+                                self.d_coef, self.d_const, self.n_slots, batch, batch_offset)
+        if self.n_slots == 0:
+            import torch
+            angles = torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device)
+        masks = [z_parity_mask(o) for o in self.obs]
+        if self.type == "expval":
+            if self.obs and all(m is not None and len(m) == 1 for m in masks):
+                return self.plan.run(angles, "expval", [m[0] for m in masks])
+            return simulation._general_expval(self.plan.run(angles, "state"), self.n_qubits, self.obs)
+        return self.plan.run(angles, self.type)
 
 
 class Script:
@@ -25,6 +107,18 @@ class Script:
     def __init__(self, f: Callable[..., None], n_qubits: Optional[int] = None) -> None:
         self.f = f
         self._n_qubits = n_qubits
+        self._compiled: dict = {}  # structure key -> CompiledCall (device-resident path)
+
+    def compiled(self, key, type: str, obs, args: tuple, leaf_ids: Tuple[int, ...],
+                 kwargs: Optional[dict] = None) -> CompiledCall:
+        """Fetch / build the :class:`CompiledCall` for ``key`` (raises :class:`NotAffine`)."""
+        cc = self._compiled.get(key)
+        if cc is None:
+            cc = CompiledCall(self, type, obs, args, leaf_ids, kwargs or {})
+            if len(self._compiled) > 64:
+                self._compiled.pop(next(iter(self._compiled)))
+            self._compiled[key] = cc
+        return cc
 
     def _record(self, *args, **kwargs) -> List[Operation]:
         with recording() as tape:
