@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 100 /* 0.1.0 */
+#define QMLE_SV_VERSION 110 /* 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -89,14 +89,17 @@ typedef enum qmle_opcode {
   QMLE_OP_DIAG_ALL = 26, /* DiagonalQubitUnitary on wires 0..n-1 in order (:922-926):
                             amp[i] *= exp(-i * consts[mat_off+i] * angle[slot0])
                             (Golomb encoding, unitary.py:661-701)              */
-  QMLE_OP__COUNT = 27
+  QMLE_OP_MAT4 = 27,   /* dense 16x16 on 4 wires, batch-constant; mat_off -> 512 floats.
+                          Superoperator of a 2-qubit Kraus channel on vec(rho)
+                          (KrausChannel.apply_to_density, operations.py:1551-1578)   */
+  QMLE_OP__COUNT = 28
 } qmle_opcode;
 
 /* One tape entry.  Barriers (operations.py:964) are not sent: simulate_pure skips
  * them (simulation.py:93-94). */
 typedef struct qmle_op {
   uint16_t opcode;  /* qmle_opcode */
-  int16_t wire[3];  /* reference wire order; unused = -1 */
+  int16_t wire[4];  /* reference wire order; unused = -1 */
   int32_t slot[3];  /* column of the angle table per parameter; unused = -1 */
   int32_t mat_off;  /* float offset into `consts` for MAT1/MAT2/DIAG_ALL, else -1 */
 } qmle_op;
@@ -196,6 +199,14 @@ int qmle_marginal_probs(const void *d_states, int n_qubits, int batch,
 int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d_out,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream);
 size_t qmle_pair_fidelity_workspace_bytes(int n_qubits, int n_pairs);
+/* Measurements of a vectorised density matrix (2n-"qubit" register, ket wires first:
+ * the layout of Operation.apply_to_density, operations.py:485-512): diagonal
+ * probabilities [batch][2^n] (measure_density "probs", simulation.py:303-304) and <Z> on
+ * obs_wires from that diagonal. */
+int qmle_density_probs(const void *d_rho, int n_qubits, int batch, float *d_out,
+                       qmle_stream stream);
+int qmle_density_expval_z(const void *d_rho, int n_qubits, int batch, const int32_t *obs_wires,
+                          int n_obs, float *d_out, qmle_stream stream);
 /* <a_i|b_i> for i < count (complex64 out[count]); the matrix-free general
  * observable path: <O> = Re <psi | O psi>  (simulation.py:263-269) */
 int qmle_overlap(const void *d_a, const void *d_b, int n_qubits, int count, void *d_out,

@@ -43,7 +43,7 @@ OPCODES = {
     "CX": 10, "CY": 11, "CZ": 12, "CRX": 13, "CRY": 14, "CRZ": 15,
     "CPhase": 16, "ControlledPhaseShift": 16, "SWAP": 17,
     "RXX": 18, "RYY": 19, "RZZ": 20, "RZX": 21, "CCX": 22, "CSWAP": 23,
-    "MAT1": 24, "MAT2": 25, "DIAG_ALL": 26,
+    "MAT1": 24, "MAT2": 25, "DIAG_ALL": 26, "MAT4": 27,
 }
 MEAS = {"state": 0, "probs": 1, "expval": 2, "density": 3}
 
@@ -68,7 +68,7 @@ def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=
 class QmleOp(C.Structure):
     _fields_ = [
         ("opcode", C.c_uint16),
-        ("wire", C.c_int16 * 3),
+        ("wire", C.c_int16 * 4),
         ("slot", C.c_int32 * 3),
         ("mat_off", C.c_int32),
     ]
@@ -102,6 +102,8 @@ SYMBOLS = [
     ("qmle_marginal_probs", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP]),
     ("qmle_pair_fidelity", _I, [_VP, _I, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_pair_fidelity_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_density_probs", _I, [_VP, _I, _I, _VP, _VP]),
+    ("qmle_density_expval_z", _I, [_VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP]),
     ("qmle_overlap", _I, [_VP, _VP, _I, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_overlap_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_expval_parity", _I, [_VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
@@ -181,10 +183,11 @@ class Plan:
                 raise ValueError(f"Unknown gate {name!r}")
             arr[i].opcode = code
             wires = list(wires)
-            if len(wires) > 3:
-                raise ValueError(f"{name} expects at most 3 wires, got {len(wires)}: {wires}")
-            for k in range(3):
+            if len(wires) > 4:
+                raise ValueError(f"{name} expects at most 4 wires, got {len(wires)}: {wires}")
+            for k in range(4):
                 arr[i].wire[k] = int(wires[k]) if k < len(wires) else -1
+            for k in range(3):
                 arr[i].slot[k] = int(slots[k]) if k < len(slots) else -1
             arr[i].mat_off = int(mat_off)
         if consts is None:
@@ -376,6 +379,29 @@ def pair_fidelity(states):
     check(lib().qmle_pair_fidelity(C.c_void_p(states.data_ptr()), n, S, C.c_void_p(out.data_ptr()),
                                    C.c_void_p(ws.data_ptr()), wsb, _stream_ptr()),
           "qmle_pair_fidelity")
+    return out
+
+
+def density_probs(rho_vec, n_qubits: int):
+    """diag(rho) of vectorised density matrices [B, 4^n] -> float32 [B, 2^n]."""
+    torch = require_gpu()
+    rho_vec = rho_vec.contiguous()
+    B = int(rho_vec.shape[0])
+    out = torch.empty((B, 1 << n_qubits), dtype=torch.float32, device=rho_vec.device)
+    check(lib().qmle_density_probs(C.c_void_p(rho_vec.data_ptr()), n_qubits, B,
+                                   C.c_void_p(out.data_ptr()), _stream_ptr()), "qmle_density_probs")
+    return out
+
+
+def density_expval_z(rho_vec, n_qubits: int, obs_wires: Sequence[int]):
+    torch = require_gpu()
+    rho_vec = rho_vec.contiguous()
+    B = int(rho_vec.shape[0])
+    out = torch.empty((B, len(obs_wires)), dtype=torch.float32, device=rho_vec.device)
+    check(lib().qmle_density_expval_z(C.c_void_p(rho_vec.data_ptr()), n_qubits, B,
+                                      _i32(obs_wires), len(obs_wires),
+                                      C.c_void_p(out.data_ptr()), _stream_ptr()),
+          "qmle_density_expval_z")
     return out
 
 

@@ -15,7 +15,9 @@ namespace qmle {
 enum LKind : uint8_t {
   LK_1Q = 0,       // (0..2 controls) x dense/diagonal 2x2 on t0
   LK_2Q = 1,       // (0..1 controls) x dense 4x4 on (t0,t1); row = 2*bit[t0] + bit[t1]
-  LK_DIAG_ALL = 2  // full-register diagonal exp(-i * mark[i] * x)
+  LK_DIAG_ALL = 2, // full-register diagonal exp(-i * mark[i] * x)
+  LK_4Q = 3        // dense 16x16 on (t0, t1, c0, c1) = 4 TARGET bits in wire order (MSB first);
+                   // batch-constant matrix in the const blob (2-qubit Kraus superoperators)
 };
 enum LFlag : uint8_t {
   LF_DIAG = 1,     // matrix is diagonal
@@ -24,7 +26,11 @@ enum LFlag : uint8_t {
 
 // A run of ops applied in ONE LDS round trip: every thread gathers the 2^4 amplitudes
 // spanned by `bits` into registers, applies all ops of the group there, scatters back.
-enum GKind : uint8_t { GK_SWEEP = 0 /* one op, LDS sweep */, GK_REG4 = 1 };
+enum GKind : uint8_t {
+  GK_SWEEP = 0,   // one op, LDS sweep
+  GK_REG4 = 1,    // run of (controlled) 2x2 ops on <= 4 bits, in registers
+  GK_DENSE4 = 2   // one LK_4Q op: gather over its 4 bits, 16x16 matrix-vector product
+};
 struct OpGroup {
   uint8_t kind;
   uint8_t n_ops;

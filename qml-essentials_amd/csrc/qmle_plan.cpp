@@ -46,6 +46,8 @@ bool op_info(int opcode, OpInfo *info) {
       *info = {2, 0, true}; return true;
     case QMLE_OP_DIAG_ALL:
       *info = {-1, 1, true}; return true;
+    case QMLE_OP_MAT4:
+      *info = {4, 0, true}; return true;
     default:
       return false;
   }
@@ -114,6 +116,40 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
     while (done[first]) ++first;
     OpGroup g{};
     g.op_begin = (uint32_t)(st.op_begin + out.size());
+    if (src[first].kind == LK_4Q && st.T >= 4) {
+      // gather order = ascending tile-local bit; permute the 16x16 matrix (given in wire
+      // order, first wire = MSB) into that order once, on the host
+      LoweredOp o = src[first];
+      const int pos4[4] = {o.t0, o.t1, o.c0, o.c1};  // wire order, MSB first
+      int sorted[4] = {pos4[0], pos4[1], pos4[2], pos4[3]};
+      std::sort(sorted, sorted + 4);
+      int rank_of[4];  // matrix bit (3 - j) of wire j  ->  gather bit = rank of its position
+      for (int j = 0; j < 4; ++j)
+        rank_of[j] = (int)(std::find(sorted, sorted + 4, pos4[j]) - sorted);
+      auto to_wire_index = [&](int c) {  // gather index c -> matrix index in wire order
+        int m = 0;
+        for (int j = 0; j < 4; ++j)
+          if (c & (1 << rank_of[j])) m |= 1 << (3 - j);
+        return m;
+      };
+      const size_t src_off = o.mat_off, dst_off = p->consts.size();
+      p->consts.resize(dst_off + 512);
+      for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 16; ++c) {
+          const int mr = to_wire_index(r), mc = to_wire_index(c);
+          p->consts[dst_off + 2 * (r * 16 + c)] = p->consts[src_off + 2 * (mr * 16 + mc)];
+          p->consts[dst_off + 2 * (r * 16 + c) + 1] = p->consts[src_off + 2 * (mr * 16 + mc) + 1];
+        }
+      o.mat_off = (uint32_t)dst_off;
+      g.kind = GK_DENSE4;
+      g.n_ops = 1;
+      for (int j = 0; j < 4; ++j) g.bits[j] = (uint8_t)sorted[j];
+      out.push_back(o);
+      done[first] = 1;
+      ++n_done;
+      p->op_groups.push_back(g);
+      continue;
+    }
     if (!groupable(src[first])) {
       g.kind = GK_SWEEP;
       g.n_ops = 1;
@@ -173,6 +209,7 @@ int compile_plan(qmle_plan *p) {
   p->mat_floats = 0;
   const bool fuse = !(p->flags & QMLE_PLAN_NO_FUSION);
   const bool no_fusion_flag = !fuse;
+  const size_t n_user_consts = p->consts.size();
   std::vector<std::vector<BuildOp>> group_ops;            // source gates per matrix
   std::vector<std::pair<uint32_t, uint32_t>> group_meta;  // (mat_off, dim)
   std::vector<int> group_of;                              // lowered index -> group
@@ -182,7 +219,7 @@ int compile_plan(qmle_plan *p) {
     OpInfo info;
     if (!op_info(op.opcode, &info)) return QMLE_ERR_UNKNOWN_OP;
     int nw = 0;
-    while (nw < 3 && op.wire[nw] >= 0) ++nw;
+    while (nw < 4 && op.wire[nw] >= 0) ++nw;
     if (op.opcode == QMLE_OP_DIAG_ALL) {
       // wires are implicitly 0..n-1 in order (operations.py:922-926)
       if (op.mat_off < 0 || (size_t)op.mat_off + (1ull << n) > p->consts.size())
@@ -195,7 +232,7 @@ int compile_plan(qmle_plan *p) {
           if (op.wire[a] == op.wire[b]) return QMLE_ERR_DUPLICATE_WIRES;
       }
       if (info.has_const) {
-        const size_t need = op.opcode == QMLE_OP_MAT1 ? 8 : 32;
+        const size_t need = op.opcode == QMLE_OP_MAT1 ? 8 : op.opcode == QMLE_OP_MAT2 ? 32 : 512;
         if (op.mat_off < 0 || (size_t)op.mat_off + need > p->consts.size())
           return QMLE_ERR_INVALID_ARG;
       }
@@ -225,6 +262,22 @@ int compile_plan(qmle_plan *p) {
       lo.slot = op.slot[0];
       for (int b = 0; b < n; ++b) last_touch[b] = (int)p->lowered.size();
       group_of.resize(p->lowered.size() + 1, -1);
+      p->lowered.push_back(lo);
+      p->lowered_src.push_back({(int)i});
+      continue;
+    }
+
+    if (op.opcode == QMLE_OP_MAT4) {
+      lo.kind = LK_4Q;
+      lo.t0 = pos(op.wire[0]); lo.t1 = pos(op.wire[1]);
+      lo.c0 = pos(op.wire[2]); lo.c1 = pos(op.wire[3]);
+      lo.nc = 0;
+      lo.mat_off = (uint32_t)op.mat_off;  // const blob; permuted copy is made per stage
+      const int idx4 = (int)p->lowered.size();
+      const uint64_t m4 = op_mask(lo, n);
+      for (int b = 0; b < n; ++b)
+        if (m4 & bit(b)) last_touch[b] = idx4;
+      group_of.resize(idx4 + 1, -1);
       p->lowered.push_back(lo);
       p->lowered_src.push_back({(int)i});
       continue;
@@ -311,6 +364,7 @@ int compile_plan(qmle_plan *p) {
     p->stages.clear();
     p->dev_ops.clear();
     p->op_groups.clear();
+    p->consts.resize(n_user_consts);  // drop permuted-matrix copies of a previous candidate
     const size_t nl = p->lowered.size();
     std::vector<char> done(nl, 0);
     size_t n_done = 0;

@@ -358,6 +358,37 @@ __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, c
   }
 }
 
+// GK_DENSE4: one dense 16x16 operator on 4 tile-local bits (2-qubit Kraus superoperator on
+// vec(rho)).  Matrix rows/cols are already in gather order (host-permuted).
+__device__ void lds_apply_dense4(float2 *__restrict__ s, int T, const OpGroup g,
+                                 const float *__restrict__ mat) {
+  const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+  uint32_t off[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    off[c] = sw(((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
+                ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
+  const uint32_t cnt = 1u << (T - 4);
+  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const uint32_t base = sw(ins0(ins0(ins0(ins0(i, b0), b1), b2), b3));
+    float2 a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = s[base ^ off[c]];
+    // the 16 slots of a work item are private to it and already in registers: results can
+    // be written back row by row
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {  // rolled: one matrix row (32 scalars) live at a time
+      const float *row = mat + 32 * r;
+      float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc = cfma(make_float2(row[2 * c], row[2 * c + 1]), a[c], acc);
+      const uint32_t o = ((r & 1) ? (1u << b0) : 0u) | ((r & 2) ? (1u << b1) : 0u) |
+                         ((r & 4) ? (1u << b2) : 0u) | ((r & 8) ? (1u << b3) : 0u);
+      s[base ^ sw(o)] = acc;
+    }
+  }
+}
+
 struct TileArgs {
   float2 *states;           // [B][2^n] (read unless init_zero; written for TM_STORE)
   const float *mats;        // [B][mat_floats]
@@ -472,6 +503,7 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
   }
 }
 
+template <bool DENSE4>
 __global__ void k_tile(const TileArgs a) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -546,6 +578,8 @@ __global__ void k_tile(const TileArgs a) {
     if (g.kind == GK_REG4) {
       if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin);
       else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin);
+    } else if (DENSE4 && g.kind == GK_DENSE4) {
+      lds_apply_dense4(s, T, g, a.consts + a.ops[g.op_begin].mat_off);
     } else {
       lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
     }
@@ -1312,6 +1346,33 @@ k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restric
   out[i] = acc;
 }
 
+
+// vec(rho) measurements: rho[i][j] at flat index i * D + j (ket bits first)
+__global__ void __launch_bounds__(256)
+k_density_probs(const float2 *__restrict__ rho, int n, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D) out[(size_t)b * D + i] = rho[((size_t)b << (2 * n)) + i * (D + 1)].x;
+}
+
+__global__ void __launch_bounds__(256)
+k_density_expval(const float2 *__restrict__ rho, int n, ObsBits obs, int n_obs,
+                 float *__restrict__ out) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, k = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const float2 *r = rho + ((size_t)b << (2 * n));
+  const int p = obs.bits[k];
+  double acc = 0.0;
+  for (uint64_t i = threadIdx.x; i < D; i += blockDim.x) {
+    const float v = r[i * (D + 1)].x;
+    acc += ((i >> p) & 1ull) ? -(double)v : (double)v;
+  }
+  const double tot = block_sum_d(acc, red);
+  if (threadIdx.x == 0) out[(size_t)b * n_obs + k] = (float)tot;
+}
+
 // ---------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------
@@ -1402,13 +1463,19 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_tile<false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_tile<true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  bool has_dense4 = false;  // 16x16 Kraus superoperators: separate instantiation, so that the
+                            // common kernel keeps its register budget
+  for (int g = st.grp_begin; g < st.grp_end; ++g) has_dense4 |= p->op_groups[g].kind == GK_DENSE4;
   const unsigned tiles = 1u << (p->n - st.T);
   dim3 grid(tiles, (unsigned)batch);
-  hipLaunchKernelGGL(k_tile, grid, dim3(tile_threads(st.T)), lds, stream, a);
+  if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(tile_threads(st.T)), lds, stream, a);
+  else hipLaunchKernelGGL(k_tile<false>, grid, dim3(tile_threads(st.T)), lds, stream, a);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }
@@ -1999,6 +2066,34 @@ int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d
   }
   hipLaunchKernelGGL(k_overlap_final, dim3(n_pairs), dim3(nb >= 256 ? 256 : 64), 0, stream,
                      (const float2 *)d_workspace, nb, n_pairs, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_density_probs(const void *d_rho, int n_qubits, int batch, float *d_out,
+                       qmle_stream stream) {
+  if (!d_rho || !d_out || n_qubits < 1 || 2 * n_qubits > QMLE_MAX_QUBITS || batch < 1 ||
+      batch > 65535)
+    return QMLE_ERR_INVALID_ARG;
+  const uint64_t D = (uint64_t)1 << n_qubits;
+  hipLaunchKernelGGL(k_density_probs, dim3(grid_for(D, 256), batch), dim3(256), 0,
+                     (hipStream_t)stream, (const float2 *)d_rho, n_qubits, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_density_expval_z(const void *d_rho, int n_qubits, int batch, const int32_t *obs_wires,
+                          int n_obs, float *d_out, qmle_stream stream) {
+  if (!d_rho || !d_out || !obs_wires || n_qubits < 1 || 2 * n_qubits > QMLE_MAX_QUBITS ||
+      batch < 1 || batch > 65535 || n_obs < 1 || n_obs > QMLE_MAX_QUBITS)
+    return QMLE_ERR_INVALID_ARG;
+  ObsBits ob;
+  for (int k = 0; k < n_obs; ++k) {
+    if (obs_wires[k] < 0 || obs_wires[k] >= n_qubits) return QMLE_ERR_WIRE_RANGE;
+    ob.bits[k] = (int8_t)(n_qubits - 1 - obs_wires[k]);
+  }
+  hipLaunchKernelGGL(k_density_expval, dim3(batch, n_obs), dim3(256), 0, (hipStream_t)stream,
+                     (const float2 *)d_rho, n_qubits, ob, n_obs, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

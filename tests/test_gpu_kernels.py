@@ -208,3 +208,41 @@ def test_meyer_wallach_lds_tile_path(n):
     assert np.abs(pur.cpu().numpy() - want_p).max() < 2e-6
     want_q = np.array([OA.meyer_wallach_pure(s, n) for s in st])
     assert np.abs(q.cpu().numpy() - want_q).max() < 2e-6
+
+
+def test_dense_4wire_operator_and_density_measurements():
+    """QMLE_OP_MAT4 (16x16 on 4 wires, any wire order) against the dense oracle, in the
+    whole-state and the tiled regime; diag / <Z> of a vectorised density matrix."""
+    from oracle.dense import lift
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(21)
+    n = 7
+    M = rng.normal(size=(16, 16)) + 1j * rng.normal(size=(16, 16))
+    M /= np.linalg.norm(M, 2)
+    pre = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    pre += [("CX", [q, q + 1], ()) for q in range(n - 1)]
+    psi = OE.simulate_pure(pre, n, np.complex128)
+    blob = np.stack([M.real, M.imag], axis=-1).astype(np.float32).reshape(-1)
+    for wires in ([0, 1, 2, 3], [6, 2, 0, 4], [3, 6, 5, 1]):
+        want = lift(M, wires, n) @ psi
+        ops, angles, consts = tape_to_native(pre, n)
+        off = len(consts)
+        ops = ops + [("MAT4", wires, [], off)]
+        consts = np.concatenate([consts, blob])
+        for flags in (0, N.plan_flags(force_global=True, tile_bits=5, low_bits=1),
+                      N.plan_flags(force_global=True, no_fusion=True, tile_bits=6, low_bits=2)):
+            plan = N.Plan(ops, n, len(angles), consts, flags)
+            got = plan.run(torch.from_numpy(angles[None, :]).cuda(), "state").cpu().numpy()[0]
+            assert np.abs(got - want).max() < 2e-6, (wires, flags)
+    # density measurements on a random (non-physical is fine) vectorised matrix
+    nq, B = 4, 3
+    rho = (rng.normal(size=(B, 16, 16)) + 1j * rng.normal(size=(B, 16, 16))).astype(np.complex64)
+    dev = torch.from_numpy(rho.reshape(B, -1)).cuda()
+    pr = N.density_probs(dev, nq).cpu().numpy()
+    assert np.abs(pr - np.real(np.einsum("bii->bi", rho))).max() < 1e-6
+    ez = N.density_expval_z(dev, nq, [0, 3, 1]).cpu().numpy()
+    idx = np.arange(16)
+    for k, w in enumerate([0, 3, 1]):
+        sign = 1 - 2 * ((idx >> (nq - 1 - w)) & 1)
+        assert np.abs(ez[:, k] - (pr * sign).sum(axis=1)).max() < 1e-5

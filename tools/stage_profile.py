@@ -30,9 +30,6 @@ def run(n, B, flags, label, reps=3):
 
 if __name__ == "__main__":
     F = N.plan_flags
-    run(24, 16, 0, "auto n24")
-    run(24, 16, F(tile_bits=13, low_bits=5), "T13 L5")
-    run(28, 2, 0, "auto n28")
-    run(28, 2, F(tile_bits=13, low_bits=5), "n28 T13 L5")
-    run(20, 64, 0, "auto n20")
-    run(16, 512, 0, "auto n16")
+    run(24, 32, 0, "auto n24")
+    for T, L in ((11, 4), (11, 3), (10, 3), (12, 3), (12, 4), (13, 5)):
+        run(24, 32, F(tile_bits=T, low_bits=L), f"T{T} L{L}")
