@@ -240,4 +240,6 @@ def to_numpy(x: Any):
         return x
     if hasattr(x, "detach"):
         return x.detach().cpu().numpy()
-    return np.asarray(x)
+    if isinstance(x, (list, tuple, numbers.Number, np.generic)):
+        return np.asarray(x)
+    return x  # dicts (noise_params passed positionally), PRNG keys, strings: not array data

@@ -43,6 +43,11 @@ def estimate_peak_bytes(n_qubits: int, batch_size: int, type: str, use_density: 
     """Device bytes needed to run ``batch_size`` samples in one engine call."""
     state = (2**n_qubits) * COMPLEX_BYTES
     out = output_bytes(type, batch_size, n_qubits, n_obs)
+    if use_density and type != "density":
+        # noisy tape: every sample's vec(rho) (4^n amplitudes) is materialised, plus one
+        # scratch copy for general observables
+        return int(1.1 * (out + 2 * batch_size * state * (2**n_qubits)
+                          + batch_size * max(n_ops, 1) * 64)) + (1 << 20)
     if type == "state":
         in_flight = 0  # computed in place in the output
     elif n_qubits <= 14 and type in ("probs", "expval"):

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import jaqsi as js
 from . import operations as op
+from .tape import recording
 from .ansaetze import Ansaetze, Circuit, Encoding
 from .batching import to_numpy
 from .gates import Gates
@@ -314,16 +315,18 @@ class Model:
             return
         if enc.is_golomb:
             if data_reupload[:, 0].any():
+                random_key, sub_key = safe_random_split(random_key)
                 scale = np.mean(enc_params[:, 0])
                 enc[0](self.transform_input(inputs[..., 0], scale),
                        wires=list(range(self.n_qubits)), noise_params=noise_params,
-                       random_key=None)
+                       random_key=sub_key)
             return
         for q in range(self.n_qubits):
             for idx in range(inputs.shape[-1]):
                 if data_reupload[q, idx]:
+                    random_key, sub_key = safe_random_split(random_key)
                     enc[idx](self.transform_input(inputs[..., idx], enc_params[q, idx]),
-                             wires=q, noise_params=noise_params, random_key=None)
+                             wires=q, noise_params=noise_params, random_key=sub_key)
 
     def _variational(self, params, inputs, pulse_params=None, random_key=None, enc_params=None,
                      gate_mode: str = "unitary", noise_params=None) -> None:
@@ -342,18 +345,105 @@ class Model:
                 )
             enc_params = self.enc_params
         if noise_params is None and self.noise_params is not None:
+            warnings.warn(
+                "Explicit call to `_circuit` or `_variational` detected: "
+                "`noise_params` is None, using `self.noise_params` instead.",
+                RuntimeWarning,
+            )
             noise_params = self.noise_params
+        if noise_params is not None:
+            if random_key is None:
+                warnings.warn(
+                    "Explicit call to `_circuit` or `_variational` detected: "
+                    "`random_key` is None, using the model's key instead.",
+                    RuntimeWarning,
+                )
+                random_key = self.random_key
+            self._apply_state_prep_noise(noise_params=noise_params)
 
         for q in range(self.n_qubits):
             for prep in self._sp:
-                prep(wires=q, noise_params=noise_params, gate_mode=gate_mode)
+                random_key, sub_key = safe_random_split(random_key)
+                prep(wires=q, noise_params=noise_params, random_key=sub_key, gate_mode=gate_mode)
         for layer in range(self.n_layers):
-            self.pqc(params[layer], self.n_qubits, noise_params=noise_params, gate_mode=gate_mode)
+            random_key, sub_key = safe_random_split(random_key)
+            self.pqc(params[layer], self.n_qubits, noise_params=noise_params,
+                     random_key=sub_key, gate_mode=gate_mode)
+            random_key, sub_key = safe_random_split(random_key)
             self._iec(inputs, data_reupload=self.data_reupload[layer], enc=self._enc,
-                      enc_params=enc_params[layer], noise_params=noise_params)
+                      enc_params=enc_params[layer], noise_params=noise_params,
+                      random_key=sub_key)
         if self.has_dru:
+            random_key, sub_key = safe_random_split(random_key)
             self.pqc(params[self.n_layers], self.n_qubits, noise_params=noise_params,
-                     gate_mode=gate_mode)
+                     random_key=sub_key, gate_mode=gate_mode)
+        if noise_params is not None:
+            self._apply_general_noise(noise_params=noise_params)
+
+    # ------------------------------------------------------------------ noise
+    def _apply_state_prep_noise(self, noise_params) -> None:
+        """BitFlip(p = "StatePreparation") on every qubit (``model.py:1000-1020``)."""
+        p = noise_params.get("StatePreparation", 0.0)
+        if p > 0:
+            for q in range(self.n_qubits):
+                op.BitFlip(p, wires=q)
+
+    def _apply_general_noise(self, noise_params) -> None:
+        """End-of-circuit decoherence channels per qubit: AmplitudeDamping, PhaseDamping,
+        Measurement (BitFlip), ThermalRelaxation with gate time = depth * t_factor
+        (``model.py:1022-1064``)."""
+        amp = noise_params.get("AmplitudeDamping", 0.0)
+        phase = noise_params.get("PhaseDamping", 0.0)
+        thermal = noise_params.get("ThermalRelaxation", 0.0)
+        meas = noise_params.get("Measurement", 0.0)
+        for q in range(self.n_qubits):
+            if amp > 0:
+                op.AmplitudeDamping(amp, wires=q)
+            if phase > 0:
+                op.PhaseDamping(phase, wires=q)
+            if meas > 0:
+                op.BitFlip(meas, wires=q)
+            if isinstance(thermal, dict):
+                tg = self._get_circuit_depth() * thermal["t_factor"]
+                op.ThermalRelaxationError(1.0, thermal["t1"], thermal["t2"], tg, q)
+
+    def _get_circuit_depth(self, inputs=None) -> int:
+        """Critical-path length of the noise-free circuit: every gate is scheduled at the
+        earliest step where all its wires are free (``model.py:1066-1118``); cached."""
+        if hasattr(self, "_cached_circuit_depth"):
+            return self._cached_circuit_depth
+        inputs = self._inputs_validation(inputs)
+        saved, self._noise_params = self._noise_params, None
+        try:
+            with recording() as tape:
+                self._variational(self.params[0] if self.params.ndim == 3 else self.params,
+                                  inputs[0] if inputs.ndim == 2 else inputs, noise_params=None)
+        finally:
+            self._noise_params = saved
+        busy, depth = {}, 0
+        for gate in tape:
+            if isinstance(gate, op.KrausChannel):
+                continue
+            end = max((busy.get(w, 0) for w in gate.wires), default=0) + 1
+            for w in gate.wires:
+                busy[w] = end
+            depth = max(depth, end)
+        self._cached_circuit_depth = depth
+        return depth
+
+    def _requires_density(self) -> bool:
+        """Density request, or any incoherent channel with non-zero strength
+        (``model.py:1485-1510``); GateError alone stays on the pure path."""
+        if self.execution_type == "density":
+            return True
+        if self.noise_params is None:
+            return False
+        for k, v in self.noise_params.items():
+            if k == "GateError":
+                continue
+            if isinstance(v, dict) or (v is not None and v > 0):
+                return True
+        return False
 
     def _build_obs(self) -> Tuple[str, List[op.Operation]]:
         et = self.execution_type
@@ -652,7 +742,7 @@ class Model:
         inputs = self._inputs_validation(inputs)
         enc_params = self._enc_params_validation(enc_params)
         inputs, params = self._assimilate_batch(inputs, params)
-        self.random_key, _ = safe_random_split(self.random_key)
+        self.random_key, sub_key = safe_random_split(self.random_key)
 
         meas_type, obs = self._build_obs()
         B = int(np.prod(self.eff_batch_shape))
@@ -669,7 +759,10 @@ class Model:
         else:
             as_tensor_call = as_tensor
 
-        args = (params, inputs, None, None, enc_params)
+        # one key for the whole batch: GateError draws B values per gate from it (the
+        # reference vmaps over B split keys, model.py:1678-1691)
+        args = (params, inputs, None, sub_key if self.noise_params is not None else None,
+                enc_params)
         if B > 1:
             in_axes = (0 if self.batch_shape[1] > 1 else None,
                        0 if self.batch_shape[0] > 1 else None, None, None, None)

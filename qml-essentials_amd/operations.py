@@ -7,8 +7,12 @@ the statevector arithmetic is done by ``libqmle_sv`` (HIP), which receives the
 record through :meth:`Operation.lower`.  Parameters may be floats or per-sample
 columns (see :mod:`batching`), so one tape serves a whole batch.
 
-Out of scope here: Kraus channels, ``ParametrizedHamiltonian``,
-``PauliWord`` algebra, pulse evolution.
+Noise channels (``KrausChannel`` and subclasses, ``operations.py:1490-1929``) are records
+too: on the engine a channel is the superoperator ``sum_k K_k (x) conj(K_k)`` acting on the
+ket and bra copies of its wires in the vectorised density matrix (see ``simulation.py``).
+
+Out of scope here: ``ParametrizedHamiltonian``, ``PauliWord``
+algebra, pulse evolution.
 """
 from __future__ import annotations
 
@@ -235,6 +239,42 @@ class Operation:
             raise NotImplementedError(f"{self.name}: generic {k}-qubit matrices are not supported")
         blob = np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
         return ("MAT1" if k == 1 else "MAT2"), self.wires, [], blob
+
+
+def _neg(x):
+    return -x if not isinstance(x, np.ndarray) else -x
+
+
+# how U* (the gate acting on the bra wires of vec(rho), operations.py:505-510) is obtained
+# from U for the named gates: negate these parameter positions, keep the others
+_CONJ_NEGATE = {"RX": (0,), "RZ": (0,), "CRX": (0,), "CRZ": (0,), "CPhase": (0,), "RXX": (0,),
+                "RYY": (0,), "RZZ": (0,), "RZX": (0,), "Rot": (0, 2), "RY": (), "CRY": (),
+                "H": (), "PauliX": (), "PauliZ": (), "CX": (), "CZ": (), "SWAP": (), "CCX": (),
+                "CSWAP": (), "Id": ()}
+
+
+def conj_lower(op_: "Operation", n_qubits: int, offset: int):
+    """Lowered form of ``conj(U)`` on wires shifted by ``offset`` (the bra register)."""
+    low = op_.lower(n_qubits)
+    if low is None:
+        return None
+    name, wires, params, blob = low
+    wires = [w + offset for w in wires]
+    if name in _CONJ_NEGATE:
+        neg = _CONJ_NEGATE[name]
+        return name, wires, [(-p if j in neg else p) for j, p in enumerate(params)], None
+    if name in ("MAT1", "MAT2", "MAT4"):
+        b = np.array(blob, dtype=np.float32).reshape(-1, 2)
+        b[:, 1] *= -1
+        return name, wires, [], b.reshape(-1)
+    if name == "DIAG_ALL":
+        raise NotImplementedError("full-register diagonal encodings in density-matrix mode")
+    # PauliY, CY, S ...: conjugate the explicit matrix
+    m = np.conj(np.asarray(op_.matrix))
+    if m.ndim != 2 or len(wires) > 2:
+        raise NotImplementedError(f"conj({op_.name}) is not available on the engine")
+    blob = np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
+    return ("MAT1" if len(wires) == 1 else "MAT2"), wires, [], blob
 
 
 def embed_matrix(mat: np.ndarray, wires: Sequence[int], all_wires: Sequence[int]) -> np.ndarray:
@@ -563,3 +603,167 @@ def z_parity_mask(ob: Operation) -> Optional[List[int]]:
     if label is not None and set(label) == {"Z"} and len(label) == len(ob.wires):
         return list(ob.wires)
     return None
+
+
+# ---- noise channels ---------------------------------------------------------------------------
+class KrausChannel(Operation):
+    """phi(rho) = sum_k K_k rho K_k^dagger  (``operations.py:1490-1578``).
+
+    Channels cannot act on a pure statevector; a tape that contains one is simulated on
+    the vectorised density matrix, where the channel is the dense operator
+    :meth:`superoperator` on ``[wires..., wires + n_qubits...]``.
+    """
+
+    def kraus_matrices(self) -> List[np.ndarray]:
+        raise NotImplementedError
+
+    @property
+    def matrix(self) -> np.ndarray:
+        raise TypeError(
+            f"{type(self).__name__} is a noise channel and has no single "
+            "unitary matrix. Use apply_to_density() instead."
+        )
+
+    def superoperator(self) -> np.ndarray:
+        """sum_k K_k (x) conj(K_k): row/col index = (ket bits of the wires, bra bits)."""
+        ks = [np.asarray(k, dtype=np.complex128) for k in self.kraus_matrices()]
+        return sum(np.kron(k, np.conj(k)) for k in ks)
+
+    def lower(self, n_qubits: int):
+        raise TypeError(
+            f"{type(self).__name__} is a noise channel and cannot be "
+            "applied to a pure statevector. Use execute(type='density') instead."
+        )
+
+
+def _check_unit(name: str, v: float) -> float:
+    v = float(v)
+    if not 0.0 <= v <= 1.0:
+        raise ValueError(f"{name} must be in [0, 1].")
+    return v
+
+
+class BitFlip(KrausChannel):
+    """K0 = sqrt(1-p) I, K1 = sqrt(p) X."""
+
+    _num_wires = 1
+    _param_names = ("p",)
+
+    def __init__(self, p: float, wires=0) -> None:
+        self.p = _check_unit("p", p)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        return [np.sqrt(1 - self.p) * _I2, np.sqrt(self.p) * _X]
+
+
+class PhaseFlip(KrausChannel):
+    """K0 = sqrt(1-p) I, K1 = sqrt(p) Z."""
+
+    _num_wires = 1
+    _param_names = ("p",)
+
+    def __init__(self, p: float, wires=0) -> None:
+        self.p = _check_unit("p", p)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        return [np.sqrt(1 - self.p) * _I2, np.sqrt(self.p) * _Z]
+
+
+class DepolarizingChannel(KrausChannel):
+    """K0 = sqrt(1-p) I, K1..3 = sqrt(p/3) {X, Y, Z}."""
+
+    _num_wires = 1
+    _param_names = ("p",)
+
+    def __init__(self, p: float, wires=0) -> None:
+        self.p = _check_unit("p", p)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        q = np.sqrt(self.p / 3)
+        return [np.sqrt(1 - self.p) * _I2, q * _X, q * _Y, q * _Z]
+
+
+class AmplitudeDamping(KrausChannel):
+    """K0 = diag(1, sqrt(1-g)), K1 = sqrt(g) |0><1|."""
+
+    _num_wires = 1
+    _param_names = ("gamma",)
+
+    def __init__(self, gamma: float, wires=0) -> None:
+        self.gamma = _check_unit("gamma", gamma)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        g = self.gamma
+        return [np.array([[1, 0], [0, np.sqrt(1 - g)]], dtype=np.complex128),
+                np.array([[0, np.sqrt(g)], [0, 0]], dtype=np.complex128)]
+
+
+class PhaseDamping(KrausChannel):
+    """K0 = diag(1, sqrt(1-g)), K1 = diag(0, sqrt(g))."""
+
+    _num_wires = 1
+    _param_names = ("gamma",)
+
+    def __init__(self, gamma: float, wires=0) -> None:
+        self.gamma = _check_unit("gamma", gamma)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        g = self.gamma
+        return [np.array([[1, 0], [0, np.sqrt(1 - g)]], dtype=np.complex128),
+                np.array([[0, 0], [0, np.sqrt(g)]], dtype=np.complex128)]
+
+
+class ThermalRelaxationError(KrausChannel):
+    """T1 relaxation + T2 dephasing over a gate time ``tg`` (``operations.py:1790-1893``):
+    six reset / phase-flip operators for T2 <= T1, Choi-matrix eigen-operators otherwise."""
+
+    _num_wires = 1
+    _param_names = ("pe", "t1", "t2", "tg")
+
+    def __init__(self, pe: float, t1: float, t2: float, tg: float, wires=0) -> None:
+        if not 0.0 <= pe <= 1.0:
+            raise ValueError("pe must be in [0, 1].")
+        if t1 <= 0:
+            raise ValueError("t1 must be > 0.")
+        if t2 <= 0:
+            raise ValueError("t2 must be > 0.")
+        if t2 > 2 * t1:
+            raise ValueError("t2 must be <= 2*t1.")
+        if tg < 0:
+            raise ValueError("tg must be >= 0.")
+        self.pe, self.t1, self.t2, self.tg = float(pe), float(t1), float(t2), float(tg)
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        pe, t1, t2, tg = self.pe, self.t1, self.t2, self.tg
+        e1, e2 = np.exp(-tg / t1), np.exp(-tg / t2)
+        p_reset = 1.0 - e1
+        if t2 <= t1:
+            pz = (1.0 - p_reset) * (1.0 - e2 / e1) / 2.0
+            pr0, pr1 = (1.0 - pe) * p_reset, pe * p_reset
+            pid = 1.0 - pz - pr0 - pr1
+            E = lambda r, c: np.array([[float((r, c) == (i, j)) for j in range(2)]  # noqa: E731
+                                       for i in range(2)], dtype=np.complex128)
+            return [np.sqrt(pid) * _I2, np.sqrt(pz) * _Z, np.sqrt(pr0) * E(0, 0),
+                    np.sqrt(pr0) * E(0, 1), np.sqrt(pr1) * E(1, 0), np.sqrt(pr1) * E(1, 1)]
+        choi = np.array([[1 - pe * p_reset, 0, 0, e2], [0, pe * p_reset, 0, 0],
+                         [0, 0, (1 - pe) * p_reset, 0], [e2, 0, 0, 1 - (1 - pe) * p_reset]],
+                        dtype=np.complex128)
+        lam, vec = np.linalg.eigh(choi)
+        return [np.sqrt(abs(lam[i])) * vec[:, i].reshape(2, 2, order="F") for i in range(4)]
+
+
+class QubitChannel(KrausChannel):
+    """Channel given by an explicit list of Kraus matrices (``operations.py:1896-1929``)."""
+
+    def __init__(self, kraus_ops, wires=0) -> None:
+        self._kraus_ops = [np.asarray(k, dtype=np.complex128) for k in kraus_ops]
+        super().__init__(wires=wires)
+
+    def kraus_matrices(self):
+        return self._kraus_ops

@@ -16,8 +16,8 @@ import numpy as np
 from . import _native as N
 from . import distributed, memory, simulation
 from .batching import Batched, to_numpy
-from .operations import Operation, z_parity_mask
-from .tape import recording
+from .operations import KrausChannel, Operation, z_parity_mask
+from .tape import batch_context, recording
 
 
 class NotAffine(Exception):
@@ -168,7 +168,8 @@ class Script:
                     wrapped.append(a)
                 else:
                     wrapped.append(Batched(np.moveaxis(np.asarray(a), ax, 0)[start:end]))
-            tape = self._record(*wrapped, **kwargs)
+            with batch_context(end - start):
+                tape = self._record(*wrapped, **kwargs)
             n_qubits = self._n_qubits or simulation.infer_n_qubits(tape, obs)
             return simulation.simulate_and_measure(
                 tape, n_qubits, type, obs, simulation.uses_density(tape, type), shots=shots,
@@ -178,12 +179,14 @@ class Script:
         # memory-aware chunking needs n_qubits / n_ops: probe with one sample's structure
         n_qubits = self._n_qubits
         n_ops = 1
-        if n_qubits is None:
+        use_density = False
+        if n_qubits is None or kwargs.get("noise_params"):
             probe = [a if ax is None or a is None else Batched(np.moveaxis(np.asarray(a), ax, 0)[:1])
                      for a, ax in zip(args, in_axes)]
             tape = self._record(*probe, **kwargs)
-            n_qubits = simulation.infer_n_qubits(tape, obs)
+            n_qubits = n_qubits or simulation.infer_n_qubits(tape, obs)
             n_ops = len(tape)
+            use_density = any(isinstance(o, KrausChannel) for o in tape)
         # multi-GPU: this rank simulates one contiguous block of the batch; one
         # all-gather returns the full result everywhere (script.py:443-453)
         lo, hi = 0, batch_size
@@ -191,7 +194,7 @@ class Script:
         if sharded:
             lo, hi = distributed.shard_bounds(batch_size)
         local = hi - lo
-        chunk = memory.compute_chunk_size(n_qubits, local, type, False, n_obs, n_ops=n_ops)
+        chunk = memory.compute_chunk_size(n_qubits, local, type, use_density, n_obs, n_ops=n_ops)
         if chunk >= local:
             res = run(lo, hi)[0]
         else:

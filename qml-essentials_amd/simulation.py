@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _native as N
-from .operations import Barrier, Operation, z_parity_mask
+from .operations import Barrier, KrausChannel, Operation, conj_lower, z_parity_mask
 
 MEAS_TYPES = ("expval", "probs", "state", "density")
 _PLAN_CACHE: "OrderedDict[tuple, N.Plan]" = OrderedDict()
@@ -33,8 +33,182 @@ def infer_n_qubits(ops: Sequence[Operation], obs: Sequence[Operation]) -> int:
 
 
 def uses_density(tape: Sequence[Operation], type: str) -> bool:
-    """Noise channels are not supported here, so only the explicit request counts."""
-    return type == "density"
+    """Density request, or a noise channel on the tape (``simulation.py:42-57``)."""
+    return type == "density" or any(isinstance(o, KrausChannel) for o in tape)
+
+
+MAX_DENSITY_QUBITS = 14  # vec(rho) is a 2n-qubit register; 2n <= 28 keeps it one tile plan
+
+
+class _Lowered:
+    """An already-lowered op (what ``LoweredTape`` consumes)."""
+
+    __slots__ = ("_low",)
+
+    def __init__(self, low):
+        self._low = low
+
+    def lower(self, n_qubits: int):
+        return self._low
+
+
+class _WideChannel:
+    """A channel on 3 or 4 wires: too wide for one dense engine operator (its superoperator
+    spans 6-8 wires), applied as the Kraus sum with one engine call per operator."""
+
+    __slots__ = ("kraus", "wires")
+
+    def __init__(self, kraus, wires):
+        self.kraus, self.wires = kraus, list(wires)
+
+    def kraus_plans(self, n_qubits: int):
+        """One tiny tape per Kraus operator: K on the ket wires, conj(K) on the bra wires,
+        both as 4-wire dense operators (3-wire K is padded with an untouched wire of the
+        other half of the register)."""
+        k = len(self.wires)
+        ket = list(self.wires)
+        bra = [w + n_qubits for w in self.wires]
+        for K in self.kraus:
+            K = np.asarray(K, dtype=np.complex128)
+            if k == 3:
+                K = np.kron(K, np.eye(2))
+                wk, wb = ket + [bra[0]], bra + [ket[0]]
+            else:
+                wk, wb = ket, bra
+            blob = lambda M: np.stack([M.real, M.imag], axis=-1).astype(np.float32).reshape(-1)  # noqa: E731
+            yield [_Lowered(("MAT4", wk, [], blob(K))), _Lowered(("MAT4", wb, [], blob(np.conj(K))))]
+
+
+def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
+    """The tape acting on vec(rho), a pure "state" of a 2n-wire register whose first n wires
+    carry the row (ket) index and whose last n wires carry the column (bra) index, so that
+    ``vec(rho)[i * 2^n + j] = rho[i, j]``.
+
+    * gate U -> U on the ket wires and conj(U) on the bra wires
+      (``rho -> U rho U^+``, ``simulation.py:106-128`` + ``operations.py:485-512``);
+    * channel {K} on wires w -> the dense superoperator ``sum_K K (x) conj(K)`` on
+      ``[w.., n + w..]`` (``operations.py:1552-1578``): a 4x4 operator for 1-wire channels,
+      a 16x16 one for 2-wire channels; 3- and 4-wire channels become a :class:`_WideChannel`.
+    """
+    out: list = []
+    for op_ in tape:
+        if isinstance(op_, Barrier):
+            continue
+        if isinstance(op_, KrausChannel):
+            k = len(op_.wires)
+            if k > 4:
+                raise NotImplementedError(
+                    f"{op_.name}: channels on more than 4 wires are not available on the engine")
+            if k > 2:
+                out.append(_WideChannel(op_.kraus_matrices(), op_.wires))
+                continue
+            S = op_.superoperator()
+            blob = np.stack([S.real, S.imag], axis=-1).astype(np.float32).reshape(-1)
+            wires = list(op_.wires) + [w + n_qubits for w in op_.wires]
+            out.append(_Lowered(("MAT2" if k == 1 else "MAT4", wires, [], blob)))
+            continue
+        low = op_.lower(n_qubits)
+        if low is None:
+            continue
+        if low[0] == "DIAG_ALL":
+            # rho_ij -> d_i conj(d_j) rho_ij (operations.py:944-961): one diagonal pass over
+            # the doubled register with marks m_i - m_j
+            m = np.asarray(low[3], dtype=np.float64)
+            out.append(_Lowered(("DIAG_ALL", [], low[2],
+                                 (m[:, None] - m[None, :]).reshape(-1).astype(np.float32))))
+            continue
+        out.append(_Lowered(low))
+        out.append(_Lowered(conj_lower(op_, n_qubits, n_qubits)))
+    return out
+
+
+def _apply_segment(seg, n2: int, B: int, rho_vec):
+    """Run a run of lowered ops on the doubled register: from |0..0> when ``rho_vec`` is
+    None, else in place on the resident ``rho_vec``."""
+    torch = N.require_gpu()
+    low = LoweredTape(seg, n2)
+    plan = get_plan(low)
+    angles = torch.from_numpy(low.angle_table(B)).cuda()
+    if rho_vec is None:
+        return plan.run(angles, "state")
+    for b0 in range(0, B, 65535):
+        sl = slice(b0, min(B, b0 + 65535))
+        N.apply_inplace(plan, angles[sl] if low.n_slots else None, rho_vec[sl])
+    return rho_vec
+
+
+def _evolve_density(tape: Sequence[Operation], n_qubits: int, B: int):
+    """vec(rho) [B, 4^n] after the whole (noisy) tape."""
+    torch = N.require_gpu()
+    n2 = 2 * n_qubits
+    rho_vec, seg = None, []
+    for item in doubled_tape(tape, n_qubits) + [None]:
+        if isinstance(item, _Lowered):
+            seg.append(item)
+            continue
+        if seg or rho_vec is None:
+            rho_vec = _apply_segment(seg, n2, B, rho_vec)
+            seg = []
+        if item is None:
+            break
+        acc = torch.zeros_like(rho_vec)
+        for pair in item.kraus_plans(n_qubits):
+            acc += _apply_segment(pair, n2, B, rho_vec.clone())
+        rho_vec = acc
+    return rho_vec
+
+
+def _density_expval(rho_vec, n_qubits: int, obs: Sequence[Operation]):
+    """Tr(O rho) per observable (``simulation.py:263-269`` for density matrices): Z natively,
+    anything else by applying O to the ket wires and summing the diagonal."""
+    torch = N.require_gpu()
+    B = rho_vec.shape[0]
+    masks = [z_parity_mask(o) for o in obs]
+    if obs and all(m is not None and len(m) == 1 for m in masks):
+        return N.density_expval_z(rho_vec, n_qubits, [m[0] for m in masks])
+    out = torch.empty((B, len(obs)), dtype=torch.float32, device=rho_vec.device)
+    diag = None
+    for k, (ob, m) in enumerate(zip(obs, masks)):
+        if m is not None:
+            if diag is None:
+                diag = N.density_probs(rho_vec, n_qubits).double()
+            idx = torch.arange(1 << n_qubits, device=rho_vec.device)
+            par = torch.zeros_like(idx)
+            for w in m:
+                par ^= (idx >> (n_qubits - 1 - w)) & 1
+            out[:, k] = (diag * (1.0 - 2.0 * par.double())).sum(dim=1).float()
+            continue
+        low = LoweredTape([ob], 2 * n_qubits)
+        plan = get_plan(low, N.PLAN_NO_FUSION)
+        scratch = rho_vec.clone()
+        N.apply_inplace(plan, None, scratch)
+        out[:, k] = N.density_probs(scratch, n_qubits).double().sum(dim=1).float()
+    return out
+
+
+def _simulate_mixed(tape: Sequence[Operation], n_qubits: int, type: str, obs, B: int):
+    """Noisy tape -> measurement, with rho evolved as a 2n-wire pure register
+    (``simulation.py:106-128`` ``simulate_mixed`` + ``:204-271`` ``measure_state``)."""
+    if n_qubits > MAX_DENSITY_QUBITS:
+        raise NotImplementedError(
+            f"density-matrix simulation supports at most {MAX_DENSITY_QUBITS} qubits "
+            f"(got {n_qubits})")
+    if type == "state":
+        raise ValueError(
+            "Measurement type 'state' is not defined for mixed (noisy) circuits. "
+            "Use 'density' instead."
+        )
+    torch = N.require_gpu()
+    rho_vec = _evolve_density(tape, n_qubits, B)
+    D = 1 << n_qubits
+    if type == "density":
+        return rho_vec.view(B, D, D)
+    if type == "probs":
+        return N.density_probs(rho_vec, n_qubits)
+    obs = list(obs)
+    if not obs:
+        return torch.empty((B, 0), dtype=torch.float32, device=rho_vec.device)
+    return _density_expval(rho_vec, n_qubits, obs)
 
 
 class LoweredTape:
@@ -147,8 +321,11 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
     if shots is not None:
         raise NotImplementedError("shot sampling is a later row (SURVEY.md 8-f rank 4)")
     torch = N.require_gpu()
-    low = LoweredTape(tape, n_qubits)
     B = int(batch) if batch is not None else _tape_batch(tape)
+    if any(isinstance(o, KrausChannel) for o in tape):
+        res = _simulate_mixed(tape, n_qubits, type, obs, B)
+        return res if as_tensor else res.cpu().numpy()
+    low = LoweredTape(tape, n_qubits)
     plan = get_plan(low)
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if type == "expval":

@@ -62,3 +62,20 @@ def copy_to_tape(fn: Callable[[], None], offset: int) -> None:
     with recording() as side:
         fn()
     shift_and_append(side, offset)
+
+
+@contextmanager
+def batch_context(batch: int) -> Iterator[None]:
+    """Batch size of the recording in progress (per thread).  Gates that draw per-sample
+    random numbers while being recorded (``UnitaryGates.GateError``) read it, because a
+    batch-constant angle carries no batch axis of its own."""
+    prev = getattr(_tls, "batch", 1)
+    _tls.batch = int(batch)
+    try:
+        yield
+    finally:
+        _tls.batch = prev
+
+
+def current_batch() -> int:
+    return getattr(_tls, "batch", 1)

@@ -70,3 +70,52 @@ def random_tape(n, n_gates, rng, three_q=True):
         params = tuple(float(x) for x in rng.uniform(0, 2 * np.pi, N_PARAMS.get(name, 0)))
         tape.append((name, wires, params))
     return tape
+
+
+def lowered_to_oracle(lowered, n_qubits, sample=0):
+    """Engine-level op tuples ``(name, wires, params, blob)`` (what ``LoweredTape`` consumes,
+    e.g. from ``simulation.doubled_tape``) -> oracle tape on the same register, for one
+    batch element."""
+    out = []
+    for low in lowered:
+        name, wires, params, blob = low.lower(n_qubits)
+        vals = [float(np.asarray(p, dtype=np.float64).reshape(-1)[sample]
+                      if np.ndim(p) else p) for p in params]
+        if name in ("MAT1", "MAT2", "MAT4"):
+            b = np.asarray(blob, dtype=np.float64).reshape(-1, 2)
+            d = 2 ** len(wires)
+            out.append(("Matrix", list(wires), ((b[:, 0] + 1j * b[:, 1]).reshape(d, d),)))
+        elif name == "DIAG_ALL":
+            out.append(("DiagU", list(range(n_qubits)),
+                        (np.exp(-1j * np.asarray(blob, dtype=np.float64) * vals[0]),)))
+        else:
+            out.append((name, list(wires), tuple(vals)))
+    return out
+
+
+def frontend_to_oracle(tape, sample=0):
+    """Front-end ``Operation`` objects (gates and noise channels) -> oracle tape entries."""
+    from qml_essentials_amd import operations as op
+
+    out = []
+    for o in tape:
+        if isinstance(o, op.Barrier):
+            continue
+        if isinstance(o, op.QubitChannel):
+            out.append(("QubitChannel", list(o.wires), (o.kraus_matrices(),)))
+        elif isinstance(o, op.KrausChannel):
+            out.append((type(o).__name__, list(o.wires),
+                        tuple(getattr(o, k) for k in o._param_names)))
+        elif isinstance(o, op.DiagonalQubitUnitary):
+            m = np.asarray(o.matrix)
+            m = m[sample] if m.ndim == 3 else m
+            out.append(("DiagU", list(o.wires), (np.diag(m),)))
+        else:
+            low = o.lower(max(o.wires) + 1)
+            name, _, params, blob = low
+            if name in ("MAT1", "MAT2", "MAT4"):
+                out.append(("Matrix", list(o.wires), (np.asarray(o.matrix),)))
+            else:
+                out.append((name, list(o.wires), tuple(
+                    float(p if np.ndim(p) == 0 else np.asarray(p)[sample]) for p in params)))
+    return out

@@ -166,8 +166,10 @@ def test_gates_router_and_validation():
         op.CX(wires=[1, 1])
     with pytest.raises(NotImplementedError):
         Gates.RX(0.1, wires=0, gate_mode="pulse")
-    with pytest.raises(NotImplementedError):
+    with recording() as t:
         Gates.RX(0.1, wires=0, noise_params={"BitFlip": 0.1})
+        Gates.NQubitDepolarizingChannel(0.1, wires=[0, 1])
+    assert [o.name for o in t] == ["RX", "BitFlip", "QubitChannel"]
     with pytest.raises(ValueError, match="Invalid execution type"):
         Model(2, 1, "Circuit_1").execution_type = "nope"
 

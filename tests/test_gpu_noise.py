@@ -1,0 +1,231 @@
+"""GPU parity tests of the density-matrix / noise row against the
+oracle's ``simulate_mixed`` (``oracle/noise.py``).  Mirrors the reference's
+``tests/test_jaqsi.py:587-696`` (TestNoise) and ``tests/test_ansaetze.py:60-176``.
+Tolerance: complex64 engine vs complex128 oracle -> 2e-6 absolute on O(1) quantities."""
+import numpy as np
+import pytest
+
+from oracle import dense as OD
+from oracle import noise as ON
+from qml_essentials_amd import jaqsi as js
+from qml_essentials_amd import operations as op
+from qml_essentials_amd.gates import Gates
+from qml_essentials_amd.model import Model
+from qml_essentials_amd.script import Script
+from qml_essentials_amd.tape import recording
+from qml_essentials_amd.unitary import UnitaryGates
+from qml_essentials_amd.utils import key
+
+from helpers import frontend_to_oracle
+from test_noise_cpu import CHANNELS, _noisy_tape, rx_rho
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-6
+
+
+def _replay_script(tape, n):
+    from qml_essentials_amd.tape import shift_and_append
+
+    return Script(f=lambda: shift_and_append(tape, 0), n_qubits=n)
+
+
+@pytest.mark.parametrize("cls,params", CHANNELS)
+def test_single_channel_density(cls, params):
+    theta = 0.8
+
+    def circuit(t):
+        op.RX(t, wires=0)
+        cls(*params, wires=0)
+
+    rho = Script(f=circuit).execute(type="density", args=(np.array(theta),))
+    want = ON.simulate_mixed([("RX", [0], (theta,)), (cls.__name__, [0], params)], 1)
+    assert rho.shape == (2, 2) and np.allclose(rho, want, atol=ATOL)
+
+
+def test_bitflip_closed_form_and_auto_route():
+    """test_jaqsi.py:664-675: probs on a noisy tape routes to the density path."""
+    def noisy():
+        op.H(wires=0)
+        op.BitFlip(0.1, wires=0)
+
+    script = Script(f=noisy)
+    probs = script.execute(type="probs")
+    assert probs.shape == (2,) and np.isclose(probs.sum(), 1.0, atol=1e-6)
+    with pytest.raises(ValueError, match="not defined for mixed"):
+        script.execute(type="state")
+
+    def rx_flip(t):
+        op.RX(t, wires=0)
+        op.BitFlip(0.15, wires=0)
+
+    rho = Script(f=rx_flip).execute(type="density", args=(np.array(0.8),))
+    r0 = rx_rho(0.8)
+    assert np.allclose(rho, 0.85 * r0 + 0.15 * ON.X @ r0 @ ON.X, atol=ATOL)
+
+
+def test_noisy_bell_density_is_valid():
+    """test_jaqsi.py:677-696."""
+    def noisy_bell():
+        op.H(wires=0)
+        op.CX(wires=[0, 1])
+        op.DepolarizingChannel(0.05, wires=0)
+        op.DepolarizingChannel(0.05, wires=1)
+
+    rho = Script(f=noisy_bell).execute(type="density")
+    assert rho.shape == (4, 4)
+    assert np.isclose(np.trace(rho), 1.0, atol=1e-6) and np.allclose(rho, rho.conj().T, atol=1e-6)
+    purity = np.real(np.trace(rho @ rho))
+    assert purity < 1 - 1e-3
+
+
+def test_random_noisy_tape_all_measurements():
+    rng = np.random.default_rng(11)
+    n = 3
+    tape = _noisy_tape(rng)
+    want = ON.simulate_mixed(frontend_to_oracle(tape), n)
+
+    script = _replay_script(tape, n)
+    rho = script.execute(type="density")
+    assert np.allclose(rho, want, atol=ATOL)
+    probs = script.execute(type="probs")
+    assert np.allclose(probs, np.real(np.diag(want)), atol=ATOL)
+    herm = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    herm = herm + herm.conj().T
+    obs = [op.PauliZ(wires=0, record=False), op.PauliZ(wires=2, record=False),
+           js.build_parity_observable([0, 2]), op.PauliX(wires=1, record=False),
+           op.Hermitian(herm, wires=[2, 0], record=False)]
+    dense = [OD.lift(np.asarray(o.matrix), o.wires, n) for o in obs]
+    got = script.execute(type="expval", obs=obs)
+    assert np.allclose(got, ON.measure_density(want, n, "expval", dense), atol=1e-5)
+    got_z = script.execute(type="expval", obs=obs[:2])
+    assert np.allclose(got_z, ON.measure_density(want, n, "expval", dense[:2]), atol=ATOL)
+
+
+def test_gate_level_noise_reference_cases():
+    """test_ansaetze.py:82-176 (BitFlip, PhaseFlip, Depolarizing, n-qubit depolarizing)."""
+    def rx_pi(noise_params=None):
+        Gates.RX(np.pi, wires=0, noise_params=noise_params)
+
+    z0 = [op.PauliZ(wires=0, record=False)]
+    s = Script(rx_pi, n_qubits=1)
+    assert np.isclose(s.execute(type="expval", obs=z0, args=({},)), -1, atol=1e-5)
+    assert np.isclose(s.execute(type="expval", obs=z0, args=({"BitFlip": 0.5},)), 0, atol=1e-5)
+    assert np.isclose(s.execute(type="expval", obs=z0, args=({"Depolarizing": 0.75},)), 0,
+                      atol=1e-5)
+
+    def had(noise_params=None):
+        Gates.H(wires=0, noise_params=noise_params)
+
+    x0 = [op.PauliX(wires=0, record=False)]
+    s = Script(had, n_qubits=1)
+    assert np.isclose(s.execute(type="expval", obs=x0, args=({},)), 1, atol=1e-5)
+    assert np.isclose(s.execute(type="expval", obs=x0, args=({"PhaseFlip": 0.5},)), 0, atol=1e-5)
+
+    def two(noise_params=None):
+        Gates.RX(np.pi, wires=0)
+        Gates.CRX(np.pi, wires=[0, 1], noise_params=noise_params)
+
+    z1 = [op.PauliZ(wires=1, record=False)]
+    s = Script(two, n_qubits=2)
+    assert np.isclose(s.execute(type="expval", obs=z1, args=({},)), -1, atol=1e-5)
+    # rho -> (1 - p) rho + p I/4: exactly -(1 - p); the reference asserts |.| < 0.1
+    assert np.isclose(s.execute(type="expval", obs=z1,
+                                args=({"MultiQubitDepolarizing": 15 / 16},)), -1 / 16, atol=1e-5)
+
+    def three(noise_params=None):
+        if noise_params is not None:
+            Gates.NQubitDepolarizingChannel(noise_params.get("MultiQubitDepolarizing", 0),
+                                            wires=[0, 1, 2])
+
+    par = [js.build_parity_observable([0, 1, 2])]
+    s = Script(three, n_qubits=3)
+    assert np.isclose(s.execute(type="expval", obs=par, args=({},)), 1, atol=1e-5)
+    assert np.isclose(s.execute(type="expval", obs=par,
+                                args=({"MultiQubitDepolarizing": 63 / 64},)), 1 / 64, atol=1e-5)
+
+
+def test_wide_channel_mid_circuit():
+    n = 4
+    with recording() as tape:
+        for q in range(n):
+            op.RY(0.3 + q, wires=q)
+        op.CX(wires=[0, 3])
+        UnitaryGates.NQubitDepolarizingChannel(0.3, [3, 0, 2])
+        op.CRX(0.7, wires=[2, 1])
+        UnitaryGates.NQubitDepolarizingChannel(0.2, [0, 1, 2, 3])
+        op.RX(0.4, wires=1)
+        op.AmplitudeDamping(0.1, wires=1)
+
+    rho = _replay_script(tape, n).execute(type="density")
+    want = ON.simulate_mixed(frontend_to_oracle(tape), n)
+    assert np.allclose(rho, want, atol=ATOL)
+
+
+NOISE = {"BitFlip": 0.01, "PhaseFlip": 0.015, "Depolarizing": 0.02,
+         "MultiQubitDepolarizing": 0.03, "StatePreparation": 0.04, "AmplitudeDamping": 0.05,
+         "PhaseDamping": 0.06, "Measurement": 0.07,
+         "ThermalRelaxation": {"t1": 2000.0, "t2": 1000.0, "t_factor": 1.0}}
+
+
+@pytest.mark.parametrize("ansatz,n", [("Hardware_Efficient", 3), ("Circuit_19", 4),
+                                      ("Strongly_Entangling", 3)])
+@pytest.mark.parametrize("execution_type", ["expval", "probs", "density"])
+def test_model_with_noise_batched(ansatz, n, execution_type):
+    model = Model(n_qubits=n, n_layers=2, circuit_type=ansatz, output_qubit=-1)
+    rng = np.random.default_rng(3)
+    inputs = rng.uniform(0, 2 * np.pi, size=(3, 1))
+    params = rng.uniform(0, 2 * np.pi, size=(2, *model.params.shape[1:]))
+    got = model(params=params, inputs=inputs, noise_params=dict(NOISE),
+                execution_type=execution_type)
+    # oracle: record the same noisy circuit sample by sample (inputs slowest)
+    k = 0
+    for i in range(3):
+        for p in range(2):
+            with recording() as tape:
+                model._variational(params[p], inputs[i], random_key=key(0),
+                                   noise_params=model.noise_params)
+            rho = ON.simulate_mixed(frontend_to_oracle(tape), n)
+            if execution_type == "density":
+                assert np.allclose(got[i, p], rho, atol=ATOL)
+            elif execution_type == "probs":
+                assert np.allclose(got[i, p].reshape(-1), np.real(np.diag(rho)), atol=ATOL)
+            else:
+                zs = [OD.lift(ON.Z, [q], n) for q in range(n)]
+                assert np.allclose(got[i, p], ON.measure_density(rho, n, "expval", zs),
+                                   atol=ATOL)
+            k += 1
+    assert k == 6
+
+
+def test_gate_error_stays_pure_and_is_per_sample():
+    """test_ansaetze.py:60-78 + unitary.py:233-246: GateError alone runs on the statevector
+    path; each batch element draws its own angles unless batch_gate_error is False."""
+    model = Model(n_qubits=3, n_layers=1, circuit_type="Circuit_19")
+    x = np.full((8, 1), 0.3)
+    clean = model(inputs=x)
+    assert np.allclose(clean, clean[0], atol=1e-6)
+    noisy = model(inputs=x, noise_params={"GateError": 0.5})
+    assert not model._requires_density()
+    assert noisy.shape == clean.shape and np.std(noisy, axis=0).max() > 1e-2
+    UnitaryGates.batch_gate_error = False
+    try:
+        shared = model(inputs=x, noise_params={"GateError": 0.5})
+        assert np.allclose(shared, shared[0], atol=1e-6)
+        assert not np.allclose(shared[0], clean[0], atol=1e-3)
+    finally:
+        UnitaryGates.batch_gate_error = True
+    # state can still be requested (pure path)
+    st = model(inputs=x, noise_params={"GateError": 0.5}, execution_type="state")
+    assert st.shape == (8, 8) and np.allclose(np.sum(np.abs(st) ** 2, axis=1), 1, atol=1e-5)
+    model.noise_params = None
+
+
+def test_golomb_encoding_with_noise():
+    with recording() as tape:
+        op.H(wires=0)
+        op.H(wires=1)
+        UnitaryGates.GolombEncoding(0.37, wires=[0, 1], noise_params={"PhaseFlip": 0.1})
+        op.CX(wires=[0, 1])
+
+    rho = _replay_script(tape, 2).execute(type="density")
+    assert np.allclose(rho, ON.simulate_mixed(frontend_to_oracle(tape), 2), atol=ATOL)
