@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 110 /* 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 120 /* 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -230,6 +230,29 @@ size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch);
  * by the call */
 int qmle_histogram(const float *d_values, int64_t count, int n_bins, float lo, float hi,
                    int32_t *d_counts, qmle_stream stream);
+
+/* Shot sampling (simulation.py:320-377 sample_shots): for every row of d_probs
+ * [batch][2^n] float32 draw `shots` basis states by inverse-CDF sampling (the algorithm of
+ * jax.random.choice(key, dim, (shots,), p=probs): r = total * u, first index with
+ * cumsum >= r) and histogram them.  u comes from Philox4x32-10 keyed by `seed`, counter =
+ * (shot pair, row_offset + row) -- results do not depend on how a batch is chunked or
+ * sharded.  d_counts int32 [batch][2^n] (zeroed by the call); d_est_probs (optional, may be
+ * NULL) float32 counts / shots.  Workspace: the fp64 CDF. */
+int qmle_sample_counts(const float *d_probs, int n_qubits, int batch, int shots, uint64_t seed,
+                       uint64_t row_offset, int32_t *d_counts, float *d_est_probs,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+size_t qmle_sample_workspace_bytes(int n_qubits, int batch);
+/* sum_i p[b][i] * diag(O_k lifted)[i] for n_obs observables (simulation.py:363-372, the
+ * computational-basis estimate Tr(O diag(p))).  HOST arrays: obs_wires = concatenated wire
+ * lists, obs_n_wires[k] wires each (first wire = most significant bit of the table index),
+ * obs_diag_off[k] = float offset of the 2^k-entry diagonal in the DEVICE array d_diag, or
+ * -1 for a Z (x) Z (x) .. parity.  d_out float32 [batch][n_obs]. */
+int qmle_probs_diag_expval(const float *d_probs, int n_qubits, int batch,
+                           const int32_t *obs_wires, const int32_t *obs_n_wires,
+                           const int32_t *obs_diag_off, const float *d_diag, int n_obs,
+                           float *d_out, void *d_workspace, size_t workspace_bytes,
+                           qmle_stream stream);
+size_t qmle_probs_diag_expval_workspace_bytes(int n_obs);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,12 @@ SYMBOLS = [
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
+    ("qmle_sample_counts", _I, [_VP, _I, _I, _I, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _SZ,
+                                _VP]),
+    ("qmle_sample_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_probs_diag_expval", _I, [_VP, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), _VP, _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_probs_diag_expval_workspace_bytes", _SZ, [_I]),
 ]
 
 
@@ -462,3 +468,63 @@ def histogram(values, n_bins: int, lo: float = 0.0, hi: float = 1.0):
                                C.c_float(lo), C.c_float(hi), C.c_void_p(counts.data_ptr()),
                                _stream_ptr()), "qmle_histogram")
     return counts
+
+
+def sample_counts(probs, shots: int, seed: int, row_offset: int = 0, want_probs: bool = True):
+    """``shots`` inverse-CDF draws per row of ``probs`` [B, 2^n] (float32, CUDA) ->
+    ``(counts int32 [B, 2^n], estimated probs float32 [B, 2^n] or None)``."""
+    torch = require_gpu()
+    if probs.dtype != torch.float32 or not probs.is_cuda or probs.dim() != 2:
+        raise ValueError("probs must be a float32 CUDA tensor [B, 2^n]")
+    probs = probs.contiguous()
+    B, D = int(probs.shape[0]), int(probs.shape[1])
+    n = D.bit_length() - 1
+    if (1 << n) != D:
+        raise ValueError(f"row length {D} is not a power of two")
+    counts = torch.empty((B, D), dtype=torch.int32, device=probs.device)
+    est = torch.empty((B, D), dtype=torch.float32, device=probs.device) if want_probs else None
+    for b0 in range(0, B, 65535):
+        bc = min(65535, B - b0)
+        ws = torch.empty(lib().qmle_sample_workspace_bytes(n, bc), dtype=torch.uint8,
+                         device=probs.device)
+        check(lib().qmle_sample_counts(
+            C.c_void_p(probs[b0:].data_ptr()), n, bc, int(shots),
+            C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(row_offset) + b0),
+            C.c_void_p(counts[b0:].data_ptr()),
+            C.c_void_p(est[b0:].data_ptr()) if est is not None else None,
+            C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _stream_ptr()),
+            "qmle_sample_counts")
+    return counts, est
+
+
+def probs_diag_expval(probs, obs: Sequence[Tuple[Sequence[int], Optional[Sequence[float]]]]):
+    """``sum_i p[b, i] * diag(O_k)[i]`` for observables given as ``(wires, diagonal)``;
+    ``diagonal=None`` means the Z-parity over ``wires``.  Returns float32 [B, n_obs]."""
+    torch = require_gpu()
+    probs = probs.contiguous()
+    B, D = int(probs.shape[0]), int(probs.shape[1])
+    n = D.bit_length() - 1
+    wires, counts, offs, table = [], [], [], []
+    for w, d in obs:
+        wires += list(w)
+        counts.append(len(w))
+        if d is None:
+            offs.append(-1)
+        else:
+            d = np.asarray(d, dtype=np.float32).reshape(-1)
+            if d.size != 2 ** len(w):
+                raise ValueError(f"diagonal has {d.size} entries for {len(w)} wire(s)")
+            offs.append(sum(t.size for t in table))
+            table.append(d)
+    d_table = (torch.from_numpy(np.concatenate(table)).to(probs.device) if table else None)
+    out = torch.empty((B, len(obs)), dtype=torch.float32, device=probs.device)
+    ws = torch.empty(max(1, lib().qmle_probs_diag_expval_workspace_bytes(len(obs))),
+                     dtype=torch.uint8, device=probs.device)
+    for b0 in range(0, B, 65535):
+        bc = min(65535, B - b0)
+        check(lib().qmle_probs_diag_expval(
+            C.c_void_p(probs[b0:].data_ptr()), n, bc, _i32(wires), _i32(counts), _i32(offs),
+            C.c_void_p(d_table.data_ptr()) if d_table is not None else None, len(obs),
+            C.c_void_p(out[b0:].data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
+            _stream_ptr()), "qmle_probs_diag_expval")
+    return out

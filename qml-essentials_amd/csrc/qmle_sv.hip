@@ -1083,6 +1083,150 @@ k_histogram(const float *__restrict__ values, int64_t count, int n_bins, float l
 }
 
 
+// ---- shot sampling (simulation.py:320-377) ------------------------------------------
+// Philox4x32-10 counter RNG: counter = (shot pair, 0, row lo, row hi), key = seed.
+struct Philox4 { uint32_t x[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                 uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {  // uniform in (0, 1)
+  return ((double)((((uint64_t)hi << 32) | lo) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// Inclusive fp64 prefix sum of one row of probabilities per block: cdf[b][i] = sum_{j<=i} p[b][j]
+__global__ void __launch_bounds__(256)
+k_cdf(const float *__restrict__ probs, uint64_t D, double *__restrict__ cdf) {
+  __shared__ double wsum[4];
+  __shared__ double carry_s;
+  const float *p = probs + (size_t)blockIdx.x * D;
+  double *c = cdf + (size_t)blockIdx.x * D;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0.0;
+  __syncthreads();
+  for (uint64_t base = 0; base < D; base += 1024) {
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < D) ? (double)p[i0 + k] : 0.0;
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    double incl = v[3];  // inclusive scan of the per-thread totals across the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    double before = carry_s + (incl - v[3]);
+    for (int j = 0; j < w; ++j) before += wsum[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i0 + k < D) c[i0 + k] = before + v[k];
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = before + v[3];
+    __syncthreads();
+  }
+}
+
+// First index with cdf[idx] >= r (numpy.searchsorted side="left").
+__device__ __forceinline__ uint32_t cdf_search(const double *__restrict__ c, uint64_t D,
+                                               double r) {
+  uint64_t lo = 0, hi = D - 1;  // answer in [lo, hi]; cdf[D-1] = total >= r
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (c[mid] >= r) hi = mid; else lo = mid + 1;
+  }
+  return (uint32_t)lo;
+}
+
+constexpr int kShotsPerThread = 16;                       // 8 Philox blocks
+constexpr int kShotsPerBlock = 256 * kShotsPerThread;     // 4096
+constexpr int kLdsHistMax = 4096;                         // bins kept in LDS (16 KiB)
+
+// counts[b][idx] += 1 for `shots` draws idx ~ probs[b]; grid (ceil(shots/4096), rows)
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256)
+k_sample(const double *__restrict__ cdf, uint64_t D, int shots, uint64_t seed,
+         uint64_t row_offset, int *__restrict__ counts) {
+  __shared__ int hist[LDS_HIST ? kLdsHistMax : 1];
+  const double *c = cdf + (size_t)blockIdx.y * D;
+  int *out = counts + (size_t)blockIdx.y * D;
+  if (LDS_HIST) {
+    for (uint32_t i = threadIdx.x; i < D; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  const double total = c[D - 1];
+  const uint64_t row = row_offset + blockIdx.y;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int64_t first = (int64_t)blockIdx.x * kShotsPerBlock;
+#pragma unroll 1
+  for (int j = 0; j < kShotsPerThread / 2; ++j) {
+    // shot pair index: consecutive threads take consecutive pairs
+    const int64_t pair = first / 2 + (int64_t)j * 256 + threadIdx.x;
+    if (2 * pair >= shots) break;
+    const Philox4 rnd = philox4x32_10((uint32_t)pair, (uint32_t)((uint64_t)pair >> 32),
+                                      (uint32_t)row, (uint32_t)(row >> 32), k0, k1);
+    const uint32_t a = cdf_search(c, D, total * u53(rnd.x[0], rnd.x[1]));
+    if (LDS_HIST) atomicAdd(&hist[a], 1); else atomicAdd(out + a, 1);
+    if (2 * pair + 1 < shots) {
+      const uint32_t b = cdf_search(c, D, total * u53(rnd.x[2], rnd.x[3]));
+      if (LDS_HIST) atomicAdd(&hist[b], 1); else atomicAdd(out + b, 1);
+    }
+  }
+  if (LDS_HIST) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < D; i += 256)
+      if (hist[i]) atomicAdd(out + i, hist[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_counts_to_probs(const int *__restrict__ counts, uint64_t total, float inv_shots,
+                  float *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    out[i] = (float)counts[i] * inv_shots;
+}
+
+// sum_i p[b][i] * d_k[sub_k(i)]: the diagonal of observable k lifted to the register
+// (simulation.py:363-372).  diag_off < 0: Z-parity over the wires (no table).
+struct DiagObs {
+  int8_t bits[QMLE_MAX_QUBITS];  // bit positions of the observable's wires, MSB first
+  int n_wires;
+  int diag_off;
+};
+__global__ void __launch_bounds__(256)
+k_probs_diag_expval(const float *__restrict__ probs, uint64_t D, const DiagObs *__restrict__ obs,
+                    const float *__restrict__ diag, int n_obs, float *__restrict__ out) {
+  __shared__ double red[16];
+  const DiagObs ob = obs[blockIdx.y];
+  const float *p = probs + (size_t)blockIdx.x * D;
+  double acc = 0.0;
+  for (uint64_t i = threadIdx.x; i < D; i += 256) {
+    uint32_t sub = 0;
+    for (int k = 0; k < ob.n_wires; ++k) sub = (sub << 1) | (uint32_t)((i >> ob.bits[k]) & 1);
+    const float d = ob.diag_off < 0 ? ((__popc(sub) & 1) ? -1.f : 1.f) : diag[ob.diag_off + sub];
+    acc += (double)(p[i] * d);
+  }
+  const double t = block_sum_d(acc, red);
+  if (threadIdx.x == 0) out[(size_t)blockIdx.x * n_obs + blockIdx.y] = (float)t;
+}
+
+
 // <a_i|b_i> for separate arrays a, b: partial[i][block] = (re, im)
 __global__ void __launch_bounds__(256)
 k_overlap2_partial(const float4 *__restrict__ a_all, const float4 *__restrict__ b_all, int n,
@@ -2232,6 +2376,81 @@ int qmle_histogram(const float *d_values, int64_t count, int n_bins, float lo, f
                        stream, d_values, count, n_bins, lo, hi, d_counts);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
+}
+
+size_t qmle_sample_workspace_bytes(int n_qubits, int batch) {
+  if (n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS || batch < 1) return 0;
+  return ((size_t)batch << n_qubits) * sizeof(double);
+}
+
+int qmle_sample_counts(const float *d_probs, int n_qubits, int batch, int shots, uint64_t seed,
+                       uint64_t row_offset, int32_t *d_counts, float *d_est_probs,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!d_probs || !d_counts || !d_workspace || n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS ||
+      batch < 1 || batch > 65535 || shots < 1)
+    return QMLE_ERR_INVALID_ARG;
+  if (workspace_bytes < qmle_sample_workspace_bytes(n_qubits, batch))
+    return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const uint64_t D = (uint64_t)1 << n_qubits;
+  double *cdf = (double *)d_workspace;
+  HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)batch * D * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(k_cdf, dim3(batch), dim3(256), 0, stream, d_probs, D, cdf);
+  const unsigned gx = (unsigned)(((int64_t)shots + kShotsPerBlock - 1) / kShotsPerBlock);
+  if (D <= (uint64_t)kLdsHistMax)
+    hipLaunchKernelGGL(k_sample<true>, dim3(gx, batch), dim3(256), 0, stream, cdf, D, shots,
+                       seed, row_offset, d_counts);
+  else
+    hipLaunchKernelGGL(k_sample<false>, dim3(gx, batch), dim3(256), 0, stream, cdf, D, shots,
+                       seed, row_offset, d_counts);
+  if (d_est_probs)
+    hipLaunchKernelGGL(k_counts_to_probs, dim3(grid_for((uint64_t)batch * D, 256, 4096)),
+                       dim3(256), 0, stream, d_counts, (uint64_t)batch * D, 1.0f / (float)shots,
+                       d_est_probs);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_probs_diag_expval(const float *d_probs, int n_qubits, int batch,
+                           const int32_t *obs_wires, const int32_t *obs_n_wires,
+                           const int32_t *obs_diag_off, const float *d_diag, int n_obs,
+                           float *d_out, void *d_workspace, size_t workspace_bytes,
+                           qmle_stream stream_) {
+  if (!d_probs || !d_out || !obs_wires || !obs_n_wires || !obs_diag_off || !d_workspace ||
+      n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS || batch < 1 || batch > 65535 || n_obs < 1 ||
+      n_obs > 65535)
+    return QMLE_ERR_INVALID_ARG;
+  if (workspace_bytes < (size_t)n_obs * sizeof(DiagObs)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<DiagObs> host(n_obs);
+  int w0 = 0;
+  for (int k = 0; k < n_obs; ++k) {
+    const int nw = obs_n_wires[k];
+    if (nw < 1 || nw > n_qubits) return QMLE_ERR_INVALID_ARG;
+    uint32_t seen = 0;
+    for (int j = 0; j < nw; ++j) {
+      const int w = obs_wires[w0 + j];
+      if (w < 0 || w >= n_qubits) return QMLE_ERR_WIRE_RANGE;
+      if (seen & (1u << w)) return QMLE_ERR_DUPLICATE_WIRES;
+      seen |= 1u << w;
+      host[k].bits[j] = (int8_t)(n_qubits - 1 - w);
+    }
+    host[k].n_wires = nw;
+    host[k].diag_off = obs_diag_off[k];
+    if (host[k].diag_off >= 0 && !d_diag) return QMLE_ERR_INVALID_ARG;
+    w0 += nw;
+  }
+  HIPCHK(hipMemcpyAsync(d_workspace, host.data(), (size_t)n_obs * sizeof(DiagObs),
+                        hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));  // `host` dies with this frame
+  hipLaunchKernelGGL(k_probs_diag_expval, dim3(batch, n_obs), dim3(256), 0, stream, d_probs,
+                     (uint64_t)1 << n_qubits, (const DiagObs *)d_workspace, d_diag, n_obs, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+size_t qmle_probs_diag_expval_workspace_bytes(int n_obs) {
+  return n_obs < 1 ? 0 : (size_t)n_obs * sizeof(DiagObs);
 }
 
 }  // extern "C"

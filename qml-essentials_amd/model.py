@@ -747,13 +747,14 @@ class Model:
         meas_type, obs = self._build_obs()
         B = int(np.prod(self.eff_batch_shape))
         kwargs = dict(noise_params=self.noise_params, gate_mode=self.gate_mode)
-        if self.shots is not None and meas_type in ("probs", "expval"):
-            raise NotImplementedError("shot sampling is a later row (SURVEY.md 8-f rank 4)")
+        shot_key = None
+        if self.shots is not None:  # model.py:1670-1675
+            sub_key, shot_key = safe_random_split(sub_key)
 
         # probs on a subset of wires: marginalise on the GPU (jaqsi.py:106-146) instead of
         # shipping B x 2^n probabilities to the host
         native_marginal = (meas_type == "probs" and not self.all_qubit_measurement
-                           and not as_tensor and self.n_qubits > 10)
+                           and not as_tensor and self.n_qubits > 10 and self.shots is None)
         if native_marginal:
             meas_type, as_tensor_call = "state", True
         else:
@@ -767,10 +768,12 @@ class Model:
             in_axes = (0 if self.batch_shape[1] > 1 else None,
                        0 if self.batch_shape[0] > 1 else None, None, None, None)
             result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
-                                         in_axes=in_axes, as_tensor=as_tensor_call)
+                                         in_axes=in_axes, as_tensor=as_tensor_call,
+                                         shots=self.shots, key=shot_key)
         else:
             result = self.script.execute(type=meas_type, obs=obs, args=args, kwargs=kwargs,
-                                         as_tensor=as_tensor_call)
+                                         as_tensor=as_tensor_call, shots=self.shots,
+                                         key=shot_key)
         if as_tensor:
             return result  # raw (B, ...) device tensor for the analysis loops
         if native_marginal:

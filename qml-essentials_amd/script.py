@@ -18,6 +18,7 @@ from . import distributed, memory, simulation
 from .batching import Batched, to_numpy
 from .operations import KrausChannel, Operation, z_parity_mask
 from .tape import batch_context, recording
+from .utils import PRNGKey
 
 
 class NotAffine(Exception):
@@ -138,6 +139,8 @@ class Script:
         """Execute the circuit; with ``in_axes`` the result has a leading batch axis."""
         obs = [] if obs is None else obs
         kwargs = {} if kwargs is None else kwargs
+        if shots is not None and key is None:
+            key = PRNGKey(0)  # script.py:189-190
         if in_axes is not None:
             return self._execute_batched(type, obs, args, kwargs, in_axes, shots, key, as_tensor)
         tape = self._record(*[to_numpy(a) for a in args], **kwargs)
@@ -173,7 +176,7 @@ class Script:
             n_qubits = self._n_qubits or simulation.infer_n_qubits(tape, obs)
             return simulation.simulate_and_measure(
                 tape, n_qubits, type, obs, simulation.uses_density(tape, type), shots=shots,
-                key=key, batch=end - start, as_tensor=as_tensor,
+                key=key, batch=end - start, as_tensor=as_tensor, row_offset=start,
             ), n_qubits, len(tape)
 
         # memory-aware chunking needs n_qubits / n_ops: probe with one sample's structure

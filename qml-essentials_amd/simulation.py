@@ -310,24 +310,58 @@ def _general_expval(states, n_qubits: int, obs: Sequence[Operation]):
     return out
 
 
+def sample_shots(probs, n_qubits: int, type: str, obs: Sequence[Operation], shots: int, key,
+                 row_offset: int = 0):
+    """Exact probabilities [B, 2^n] (device) -> shot estimates (``simulation.py:320-377``):
+    ``counts / shots`` or, per observable, ``diag(O) . counts / shots`` (exact for diagonal
+    observables, the computational-basis estimate otherwise).  Row ``b`` uses the Philox
+    stream ``(key, row_offset + b)`` -- the reference splits the key per batch element
+    (``script.py:480-482``)."""
+    if type not in ("probs", "expval"):
+        raise ValueError(
+            f"Shot simulation is only supported for 'probs' and 'expval', got {type!r}.")
+    from .utils import key_to_seed
+
+    _, est = N.sample_counts(probs, int(shots), key_to_seed(key), row_offset)
+    if type == "probs":
+        return est
+    torch = N.require_gpu()
+    obs = list(obs)
+    if not obs:
+        return torch.empty((probs.shape[0], 0), dtype=torch.float32, device=probs.device)
+    specs = []
+    for ob in obs:
+        if z_parity_mask(ob) is not None:
+            specs.append((ob.wires, None))
+        else:
+            specs.append((ob.wires, np.real(np.diag(np.asarray(ob.matrix)))))
+    return N.probs_diag_expval(est, specs)
+
+
 def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
                          obs: Sequence[Operation] = (), use_density: bool = False,
                          shots: Optional[int] = None, key=None, batch: Optional[int] = None,
-                         as_tensor: bool = False):
+                         as_tensor: bool = False, row_offset: int = 0):
     """Run the tape from |0..0> and measure.  Returns ``(B, ...)`` (numpy unless
-    ``as_tensor``); the caller strips the batch axis for un-batched execution."""
+    ``as_tensor``); the caller strips the batch axis for un-batched execution.  With
+    ``shots`` the exact probabilities are sampled on the device (``probs`` / ``expval``
+    only; other types stay exact, ``simulation.py:191-201``)."""
     if type not in MEAS_TYPES:
         raise ValueError(f"Unknown measurement type: {type!r}")
-    if shots is not None:
-        raise NotImplementedError("shot sampling is a later row (SURVEY.md 8-f rank 4)")
     torch = N.require_gpu()
     B = int(batch) if batch is not None else _tape_batch(tape)
+    sampled = shots is not None and type in ("probs", "expval")
     if any(isinstance(o, KrausChannel) for o in tape):
-        res = _simulate_mixed(tape, n_qubits, type, obs, B)
+        res = _simulate_mixed(tape, n_qubits, "probs" if sampled else type, obs, B)
+        if sampled:
+            res = sample_shots(res, n_qubits, type, obs, shots, key, row_offset)
         return res if as_tensor else res.cpu().numpy()
     low = LoweredTape(tape, n_qubits)
     plan = get_plan(low)
     angles = torch.from_numpy(low.angle_table(B)).cuda()
+    if sampled:
+        res = sample_shots(plan.run(angles, "probs"), n_qubits, type, obs, shots, key, row_offset)
+        return res if as_tensor else res.cpu().numpy()
     if type == "expval":
         obs = list(obs)
         masks = [z_parity_mask(o) for o in obs]

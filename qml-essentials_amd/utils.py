@@ -43,6 +43,12 @@ def as_key(k) -> Optional[PRNGKey]:
     raise TypeError(f"random_key must be an int seed or a PRNGKey, got {type(k)}")
 
 
+def key_to_seed(k) -> int:
+    """64-bit seed of a key (what the device sampler's Philox stream is keyed with)."""
+    lo, hi = as_key(k)._seq.generate_state(2, dtype=np.uint32)
+    return (int(hi) << 32) | int(lo)
+
+
 def safe_random_split(random_key: Optional[PRNGKey], *args, num: int = 2, **kwargs):
     """``split`` that tolerates ``None`` (``qml_essentials/utils.py:9-13``)."""
     if random_key is None:

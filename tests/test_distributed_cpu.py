@@ -54,9 +54,12 @@ def _worker(rank, size, port, q):
     # 2. Script-level sharding; the oracle stands in for the HIP engine on CPU
     calls = []
 
+    offsets = []
+
     def fake_engine(tape, n_qubits, type, obs, use_density, shots=None, key=None, batch=None,
-                    as_tensor=False):
+                    as_tensor=False, row_offset=0):
         calls.append(batch)
+        offsets.append(row_offset)
         out = []
         for b in range(batch):
             t = [(o.name, o.wires, tuple(float(p[b]) if np.ndim(p) else float(p) for p in o.parameters))
@@ -78,6 +81,8 @@ def _worker(rank, size, port, q):
     want = np.stack([OE.simulate_and_measure([("RX", [0], (float(t),)), ("CRX", [0, 1], (0.4,))], 2,
                                              "expval", [("PauliZ", [0]), ("PauliZ", [1])]) for t in th])
     ok = res.shape == (9, 2) and np.allclose(res, want, atol=1e-6) and calls == [hi2 - lo2 for lo2, hi2 in [distributed.shard_bounds(9)]]
+    # shot-sampling streams are keyed by the GLOBAL row: the shard passes its first row
+    ok = ok and offsets == [distributed.shard_bounds(9)[0]]
     q.put((rank, bool(ok), calls))
     distributed.barrier()
     torch.distributed.destroy_process_group()
