@@ -120,6 +120,7 @@ typedef enum qmle_meas {
 #define QMLE_PLAN_FORCE_GLOBAL 2u   /* never use the whole-state-in-LDS kernel        */
 #define QMLE_PLAN_FORCE_TILE 4u     /* never use the direct per-gate kernels          */
 #define QMLE_PLAN_NO_REGTILE 8u     /* one LDS sweep per gate inside a tile (debug/A-B) */
+#define QMLE_PLAN_PREFETCH 16u      /* experiment: double-buffered LDS-DMA tile kernel (slower) */
 /* bits 8..15: tile qubits T override (0 = auto); bits 16..23: low-bit count L override */
 #define QMLE_PLAN_TILE_BITS(t) (((unsigned)(t) & 0xffu) << 8)
 #define QMLE_PLAN_LOW_BITS(l) (((unsigned)(l) & 0xffu) << 16)

@@ -52,10 +52,12 @@ PLAN_NO_FUSION = 1
 PLAN_FORCE_GLOBAL = 2
 PLAN_FORCE_TILE = 4
 PLAN_NO_REGTILE = 8
+PLAN_PREFETCH = 16
 
 
-def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0):
-    f = 0
+def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0,
+               prefetch=False):
+    f = PLAN_PREFETCH if prefetch else 0
     if no_fusion:
         f |= PLAN_NO_FUSION
     if force_global:

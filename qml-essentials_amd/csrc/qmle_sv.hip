@@ -503,6 +503,187 @@ __device__ void lds_apply(float2 *__restrict__ s, int T, const LoweredOp op,
   }
 }
 
+// Workgroup barrier.  RAW: bare s_barrier behind an LDS-only wait -- no fence, so neither
+// outstanding global stores nor LDS-DMA prefetches in flight are drained (k_tile_pf);
+// the caller orders its LDS-DMA explicitly.
+template <bool RAW> __device__ __forceinline__ void tile_sync() {
+  if (RAW) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+// Global bit positions of the tile's high local bits: lut[h] for h = local index >> L.
+__device__ __forceinline__ void tile_build_lut(const TileArgs &a, uint32_t *lut) {
+  for (uint32_t h = threadIdx.x; h < (1u << (a.T - a.L)); h += blockDim.x) {
+    uint32_t v = 0;
+    for (int i = 0; i < a.T - a.L; ++i) v |= ((h >> i) & 1u) << a.tile_bits[a.L + i];
+    lut[h] = v;
+  }
+}
+
+// Op descriptors + sample b's 2x2 matrices -> LDS.
+__device__ __forceinline__ void tile_stage_slots(const TileArgs &a, OpSlot *slots, int b) {
+  const float *mrow0 = a.mats + (size_t)b * a.mat_floats;
+  for (int k = threadIdx.x; k < a.n_ops; k += blockDim.x) {
+    const LoweredOp o = a.ops[a.op_begin + k];
+    slots[k].op = o;
+    if (o.kind == LK_1Q) {
+      const float4 lo4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off);
+      const float4 hi4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off + 4);
+      *reinterpret_cast<float4 *>(slots[k].m) = lo4;
+      *reinterpret_cast<float4 *>(slots[k].m + 4) = hi4;
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t tile_base(const TileArgs &a, uint32_t tile) {
+  uint64_t base = 0;
+  for (int i = 0; i < a.n - a.T; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
+  return base;
+}
+
+// All gate groups of the stage on the tile in `s`; ends with a barrier.
+template <bool DENSE4, bool RAW>
+__device__ __forceinline__ void tile_compute(const TileArgs &a, float2 *s, const OpSlot *slots,
+                                             int b) {
+  const int T = a.T;
+  const float *mrow = a.mats + (size_t)b * a.mat_floats;
+  const float *ang = a.angles + (size_t)b * a.n_slots;
+  for (int gi = 0; gi < a.n_groups; ++gi) {
+    const OpGroup g = a.groups[gi];
+    if (g.kind == GK_REG4) {
+      if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin);
+      else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin);
+    } else if (DENSE4 && g.kind == GK_DENSE4) {
+      lds_apply_dense4(s, T, g, a.consts + a.ops[g.op_begin].mat_off);
+    } else {
+      lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
+    }
+    tile_sync<RAW>();
+  }
+}
+
+// Store / measure the finished tile.  n_tiles = tiles per state.
+template <bool RAW>
+__device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, const uint32_t *lut,
+                                              float *red, uint32_t tile, uint32_t n_tiles, int b,
+                                              uint64_t base) {
+  const int T = a.T, L = a.L;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t D = (size_t)1 << a.n;
+  const uint32_t half = 1u << (T - 1);
+  const uint32_t lowmask = (1u << L) - 1u;
+  float2 *st = a.states + (size_t)b * D;
+  if (a.meas == TM_STORE) {
+    if ((half % (8u * nt)) == 0) {
+      for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sw((j0 + u * nt) * 2u) >> 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t j = (j0 + u * nt) * 2u;
+          *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = v[u];
+        }
+      }
+    } else {
+      for (uint32_t jc = tid; jc < half; jc += nt) {
+        const uint32_t j = jc * 2u;
+        *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) =
+            reinterpret_cast<float4 *>(s)[sw(j) >> 1];
+      }
+    }
+  } else if (a.meas == TM_PROBS) {
+    float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
+    for (uint32_t jc = tid; jc < half; jc += nt) {
+      const uint32_t j = jc * 2u;
+      const uint64_t g = base | lut[j >> L] | (j & lowmask);
+      const float4 v = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
+      *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+    }
+  } else if (a.meas == TM_EXPVAL_PARTIAL) {
+    // element e = tid + it * nt: bits [0, tb) come from tid, the top bits from `it`
+    float *po = reinterpret_cast<float *>(a.out) +
+                ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
+    const uint32_t cnt = 1u << T;
+    if (cnt == 16u * nt) {
+      float tot = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const float pr = norm2(s[sw(tid + it * nt)]);
+        tot += pr;
+        h0 += (it & 1) ? -pr : pr;
+        h1 += (it & 2) ? -pr : pr;
+        h2 += (it & 4) ? -pr : pr;
+        h3 += (it & 8) ? -pr : pr;
+      }
+      // nt = 2^tb threads: tb thread-bit sums (unused ones are harmless), 4 iteration-bit
+      // sums, the total.  One multi-value block reduction = 2 barriers, then ONE coalesced
+      // store of the 33-float row (no global store may sit in front of a barrier).
+      float v[15];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = ((tid >> j) & 1) ? -tot : tot;
+      v[10] = h0; v[11] = h1; v[12] = h2; v[13] = h3; v[14] = tot;
+      const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const float r = wave_sum(v[k]);
+        if (lane == 0) red[w * 15 + k] = r;
+      }
+      tile_sync<RAW>();
+      float *row = red + 240;  // 33 floats
+      if (tid < 15) {
+        float r = 0.f;
+        for (int i = 0; i < nw; ++i) r += red[i * 15 + tid];
+        const int tb = T - 4;
+        if (tid < 10) { if (tid < tb) row[a.tile_bits[tid]] = r; }
+        else if (tid < 14) row[a.tile_bits[tb + tid - 10]] = r;
+        else {
+          row[QMLE_MAX_QUBITS] = r;
+          for (int i = 0; i < a.n - T; ++i) row[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
+        }
+      }
+      tile_sync<RAW>();
+      if (tid <= QMLE_MAX_QUBITS) po[tid] = (tid < a.n || tid == QMLE_MAX_QUBITS) ? row[tid] : 0.f;
+    } else {  // small tiles (forced geometries in tests): one reduction per local bit
+      float acc_t = 0.f;
+      for (int j = 0; j < T; ++j) {
+        float acc = 0.f;
+        for (uint32_t e = tid; e < cnt; e += nt) {
+          const float pr = norm2(s[sw(e)]);
+          acc += ((e >> j) & 1u) ? -pr : pr;
+          if (j == 0) acc_t += pr;
+        }
+        const float r = block_sum(acc, red);
+        if (tid == 0) po[a.tile_bits[j]] = r;
+      }
+      const float r = block_sum(acc_t, red);
+      if (tid == 0) {
+        po[QMLE_MAX_QUBITS] = r;
+        for (int i = 0; i < a.n - T; ++i) po[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
+      }
+    }
+  } else {  // TM_EXPVAL, T == n
+    float *eo = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_obs;
+    const uint32_t cnt = 1u << T;
+    for (int k = 0; k < a.n_obs; ++k) {
+      const int p = a.obs_bits[k];
+      float acc = 0.f;
+      for (uint32_t j = tid; j < cnt; j += nt) {
+        const float pr = norm2(s[sw(j)]);
+        acc += ((j >> p) & 1u) ? -pr : pr;
+      }
+      const float tot = block_sum(acc, red);
+      if (tid == 0) eo[k] = tot;
+    }
+  }
+}
+
+// One tile per workgroup: load -> gate groups -> store / measure.
 template <bool DENSE4>
 __global__ void k_tile(const TileArgs a) {
   extern __shared__ float4 smem4[];
@@ -517,26 +698,9 @@ __global__ void k_tile(const TileArgs a) {
   const uint32_t tile = blockIdx.x;
   const size_t D = (size_t)1 << a.n;
 
-  uint64_t base = 0;
-  for (int i = 0; i < a.n - T; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
-  for (uint32_t h = tid; h < (1u << (T - L)); h += nt) {
-    uint32_t v = 0;
-    for (int i = 0; i < T - L; ++i) v |= ((h >> i) & 1u) << a.tile_bits[L + i];
-    lut[h] = v;
-  }
-  if (a.slots_in_lds) {
-    const float *mrow0 = a.mats + (size_t)b * a.mat_floats;
-    for (int k = tid; k < a.n_ops; k += nt) {
-      const LoweredOp o = a.ops[a.op_begin + k];
-      slots[k].op = o;
-      if (o.kind == LK_1Q) {
-        const float4 lo4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off);
-        const float4 hi4 = *reinterpret_cast<const float4 *>(mrow0 + o.mat_off + 4);
-        *reinterpret_cast<float4 *>(slots[k].m) = lo4;
-        *reinterpret_cast<float4 *>(slots[k].m + 4) = hi4;
-      }
-    }
-  }
+  const uint64_t base = tile_base(a, tile);
+  tile_build_lut(a, lut);
+  if (a.slots_in_lds) tile_stage_slots(a, slots, b);
   __syncthreads();
 
   const uint32_t half = 1u << (T - 1);
@@ -571,123 +735,100 @@ __global__ void k_tile(const TileArgs a) {
   }
   __syncthreads();
 
-  const float *mrow = a.mats + (size_t)b * a.mat_floats;
-  const float *ang = a.angles + (size_t)b * a.n_slots;
-  for (int gi = 0; gi < a.n_groups; ++gi) {
-    const OpGroup g = a.groups[gi];
-    if (g.kind == GK_REG4) {
-      if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin);
-      else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin);
-    } else if (DENSE4 && g.kind == GK_DENSE4) {
-      lds_apply_dense4(s, T, g, a.consts + a.ops[g.op_begin].mat_off);
-    } else {
-      lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
-    }
-    __syncthreads();
-  }
+  tile_compute<DENSE4, false>(a, s, slots, b);
+  tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
+}
 
-  if (a.meas == TM_STORE) {
-    if ((half % (8u * nt)) == 0) {
-      for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
-        float4 v[8];
+// ---- prefetching tile kernel ------------------------------------------------------------
+// EXPERIMENT, opt-in (QMLE_PLAN_PREFETCH): in k_tile a workgroup's HBM traffic stops while it
+// runs its gate groups.  k_tile_pf gives every workgroup a contiguous run of tiles and TWO
+// tile buffers: while the gate groups run on one buffer the next tile streams into the other
+// by LDS-DMA (global_load_lds_dwordx4, no VGPRs), so loads are in flight all the time.
+// Bit-identical to k_tile (tests), but slower on MI355X: see launch_tile and DESIGN.md 9.
+//
+// The DMA is issued from inline asm: hipcc drains a builtin LDS-DMA with vmcnt(0) in front of
+// every ds_read (it cannot tell the buffers apart), which would serialise exactly what this
+// kernel overlaps.  Ordering is therefore explicit: each wave waits for its own DMAs with a
+// counted vmcnt, then a barrier publishes the tile (read a staged buffer only after the
+// barrier behind the wait); barriers are raw (tile_sync<true>) so that nothing drains the
+// prefetch or the previous tile's stores.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+  unsigned keep;  // lds_dst: wave-uniform LDS byte address; lane l lands at lds_dst + 16 l
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+constexpr int kPfDmaPerWave = 8;  // 2^T * 8 B / (waves * 1 KiB) for T = 12 / 13 at 2^(T-4) threads
+
+// Issue this wave's share of the tile's loads into the LDS buffer at byte address lds_base.
+// Granule (16 B) position p of the buffer holds amplitude pair g = p ^ ((p >> 4) & 15): the
+// sw() layout expressed on the SOURCE address, since the DMA destination is lane-linear.
+__device__ __forceinline__ void pf_issue_tile(const TileArgs &a, const float2 *st, uint64_t base,
+                                              const uint32_t *lut, uint32_t lds_base) {
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t lowmask = (1u << a.L) - 1u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sw((j0 + u * nt) * 2u) >> 1];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const uint32_t j = (j0 + u * nt) * 2u;
-          *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = v[u];
-        }
-      }
+  for (int j = 0; j < kPfDmaPerWave; ++j) {
+    const uint32_t q = (uint32_t)j * nw + w;          // 1 KiB block of the buffer
+    const uint32_t p = q * 64u + lane;
+    const uint32_t e = (p ^ ((p >> 4) & 15u)) << 1;   // local amplitude index (even)
+    glds16(st + (base | lut[e >> a.L] | (e & lowmask)), lds_base + q * 1024u);
+  }
+}
+
+template <bool DENSE4>
+__global__ void __launch_bounds__(512)
+k_tile_pf(const TileArgs a, uint32_t n_tiles, uint32_t total, uint32_t chunk) {
+  extern __shared__ float4 smem4[];
+  const int T = a.T, L = a.L;
+  float2 *buf0 = reinterpret_cast<float2 *>(smem4);
+  float2 *buf1 = buf0 + (1u << T);
+  uint32_t *lut = reinterpret_cast<uint32_t *>(buf1 + (1u << T));
+  const uint32_t lut_n = (1u << (T - L)) < 4u ? 4u : (1u << (T - L));
+  float *red = reinterpret_cast<float *>(lut + lut_n);
+  OpSlot *slots = reinterpret_cast<OpSlot *>(red + 288);
+  const size_t D = (size_t)1 << a.n;
+  const uint32_t first = blockIdx.x * chunk;
+  const uint32_t last = first + chunk < total ? first + chunk : total;
+  if (first >= last) return;  // whole workgroup leaves together
+  const uint32_t lds0 = (uint32_t)(uintptr_t)buf0;  // low 32 bits of an LDS pointer = byte address
+  const uint32_t buf_bytes = 8u << T;
+
+  tile_build_lut(a, lut);
+  __syncthreads();
+  int cur = 0, staged_b = -1;
+  {
+    const int b = (int)(first / n_tiles);
+    pf_issue_tile(a, a.states + (size_t)b * D, tile_base(a, first % n_tiles), lut, lds0);
+  }
+  for (uint32_t f = first; f < last; ++f) {
+    const int b = (int)(f / n_tiles);
+    const uint32_t tile = f % n_tiles;
+    const uint64_t base = tile_base(a, tile);
+    if (b != staged_b) {  // (every wave passed the previous iteration's closing barrier)
+      tile_stage_slots(a, slots, b);
+      staged_b = b;
+    }
+    if (f + 1 < last) {
+      const int bn = (int)((f + 1) / n_tiles);
+      pf_issue_tile(a, a.states + (size_t)bn * D, tile_base(a, (f + 1) % n_tiles), lut,
+                    lds0 + (uint32_t)(cur ^ 1) * buf_bytes);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // = kPfDmaPerWave: tile f has landed
     } else {
-      for (uint32_t jc = tid; jc < half; jc += nt) {
-        const uint32_t j = jc * 2u;
-        *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) =
-            reinterpret_cast<float4 *>(s)[sw(j) >> 1];
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else if (a.meas == TM_PROBS) {
-    float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
-    for (uint32_t jc = tid; jc < half; jc += nt) {
-      const uint32_t j = jc * 2u;
-      const uint64_t g = base | lut[j >> L] | (j & lowmask);
-      const float4 v = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
-      *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
-    }
-  } else if (a.meas == TM_EXPVAL_PARTIAL) {
-    // element e = tid + it * nt: bits [0, tb) come from tid, the top bits from `it`
-    float *po = reinterpret_cast<float *>(a.out) +
-                ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
-    const uint32_t cnt = 1u << T;
-    if (cnt == 16u * nt) {
-      float tot = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const float pr = norm2(s[sw(tid + it * nt)]);
-        tot += pr;
-        h0 += (it & 1) ? -pr : pr;
-        h1 += (it & 2) ? -pr : pr;
-        h2 += (it & 4) ? -pr : pr;
-        h3 += (it & 8) ? -pr : pr;
-      }
-      // 15 values per thread: 10 thread-bit sums (unused ones are harmless), 4 iteration-bit
-      // sums, the total.  One multi-value block reduction = 2 barriers, then ONE coalesced
-      // store of the 33-float row (no global store may sit in front of a barrier).
-      float v[15];
-#pragma unroll
-      for (int j = 0; j < 10; ++j) v[j] = ((tid >> j) & 1) ? -tot : tot;
-      v[10] = h0; v[11] = h1; v[12] = h2; v[13] = h3; v[14] = tot;
-      const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
-#pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        const float r = wave_sum(v[k]);
-        if (lane == 0) red[w * 15 + k] = r;
-      }
-      __syncthreads();
-      float *row = red + 240;  // 33 floats
-      if (tid < 15) {
-        float r = 0.f;
-        for (int i = 0; i < nw; ++i) r += red[i * 15 + tid];
-        const int tb = T - 4;
-        if (tid < 10) { if (tid < tb) row[a.tile_bits[tid]] = r; }
-        else if (tid < 14) row[a.tile_bits[tb + tid - 10]] = r;
-        else {
-          row[QMLE_MAX_QUBITS] = r;
-          for (int i = 0; i < a.n - T; ++i) row[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
-        }
-      }
-      __syncthreads();
-      if (tid <= QMLE_MAX_QUBITS) po[tid] = (tid < a.n || tid == QMLE_MAX_QUBITS) ? row[tid] : 0.f;
-    } else {  // small tiles (forced geometries in tests): one reduction per local bit
-      float acc_t = 0.f;
-      for (int j = 0; j < T; ++j) {
-        float acc = 0.f;
-        for (uint32_t e = tid; e < cnt; e += nt) {
-          const float pr = norm2(s[sw(e)]);
-          acc += ((e >> j) & 1u) ? -pr : pr;
-          if (j == 0) acc_t += pr;
-        }
-        const float r = block_sum(acc, red);
-        if (tid == 0) po[a.tile_bits[j]] = r;
-      }
-      const float r = block_sum(acc_t, red);
-      if (tid == 0) {
-        po[QMLE_MAX_QUBITS] = r;
-        for (int i = 0; i < a.n - T; ++i) po[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
-      }
-    }
-  } else {  // TM_EXPVAL, T == n
-    float *eo = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_obs;
-    const uint32_t cnt = 1u << T;
-    for (int k = 0; k < a.n_obs; ++k) {
-      const int p = a.obs_bits[k];
-      float acc = 0.f;
-      for (uint32_t j = tid; j < cnt; j += nt) {
-        const float pr = norm2(s[sw(j)]);
-        acc += ((j >> p) & 1u) ? -pr : pr;
-      }
-      const float tot = block_sum(acc, red);
-      if (tid == 0) eo[k] = tot;
-    }
+    tile_sync<true>();  // publishes tile f (and the slots)
+    float2 *s = cur ? buf1 : buf0;
+    tile_compute<DENSE4, true>(a, s, slots, b);
+    tile_epilogue<true>(a, s, lut, red, tile, n_tiles, b, base);
+    tile_sync<true>();  // buffer `cur` is free for the DMA of tile f + 2
+    cur ^= 1;
   }
 }
 
@@ -1617,9 +1758,53 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                             // common kernel keeps its register budget
   for (int g = st.grp_begin; g < st.grp_end; ++g) has_dense4 |= p->op_groups[g].kind == GK_DENSE4;
   const unsigned tiles = 1u << (p->n - st.T);
+  // Prefetching variant: tiles are loaded (not generated), the geometry is the standard one
+  // (2^(T-4) threads, 8 DMAs per wave) and every workgroup gets a run of >= 4 tiles.
+  const uint64_t total = (uint64_t)tiles * (uint64_t)batch;
+  const int threads = tile_threads(st.T);
+  const size_t lds_pf = lds + ((size_t)8 << st.T);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cu = v;
+    else
+      n_cu = 256;
+  }
+  const unsigned wg_per_cu = (unsigned)(160 * 1024 / lds_pf);
+  // Opt-in (plan flag or QMLE_PREFETCH=1): measured SLOWER than k_tile on MI355X (K2, n = 24:
+  // 354 vs 248 ms per 1024 states) -- two tile buffers leave room for 2 workgroups = 2 waves
+  // per SIMD, and the gate groups need >= 4 to hide their own LDS / VALU latencies.
+  static const bool pf_env_on = std::getenv("QMLE_PREFETCH") != nullptr;
+  const bool pf_ok = (pf_env_on || (p->flags & QMLE_PLAN_PREFETCH)) && !init_zero && meas != TM_EXPVAL && a.slots_in_lds && st.L >= 1 &&
+                     (st.T == 12 || st.T == 13) && threads == (1 << (st.T - 4)) &&
+                     wg_per_cu >= 1 && total < (1ull << 31) &&
+                     total >= 4ull * n_cu * wg_per_cu;
+  if (pf_ok) {
+    static bool pf_attr = false;
+    if (!pf_attr) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      pf_attr = true;
+    }
+    const unsigned wgs = (unsigned)n_cu * wg_per_cu;
+    const uint32_t chunk = (uint32_t)((total + wgs - 1) / wgs);
+    const unsigned gx = (unsigned)((total + chunk - 1) / chunk);
+    if (has_dense4)
+      hipLaunchKernelGGL(k_tile_pf<true>, dim3(gx), dim3(threads), lds_pf, stream, a, tiles,
+                         (uint32_t)total, chunk);
+    else
+      hipLaunchKernelGGL(k_tile_pf<false>, dim3(gx), dim3(threads), lds_pf, stream, a, tiles,
+                         (uint32_t)total, chunk);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
   dim3 grid(tiles, (unsigned)batch);
-  if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(tile_threads(st.T)), lds, stream, a);
-  else hipLaunchKernelGGL(k_tile<false>, grid, dim3(tile_threads(st.T)), lds, stream, a);
+  if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(threads), lds, stream, a);
+  else hipLaunchKernelGGL(k_tile<false>, grid, dim3(threads), lds, stream, a);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

@@ -246,3 +246,36 @@ def test_dense_4wire_operator_and_density_measurements():
     for k, w in enumerate([0, 3, 1]):
         sign = 1 - 2 * ((idx >> (nq - 1 - w)) & 1)
         assert np.abs(ez[:, k] - (pr * sign).sum(axis=1)).max() < 1e-5
+
+
+@pytest.mark.parametrize("n,B,tile_bits,low_bits", [(18, 40, 12, 4), (18, 33, 12, 7), (19, 17, 13, 5),
+                                                     (20, 9, 12, 1)])
+def test_prefetching_tile_kernel_matches_plain_tile_kernel(n, B, tile_bits, low_bits):
+    """k_tile_pf (opt-in double-buffered LDS-DMA variant, one run of tiles per workgroup) against k_tile on the
+    same plan geometry, bit for bit (same arithmetic in the same order), for every epilogue:
+    state store, fused all-qubit <Z> partials, probabilities; batch sizes that leave ragged
+    last chunks; and against the oracle for one sample."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(n * 7 + B)
+    tape = random_tape(n, 60, rng)
+    ops, angles, consts = tape_to_native(tape, n)
+    table = rng.uniform(0, 2 * np.pi, size=(B, len(angles))).astype(np.float32)
+    table[0] = angles
+    ang = torch.from_numpy(table).cuda()
+    res = {}
+    for name, pf in (("pf", True), ("plain", False)):
+        flags = N.plan_flags(force_global=True, force_tile=True, tile_bits=tile_bits,
+                             low_bits=low_bits, prefetch=pf)
+        plan = N.Plan(ops, n, len(angles), consts, flags)
+        res[name] = (plan.run(ang, "state").cpu().numpy(),
+                     plan.run(ang, "expval", list(range(n))).cpu().numpy(),
+                     plan.run(ang, "probs").cpu().numpy())
+        if name == "pf":
+            kinds = [s["kind"] for s in plan.describe()["stages"]]
+            assert kinds.count("tile") >= 2     # at least one pass loads its tiles
+    for got, want in zip(res["pf"], res["plain"]):
+        assert np.array_equal(got, want)
+    psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
+    assert np.allclose(res["pf"][0][0], psi, atol=2e-6)
+    assert np.allclose(res["pf"][2][0], np.abs(psi) ** 2, atol=1e-6)
