@@ -121,6 +121,8 @@ typedef enum qmle_meas {
 #define QMLE_PLAN_FORCE_TILE 4u     /* never use the direct per-gate kernels          */
 #define QMLE_PLAN_NO_REGTILE 8u     /* one LDS sweep per gate inside a tile (debug/A-B) */
 #define QMLE_PLAN_PREFETCH 16u      /* experiment: double-buffered LDS-DMA tile kernel (slower) */
+#define QMLE_PLAN_NO_ABSORB 32u     /* <Z>: simulate trailing CX / SWAP / diagonal gates instead of
+                                       folding them into the observables (A-B, tests)   */
 /* bits 8..15: tile qubits T override (0 = auto); bits 16..23: low-bit count L override */
 #define QMLE_PLAN_TILE_BITS(t) (((unsigned)(t) & 0xffu) << 8)
 #define QMLE_PLAN_LOW_BITS(l) (((unsigned)(l) & 0xffu) << 16)
@@ -136,6 +138,11 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
                      const float *consts, int n_consts, unsigned flags,
                      qmle_plan **out);
 int qmle_plan_destroy(qmle_plan *plan);
+/* The plan QMLE_MEAS_EXPVAL_Z actually executes: trailing gates that permute basis states
+ * linearly (CX, SWAP) or are diagonal are folded into the Z observables (Z_t -> Z_c Z_t),
+ * the remaining gates form this child plan (owned by `plan`; NULL if nothing was folded).
+ * For introspection / profiling only. */
+qmle_plan *qmle_plan_expval_child(qmle_plan *plan);
 /* JSON description of the compiled passes (for tests / DESIGN.md); returns the
  * number of bytes needed (excluding NUL); writes at most cap-1 bytes + NUL. */
 int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap);

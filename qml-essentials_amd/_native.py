@@ -53,11 +53,12 @@ PLAN_FORCE_GLOBAL = 2
 PLAN_FORCE_TILE = 4
 PLAN_NO_REGTILE = 8
 PLAN_PREFETCH = 16
+PLAN_NO_ABSORB = 32
 
 
 def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0,
-               prefetch=False):
-    f = PLAN_PREFETCH if prefetch else 0
+               prefetch=False, no_absorb=False):
+    f = (PLAN_PREFETCH if prefetch else 0) | (PLAN_NO_ABSORB if no_absorb else 0)
     if no_fusion:
         f |= PLAN_NO_FUSION
     if force_global:
@@ -87,6 +88,7 @@ SYMBOLS = [
     ("qmle_plan_create", _I, [C.POINTER(QmleOp), _I, _I, _I, C.POINTER(_F), _I, C.c_uint,
                                C.POINTER(_VP)]),
     ("qmle_plan_destroy", _I, [_VP]),
+    ("qmle_plan_expval_child", _VP, [_VP]),
     ("qmle_plan_describe", _I, [_VP, C.c_char_p, _SZ]),
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
@@ -216,9 +218,23 @@ class Plan:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and _lib is not None:
+        if h is not None and _lib is not None and getattr(self, "_owner", None) is None:
             _lib.qmle_plan_destroy(h)
             self._h = None
+
+    def expval_child(self) -> Optional["Plan"]:
+        """The plan ``run(..., "expval")`` executes when trailing CX / SWAP / diagonal gates were
+        folded into the Z observables (non-owning view; None if nothing was folded)."""
+        h = lib().qmle_plan_expval_child(self._h)
+        if not h:
+            return None
+        child = Plan.__new__(Plan)
+        child._h = C.c_void_p(h)
+        child._owner = self        # keeps the parent (and with it the handle) alive
+        child._consts = self._consts
+        child.n_qubits, child.n_slots, child.flags = self.n_qubits, self.n_slots, self.flags
+        child.n_ops = child.stats()["n_ops"]
+        return child
 
     def describe(self) -> dict:
         L = lib()

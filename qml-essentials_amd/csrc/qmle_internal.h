@@ -124,10 +124,22 @@ struct qmle_plan {
   double algo_bytes_per_state = 0;
   qmle::DevicePlan dev;
   qmle::StageProfile prof;
+  // <Z> measurements only: trailing gates that map basis states to basis states (CX, SWAP)
+  // or only add phases (diagonal gates) never touch a statevector -- they are folded into
+  // the observables (Z_t -> Z_c Z_t under CX[c,t]) and `expval_child` runs the rest.
+  qmle_plan *expval_child = nullptr;
+  std::vector<qmle_op> absorbed;        // the folded gates, tape order
+  double absorbed_algo_bytes = 0;       // their SURVEY 8-d bytes (credited to the last stage)
+  double extra_algo_last_stage = 0;     // child side of the same number
 };
 
 namespace qmle {
 int compile_plan(qmle_plan *p);  // qmle_plan.cpp
+// Split `ops` into the gates a <Z> measurement needs (`kept`) and the absorbable tail.
+void split_expval_tail(const std::vector<qmle_op> &ops, int n, std::vector<qmle_op> &kept,
+                       std::vector<qmle_op> &absorbed);
+// Z on `wire` pulled back through the absorbed gates: bit w set <=> Z_w in the parity.
+uint32_t pull_back_z(const std::vector<qmle_op> &absorbed, int wire);
 std::string describe_plan(const qmle_plan *p);
 double algo_bytes(const qmle_op &op, int n);
 constexpr int kLdsMaxQubits = 14;       // 2^14 * 8 B = 128 KiB <= 160 KiB LDS/CU

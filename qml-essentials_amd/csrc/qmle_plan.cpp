@@ -198,6 +198,55 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
   st.grp_end = (int)p->op_groups.size();
 }
 
+// ---- observable absorption ---------------------------------------------------------------
+// Going backwards through the tape, a gate is absorbed iff it is a basis permutation with a
+// LINEAR index map (CX, SWAP), a diagonal gate (phases drop out of |amplitude|^2) or the
+// identity, and no later gate that stays in the circuit touches one of its wires.
+static bool absorbable(uint16_t opcode) {
+  switch (opcode) {
+    case QMLE_OP_ID: case QMLE_OP_Z: case QMLE_OP_S: case QMLE_OP_RZ: case QMLE_OP_CZ:
+    case QMLE_OP_CRZ: case QMLE_OP_CPHASE: case QMLE_OP_RZZ: case QMLE_OP_DIAG_ALL:
+    case QMLE_OP_CX: case QMLE_OP_SWAP:
+      return true;
+    default:
+      return false;
+  }
+}
+
+void split_expval_tail(const std::vector<qmle_op> &ops, int n, std::vector<qmle_op> &kept,
+                       std::vector<qmle_op> &absorbed) {
+  kept.clear();
+  absorbed.clear();
+  std::vector<char> take(ops.size(), 0);
+  uint32_t blocked = 0;  // wires a kept later gate acts on
+  const uint32_t all = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  for (size_t k = ops.size(); k-- > 0;) {
+    const qmle_op &op = ops[k];
+    uint32_t wires = 0;
+    if (op.opcode == QMLE_OP_DIAG_ALL) wires = all;
+    else
+      for (int a = 0; a < 4 && op.wire[a] >= 0; ++a) wires |= 1u << op.wire[a];
+    if (absorbable(op.opcode) && !(wires & blocked)) take[k] = 1;
+    else blocked |= wires;
+    if (blocked == all) break;  // nothing earlier can be absorbed
+  }
+  for (size_t k = 0; k < ops.size(); ++k) (take[k] ? absorbed : kept).push_back(ops[k]);
+}
+
+uint32_t pull_back_z(const std::vector<qmle_op> &absorbed, int wire) {
+  uint32_t m = 1u << wire;
+  for (size_t k = absorbed.size(); k-- > 0;) {
+    const qmle_op &op = absorbed[k];
+    if (op.opcode == QMLE_OP_CX) {            // Z_t -> Z_c Z_t, Z_c -> Z_c
+      if (m & (1u << op.wire[1])) m ^= 1u << op.wire[0];
+    } else if (op.opcode == QMLE_OP_SWAP) {
+      const uint32_t a = (m >> op.wire[0]) & 1u, b = (m >> op.wire[1]) & 1u;
+      if (a != b) m ^= (1u << op.wire[0]) | (1u << op.wire[1]);
+    }
+  }
+  return m;
+}
+
 int compile_plan(qmle_plan *p) {
   const int n = p->n;
   if (n < 1 || n > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
@@ -525,7 +574,8 @@ std::string describe_plan(const qmle_plan *p) {
        << (st.kind == ST_DIRECT ? "direct" : st.kind == ST_TILE ? "tile" : "diag_all")
        << "\",\"n_lowered\":" << (st.op_end - st.op_begin) << ",\"T\":" << st.T
        << ",\"L\":" << st.L << ",\"lds_round_trips\":" << (st.grp_end - st.grp_begin)
-       << ",\"algo_bytes_per_state\":" << st.algo_bytes_per_state
+       << ",\"algo_bytes_per_state\":"
+       << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
     os << "],\"groups\":[";
@@ -539,7 +589,11 @@ std::string describe_plan(const qmle_plan *p) {
     for (size_t i = 0; i < st.src_ops.size(); ++i) os << (i ? "," : "") << st.src_ops[i];
     os << "]}";
   }
-  os << "]}";
+  os << "]";
+  if (p->expval_child)
+    os << ",\"absorbed_ops\":" << p->absorbed.size()
+       << ",\"expval_plan\":" << describe_plan(p->expval_child);
+  os << "}";
   return os.str();
 }
 

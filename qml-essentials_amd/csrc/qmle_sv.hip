@@ -240,6 +240,8 @@ enum TileMeas : int {
   TM_EXPVAL = 2,  // whole-state only: <Z> on obs bits
   TM_EXPVAL_PARTIAL = 3,  // last pass of a tiled state: per-tile signed sums for EVERY bit
                           // -> out[b][tile][33] (k_expval_final reduces); state not stored
+  TM_EXPVAL_MASKS = 4,    // same, for Z-parity observables (obs_mask): per-tile Walsh-Hadamard
+                          // transform of |psi|^2 -> out[b][tile][k < n_obs]
 };
 
 // LDS layout of a tile: amplitude e lives in slot sw(e).  XOR-ing bits 1..4 with bits
@@ -405,7 +407,7 @@ struct TileArgs {
   int init_zero, meas, n_obs;
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
-  int8_t obs_bits[QMLE_MAX_QUBITS];
+  uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
 };
 
 __device__ __forceinline__ void sort3(int &a, int &b, int &c) {
@@ -667,15 +669,85 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
         for (int i = 0; i < a.n - T; ++i) po[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
       }
     }
+  } else if (a.meas == TM_EXPVAL_MASKS) {
+    float *po = reinterpret_cast<float *>(a.out) +
+                ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
+    const uint32_t cnt = 1u << T;
+    if (cnt == 16u * nt && nt >= 64) {
+      // element e = tid + it * nt: lane = local bits 0..5, wave = bits 6..T-5, it = top 4 bits.
+      // Walsh-Hadamard transform of the tile's probabilities over the 4 iteration bits (in
+      // registers) and the 6 lane bits (cross-lane butterflies): afterwards lane l, register
+      // i of wave w holds sum_{lane', it} (-1)^{|lane' & l| + |it & i|} p(w, lane', it), i.e.
+      // EVERY parity over those 10 bits at once; the observables pick theirs.
+      float w[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) w[it] = norm2(s[sw(tid + it * nt)]);
+#pragma unroll
+      for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i & h) continue;
+          const float x = w[i], y = w[i | h];
+          w[i] = x + y;
+          w[i | h] = x - y;
+        }
+      }
+      const int lane = tid & (kWave - 1), wv = tid / kWave, nw = nt / kWave;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const bool hi = (lane >> j) & 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float o = __shfl_xor(w[i], 1 << j, kWave);
+          w[i] = hi ? o - w[i] : w[i] + o;
+        }
+      }
+      tile_sync<RAW>();  // all amplitudes have been read: the tile buffer becomes scratch
+      float *C = reinterpret_cast<float *>(s);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) C[(wv * 16 + i) * kWave + lane] = w[i];
+      tile_sync<RAW>();
+      if (tid < a.n_obs) {
+        const uint32_t m = a.obs_mask[tid];
+        uint32_t ml = 0, mw = 0, mi = 0, par = 0;
+        for (int j = 0; j < T; ++j) {
+          const uint32_t bitv = (m >> a.tile_bits[j]) & 1u;
+          if (j < 6) ml |= bitv << j;
+          else if (j < T - 4) mw |= bitv << (j - 6);
+          else mi |= bitv << (j - (T - 4));
+        }
+        for (int i = 0; i < a.n - T; ++i) par ^= ((m >> a.outer_bits[i]) & 1u) & ((tile >> i) & 1u);
+        float r = 0.f;
+        for (int v = 0; v < nw; ++v) {
+          const float c = C[(v * 16 + (int)mi) * kWave + (int)ml];
+          r += (__popc((uint32_t)v & mw) & 1) ? -c : c;
+        }
+        po[tid] = par ? -r : r;
+      }
+    } else {  // small tiles (forced geometries in tests): one reduction per observable
+      for (int k = 0; k < a.n_obs; ++k) {
+        const uint32_t m = a.obs_mask[k];
+        uint32_t mloc = 0, par = 0;
+        for (int j = 0; j < T; ++j) mloc |= ((m >> a.tile_bits[j]) & 1u) << j;
+        for (int i = 0; i < a.n - T; ++i) par ^= ((m >> a.outer_bits[i]) & 1u) & ((tile >> i) & 1u);
+        float acc = 0.f;
+        for (uint32_t e = tid; e < cnt; e += nt) {
+          const float pr = norm2(s[sw(e)]);
+          acc += (__popc(e & mloc) & 1) ? -pr : pr;
+        }
+        const float r = block_sum(acc, red);
+        if (tid == 0) po[k] = par ? -r : r;
+      }
+    }
   } else {  // TM_EXPVAL, T == n
     float *eo = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_obs;
     const uint32_t cnt = 1u << T;
     for (int k = 0; k < a.n_obs; ++k) {
-      const int p = a.obs_bits[k];
+      const uint32_t m = a.obs_mask[k];
       float acc = 0.f;
       for (uint32_t j = tid; j < cnt; j += nt) {
         const float pr = norm2(s[sw(j)]);
-        acc += ((j >> p) & 1u) ? -pr : pr;
+        acc += (__popc(j & m) & 1) ? -pr : pr;
       }
       const float tot = block_sum(acc, red);
       if (tid == 0) eo[k] = tot;
@@ -700,12 +772,35 @@ __global__ void k_tile(const TileArgs a) {
 
   const uint64_t base = tile_base(a, tile);
   tile_build_lut(a, lut);
-  if (a.slots_in_lds) tile_stage_slots(a, slots, b);
-  __syncthreads();
-
   const uint32_t half = 1u << (T - 1);
   const uint32_t lowmask = (1u << L) - 1u;
   float2 *st = a.states + (size_t)b * D;
+  if (a.init_zero && base != 0) {
+    // |0..0> lives in tile 0 alone and gates are linear: every other tile of the first pass
+    // stays exactly zero -- write the zeros (state / probabilities / partial sums), skip the gates
+    __syncthreads();
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.meas == TM_STORE) {
+      for (uint32_t jc = tid; jc < half; jc += nt) {
+        const uint32_t j = jc * 2u;
+        *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = z;
+      }
+    } else if (a.meas == TM_PROBS) {
+      float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
+      for (uint32_t jc = tid; jc < half; jc += nt) {
+        const uint32_t j = jc * 2u;
+        *reinterpret_cast<float2 *>(po + (base | lut[j >> L] | (j & lowmask))) = make_float2(0.f, 0.f);
+      }
+    } else {  // TM_EXPVAL_PARTIAL / TM_EXPVAL_MASKS rows (TM_EXPVAL has a single tile)
+      float *po = reinterpret_cast<float *>(a.out) +
+                  ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
+      if (tid <= QMLE_MAX_QUBITS) po[tid] = 0.f;
+    }
+    return;
+  }
+  if (a.slots_in_lds) tile_stage_slots(a, slots, b);
+  __syncthreads();
+
   if (a.init_zero) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t jc = tid; jc < half; jc += nt) reinterpret_cast<float4 *>(s)[jc] = z;
@@ -1720,7 +1815,7 @@ int tile_threads(int T) {  // one register-tile work item (16 amplitudes) per th
 
 int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
                 const float *angles, int batch, bool init_zero, int meas, void *out,
-                const int8_t *obs_bits, int n_obs, hipStream_t stream) {
+                const uint32_t *obs_masks, int n_obs, hipStream_t stream) {
   TileArgs a;
   std::memset(&a, 0, sizeof(a));
   a.states = states;
@@ -1742,7 +1837,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   a.n_obs = n_obs;
   std::memcpy(a.tile_bits, st.tile_bits, sizeof(a.tile_bits));
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
-  if (obs_bits) std::memcpy(a.obs_bits, obs_bits, (size_t)n_obs);
+  if (obs_masks) std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
   a.op_begin = st.op_begin;
   a.slots_in_lds = tile_lds_bytes(st.T, st.L, a.n_ops) <= 160 * 1024 ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
@@ -1879,7 +1974,7 @@ int expval_blocks(int n) {
   return (int)n_seg;
 }
 
-int run_expval(const float2 *states, int n, int batch, const int32_t *obs_wires, int n_obs,
+int run_expval(const float2 *states, int n, int batch, const int8_t *obs_bits, int n_obs,
                float *d_out, void *ws, size_t ws_bytes, hipStream_t stream) {
   if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
   const int nb = expval_blocks(n);
@@ -1887,8 +1982,8 @@ int run_expval(const float2 *states, int n, int batch, const int32_t *obs_wires,
   if (ws_bytes < need) return QMLE_ERR_WORKSPACE;
   ObsBits ob;
   for (int k = 0; k < n_obs; ++k) {
-    if (obs_wires[k] < 0 || obs_wires[k] >= n) return QMLE_ERR_WIRE_RANGE;
-    ob.bits[k] = (int8_t)(n - 1 - obs_wires[k]);
+    if (obs_bits[k] < 0 || obs_bits[k] >= n) return QMLE_ERR_WIRE_RANGE;
+    ob.bits[k] = obs_bits[k];
   }
   hipLaunchKernelGGL(k_expval_partial, dim3(nb, batch), dim3(kEzThreads), 0, stream,
                      reinterpret_cast<const float4 *>(states), n, (float *)ws);
@@ -1948,12 +2043,35 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
     delete p;
     return rc;
   }
+  // <Z> measurements run a second plan without the trailing gates that only relabel basis
+  // states or add phases (they are folded into the observables at run time)
+  if (!(flags & (QMLE_PLAN_NO_ABSORB | QMLE_PLAN_NO_FUSION))) {
+    std::vector<qmle_op> kept;
+    split_expval_tail(p->ops, p->n, kept, p->absorbed);
+    if (!p->absorbed.empty()) {
+      qmle_plan *c = new (std::nothrow) qmle_plan();
+      if (c) {
+        c->n = n_qubits;
+        c->n_slots = n_slots;
+        c->flags = flags | QMLE_PLAN_NO_ABSORB;
+        c->ops = kept;
+        c->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
+        for (const qmle_op &o : p->absorbed) p->absorbed_algo_bytes += algo_bytes(o, p->n);
+        c->extra_algo_last_stage = p->absorbed_algo_bytes;
+        if (compile_plan(c) == QMLE_OK) p->expval_child = c;
+        else delete c;
+      }
+    }
+    if (!p->expval_child) p->absorbed.clear();
+  }
   *out = p;
   return QMLE_OK;
 }
+qmle_plan *qmle_plan_expval_child(qmle_plan *plan) { return plan ? plan->expval_child : nullptr; }
 
 int qmle_plan_destroy(qmle_plan *plan) {
   if (!plan) return QMLE_OK;
+  if (plan->expval_child) (void)qmle_plan_destroy(plan->expval_child);
   if (plan->dev.blob) (void)hipFree(plan->dev.blob);
   delete plan;
   return QMLE_OK;
@@ -2007,8 +2125,10 @@ static int default_states_in_flight(const qmle_plan *p, int batch) {
   return (int)s;
 }
 
+static int overlap_blocks(int n);
 static size_t expval_partial_rows(const qmle_plan *p) {
   size_t rows = (size_t)expval_blocks(p->n);
+  if ((size_t)overlap_blocks(p->n) > rows) rows = (size_t)overlap_blocks(p->n);
   if (!p->stages.empty() && p->stages.back().kind == ST_TILE && !p->whole_state_lds) {
     const size_t tiles = (size_t)1 << (p->n - p->stages.back().T);
     if (tiles > rows) rows = tiles;
@@ -2023,10 +2143,8 @@ static size_t per_state_ws_bytes(const qmle_plan *p, int meas_type) {
   return b;
 }
 
-size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int n_obs,
-                            int states_in_flight) {
-  (void)n_obs;
-  if (!plan || batch < 1) return 0;
+static size_t workspace_bytes_one(const qmle_plan *plan, int batch, int meas_type,
+                                  int states_in_flight) {
   size_t total = ws_mats_bytes(plan, batch) + 512;  // + alignment slack
   const bool lds_direct_meas =
       plan->whole_state_lds && (meas_type == QMLE_MEAS_PROBS || meas_type == QMLE_MEAS_EXPVAL_Z);
@@ -2038,20 +2156,79 @@ size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int
   return total;
 }
 
+size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int n_obs,
+                            int states_in_flight) {
+  (void)n_obs;
+  if (!plan || batch < 1) return 0;
+  size_t total = workspace_bytes_one(plan, batch, meas_type, states_in_flight);
+  if (meas_type == QMLE_MEAS_EXPVAL_Z && plan->expval_child) {
+    const size_t c = workspace_bytes_one(plan->expval_child, batch, meas_type, states_in_flight);
+    if (c > total) total = c;
+  }
+  return total;
+}
+
+// Z-parity observables (bit-position masks) of resident states: the stand-alone kernels
+static int run_parity_pos(const float2 *states, int n, int batch, const uint32_t *pos_masks,
+                          int n_obs, float *d_out, void *ws, size_t ws_bytes,
+                          hipStream_t stream) {
+  const int nb = overlap_blocks(n);
+  if (ws_bytes < (size_t)batch * nb * 8 * sizeof(float)) return QMLE_ERR_WORKSPACE;
+  for (int o0 = 0; o0 < n_obs; o0 += 8) {
+    ParityMasks pm;
+    pm.count = n_obs - o0 < 8 ? n_obs - o0 : 8;
+    for (int k = 0; k < 8; ++k) pm.m[k] = k < pm.count ? pos_masks[o0 + k] : 0u;
+    hipLaunchKernelGGL(k_parity_partial, dim3(nb, batch), dim3(256), 0, stream,
+                       (const float4 *)states, n, pm, (float *)ws);
+    hipLaunchKernelGGL(k_parity_final, dim3(batch), dim3(nb >= 256 ? 256 : 64), 0, stream,
+                       (const float *)ws, nb, pm.count, n_obs, o0, d_out);
+  }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                           const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
+                           size_t workspace_bytes, hipStream_t stream);
+
 int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream_) {
   if (!plan || batch < 1 || !d_out || !d_workspace) return QMLE_ERR_INVALID_ARG;
   if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_DENSITY) return QMLE_ERR_MEAS_TYPE;
   if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
   const int n = plan->n;
-  int8_t obs_bits[QMLE_MAX_QUBITS];
+  uint32_t masks[QMLE_MAX_QUBITS];
+  qmle_plan *exec = plan;
   if (meas_type == QMLE_MEAS_EXPVAL_Z) {
     if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !obs_wires) return QMLE_ERR_INVALID_ARG;
+    if (plan->expval_child) exec = plan->expval_child;
     for (int k = 0; k < n_obs; ++k) {
       if (obs_wires[k] < 0 || obs_wires[k] >= n) return QMLE_ERR_WIRE_RANGE;
-      obs_bits[k] = (int8_t)(n - 1 - obs_wires[k]);
+      // Z on the wire, pulled back through the gates folded into the measurement
+      const uint32_t wm = exec == plan ? 1u << obs_wires[k] : pull_back_z(plan->absorbed, obs_wires[k]);
+      uint32_t pm = 0;
+      for (int w = 0; w < n; ++w)
+        if (wm & (1u << w)) pm |= 1u << (n - 1 - w);
+      masks[k] = pm;
+    }
+  }
+  return run_batch_masks(exec, d_angles, batch, meas_type, masks, n_obs, d_out, d_workspace,
+                         workspace_bytes, (hipStream_t)stream_);
+}
+
+// Simulate + measure; <Z> observables arrive as bit-position parity masks.
+static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                           const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+  const int n = plan->n;
+  bool single_bits = true;  // plain Z observables: the 33-sums epilogue serves them all
+  int8_t obs_bits[QMLE_MAX_QUBITS];
+  if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+    for (int k = 0; k < n_obs; ++k) {
+      const uint32_t m = obs_masks[k];
+      if (m == 0 || (m & (m - 1))) single_bits = false;
+      obs_bits[k] = (int8_t)(m ? __builtin_ctz(m) : 0);
     }
   }
   int rc = ensure_device_plan(plan);
@@ -2105,7 +2282,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
                            (float *)d_out + (size_t)b0 * D, nullptr, 0, stream);
         else
           rc = launch_tile(plan, st, nullptr, mats, ang, bc, true, TM_EXPVAL,
-                           (float *)d_out + (size_t)b0 * n_obs, obs_bits, n_obs, stream);
+                           (float *)d_out + (size_t)b0 * n_obs, obs_masks, n_obs, stream);
         if (rc != QMLE_OK) return rc;
       }
       return QMLE_OK;
@@ -2146,9 +2323,10 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
       ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE) {
         const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
-        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised,
-                         last_fused ? TM_EXPVAL_PARTIAL : TM_STORE, last_fused ? d_partial : nullptr,
-                         nullptr, 0, stream);
+        const int tm = !last_fused ? TM_STORE : single_bits ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
+        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
+                         last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
+                         last_fused ? n_obs : 0, stream);
         initialised = true;
       } else {
         if (!initialised) {
@@ -2178,14 +2356,17 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
                          reinterpret_cast<const float4 *>(stc),
                          reinterpret_cast<float2 *>((float *)d_out + (size_t)b0 * D), tc);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
-      ObsBits ob;
-      for (int k = 0; k < n_obs; ++k) ob.bits[k] = obs_bits[k];
+      ObsBits ob;  // column of the 33-float row: the bit's sum, or (masks) the observable's own
+      for (int k = 0; k < n_obs; ++k) ob.bits[k] = single_bits ? obs_bits[k] : (int8_t)k;
       const int tiles = 1 << (n - plan->stages.back().T);
       hipLaunchKernelGGL(k_expval_final, dim3(bc, n_obs), dim3(256), 0, stream, (const float *)d_partial,
                          tiles, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {
-      rc = run_expval(stc, n, bc, obs_wires, n_obs, (float *)d_out + (size_t)b0 * n_obs, d_partial,
-                      partial_bytes, stream);
+      rc = single_bits
+               ? run_expval(stc, n, bc, obs_bits, n_obs, (float *)d_out + (size_t)b0 * n_obs,
+                            d_partial, partial_bytes, stream)
+               : run_parity_pos(stc, n, bc, obs_masks, n_obs, (float *)d_out + (size_t)b0 * n_obs,
+                                d_partial, partial_bytes, stream);
       if (rc != QMLE_OK) return rc;
     } else if (meas_type == QMLE_MEAS_DENSITY) {
       if (n > 15) return QMLE_ERR_UNSUPPORTED;
@@ -2313,7 +2494,13 @@ int qmle_expval_z(const void *d_states, int n_qubits, int batch, const int32_t *
   if (!d_states || !d_out || !d_workspace || !obs_wires || n_qubits < 1 ||
       n_qubits > QMLE_MAX_QUBITS || batch < 1 || batch > 65535)
     return QMLE_ERR_INVALID_ARG;
-  return run_expval((const float2 *)d_states, n_qubits, batch, obs_wires, n_obs, d_out,
+  if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
+  int8_t bits[QMLE_MAX_QUBITS];
+  for (int k = 0; k < n_obs; ++k) {
+    if (obs_wires[k] < 0 || obs_wires[k] >= n_qubits) return QMLE_ERR_WIRE_RANGE;
+    bits[k] = (int8_t)(n_qubits - 1 - obs_wires[k]);
+  }
+  return run_expval((const float2 *)d_states, n_qubits, batch, bits, n_obs, d_out,
                     d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 

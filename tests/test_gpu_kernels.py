@@ -279,3 +279,58 @@ def test_prefetching_tile_kernel_matches_plain_tile_kernel(n, B, tile_bits, low_
     psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
     assert np.allclose(res["pf"][0][0], psi, atol=2e-6)
     assert np.allclose(res["pf"][2][0], np.abs(psi) ** 2, atol=1e-6)
+
+
+def _tail_tape(n, rng, n_head, n_tail):
+    """Random circuit followed by a tail of CX / SWAP / diagonal gates on random wires."""
+    tape = random_tape(n, n_head, rng)
+    for _ in range(n_tail):
+        kind = rng.choice(["CX", "CX", "CX", "SWAP", "RZ", "CZ", "CRZ", "CPhase", "RZZ", "PauliZ", "S"])
+        if kind in ("RZ", "PauliZ", "S"):
+            w = [int(rng.integers(n))]
+        else:
+            w = [int(x) for x in rng.choice(n, size=2, replace=False)]
+        tape.append((kind, w, (float(rng.uniform(0, 6.28)),) if kind in ("RZ", "CRZ", "CPhase", "RZZ") else ()))
+    return tape
+
+
+@pytest.mark.parametrize("n,flags_kw", [(5, {}), (10, {}), (14, {}), (16, {}), (18, {}),
+                                        (18, dict(force_global=True, tile_bits=13, low_bits=5)),
+                                        (9, dict(force_global=True, tile_bits=6, low_bits=3)),
+                                        (20, {})])
+def test_trailing_permutation_gates_fold_into_z_observables(n, flags_kw):
+    """<Z> with the trailing CX / SWAP / diagonal gates folded into parity observables
+    (Z_t -> Z_c Z_t) == the same plan simulating them (QMLE_PLAN_NO_ABSORB) == the oracle.
+    Covers the whole-state kernel (n <= 14), the Walsh-Hadamard tile epilogue and the
+    stand-alone parity kernels (tail-only circuits)."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(n)
+    for n_head, n_tail in ((40, 12), (25, 40), (0, 15), (30, 0)):
+        tape = _tail_tape(n, rng, n_head, n_tail)
+        ops, angles, consts = tape_to_native(tape, n)
+        B = 3
+        table = rng.uniform(0, 2 * np.pi, size=(B, max(1, len(angles)))).astype(np.float32)
+        if len(angles):
+            table[0, :len(angles)] = angles
+        ang = torch.from_numpy(table[:, :len(angles)] if len(angles) else table[:, :0]).cuda()
+        obs = [int(w) for w in rng.permutation(n)[: max(1, n - 2)]]
+        plan = N.Plan(ops, n, len(angles), consts, N.plan_flags(**flags_kw))
+        ref = N.Plan(ops, n, len(angles), consts, N.plan_flags(no_absorb=True, **flags_kw))
+        got = plan.run(ang, "expval", obs).cpu().numpy()
+        want = ref.run(ang, "expval", obs).cpu().numpy()
+        assert np.allclose(got, want, atol=2e-6), (n_head, n_tail, np.abs(got - want).max())
+        d = plan.describe()
+        if n_tail >= 12:
+            assert d.get("absorbed_ops", 0) >= 1 and plan.expval_child() is not None
+            assert plan.expval_child().stats()["n_ops"] + d["absorbed_ops"] == len(ops)
+        if n_tail == 0 and n_head:
+            pass  # (random heads may end in an absorbable gate by chance)
+        if n <= 14:  # oracle for one sample
+            want0 = OE.simulate_and_measure(oracle_tape(tape, n), n, "expval",
+                                            [("PauliZ", [w]) for w in obs], dtype=np.complex128)
+            assert np.allclose(got[0], want0, atol=2e-6)
+        # other measurement types are untouched by the folding
+        if n <= 16:
+            assert np.array_equal(plan.run(ang, "probs").cpu().numpy(),
+                                  ref.run(ang, "probs").cpu().numpy())

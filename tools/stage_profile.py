@@ -10,17 +10,18 @@ def run(n, B, flags, label, reps=3):
     ops, slots = he_layer_ops(n)
     rng = np.random.default_rng(1000)
     ang = torch.from_numpy(rng.uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
-    plan = N.Plan(ops, n, slots, flags=flags)
+    top = N.Plan(ops, n, slots, flags=flags)
+    plan = top.expval_child() or top     # what "expval" executes (trailing CX folded away)
     d = plan.describe()
-    ws = torch.empty(plan.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(top.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
     obs = list(range(n))
-    plan.run(ang, "expval", obs, workspace=ws)
+    top.run(ang, "expval", obs, workspace=ws)
     torch.cuda.synchronize()
     plan.profile_begin(len(d["stages"]) * B * reps + 8)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        plan.run(ang, "expval", obs, workspace=ws)
+        top.run(ang, "expval", obs, workspace=ws)
     e1.record(); torch.cuda.synchronize()
     ms, cnt, _ = plan.profile_end()
     tot = e0.elapsed_time(e1) / reps / B
@@ -31,5 +32,6 @@ def run(n, B, flags, label, reps=3):
 if __name__ == "__main__":
     F = N.plan_flags
     run(24, 32, 0, "auto n24")
+    run(24, 32, F(no_absorb=True), "auto n24, no folding")
     for T, L in ((11, 4), (11, 3), (10, 3), (12, 3), (12, 4), (13, 5)):
         run(24, 32, F(tile_bits=T, low_bits=L), f"T{T} L{L}")
