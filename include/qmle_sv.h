@@ -160,6 +160,13 @@ size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type,
 int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream);
+/* Same, for Z (x) Z (x) .. parity observables (jaqsi.py:149-167; Model with tuple
+ * output_qubit, model.py:980-990): wire_masks[k] (HOST) has bit w set iff wire w takes part.
+ * Measured like QMLE_MEAS_EXPVAL_Z -- out of the last pass, no stored state; d_out
+ * float32 [batch][n_obs]; workspace as for QMLE_MEAS_EXPVAL_Z. */
+int qmle_run_batch_parity(qmle_plan *plan, const float *d_angles, int batch,
+                          const uint32_t *wire_masks, int n_obs, float *d_out, void *d_workspace,
+                          size_t workspace_bytes, qmle_stream stream);
 
 /* Angle table from DEVICE-resident arguments: out[b][s] = const[s] + sum_t coef[t] *
  * leaf_{arg[t]}[row_k(b)][idx[t]], terms of slot s = [ptr[s], ptr[s+1]); row_k(b) =

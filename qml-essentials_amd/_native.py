@@ -93,6 +93,7 @@ SYMBOLS = [
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_run_batch_parity", _I, [_VP, _VP, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_build_angles", _I, [C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32), _I, _VP, _VP, _VP, _VP, _VP, _I, C.c_int64,
                                C.c_int64, _VP, _VP]),
@@ -299,6 +300,36 @@ class Plan:
             C.c_size_t(workspace.numel()), _stream_ptr(),
         )
         check(rc, "qmle_run_batch")
+        return out
+
+    def run_parity(self, angles, wire_groups: Sequence[Sequence[int]], workspace=None,
+                   states_in_flight: int = 0):
+        """<Z..Z> over every wire group, measured out of the last pass (no stored state).
+        Returns float32 [B, len(wire_groups)]."""
+        torch = require_gpu()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if angles is None:
+            angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float32, device=dev)
+        angles = angles.to(device=dev, dtype=torch.float32).contiguous()
+        if angles.dim() != 2 or (self.n_slots and angles.shape[1] != self.n_slots):
+            raise ValueError(f"angles must be [B, {self.n_slots}], got {tuple(angles.shape)}")
+        B, n_obs = int(angles.shape[0]), len(wire_groups)
+        masks = (C.c_uint32 * max(1, n_obs))()
+        for k, grp in enumerate(wire_groups):
+            m = 0
+            for w in grp:
+                if not 0 <= int(w) < self.n_qubits:
+                    raise ValueError(f"wire {w} out of range for {self.n_qubits} qubits")
+                m |= 1 << int(w)
+            masks[k] = m
+        out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
+        need = self.workspace_bytes(B, "expval", n_obs, states_in_flight)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        check(lib().qmle_run_batch_parity(
+            self._h, C.c_void_p(angles.data_ptr()), B, masks, n_obs, C.c_void_p(out.data_ptr()),
+            C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream_ptr()),
+            "qmle_run_batch_parity")
         return out
 
 

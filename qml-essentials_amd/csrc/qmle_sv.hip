@@ -2191,30 +2191,60 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
                            const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
                            size_t workspace_bytes, hipStream_t stream);
 
+// <Z..Z> on wire masks (bit w = wire w), pulled back through the folded tail -> position masks
+static int build_obs_masks(qmle_plan *plan, qmle_plan **exec, const uint32_t *wire_masks, int n_obs,
+                           uint32_t *masks) {
+  const int n = plan->n;
+  *exec = plan->expval_child ? plan->expval_child : plan;
+  for (int k = 0; k < n_obs; ++k) {
+    const uint32_t in = wire_masks[k];
+    if (in == 0 || (n < 32 && (in >> n))) return QMLE_ERR_WIRE_RANGE;
+    uint32_t wm = 0;  // a product of Z's pulls back to the XOR of the factors' pull-backs
+    for (int w = 0; w < n; ++w)
+      if (in & (1u << w)) wm ^= *exec == plan ? 1u << w : pull_back_z(plan->absorbed, w);
+    uint32_t pm = 0;
+    for (int w = 0; w < n; ++w)
+      if (wm & (1u << w)) pm |= 1u << (n - 1 - w);
+    masks[k] = pm;  // (never 0: the pull-back is an invertible linear map)
+  }
+  return QMLE_OK;
+}
+
 int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream_) {
   if (!plan || batch < 1 || !d_out || !d_workspace) return QMLE_ERR_INVALID_ARG;
   if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_DENSITY) return QMLE_ERR_MEAS_TYPE;
   if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
-  const int n = plan->n;
   uint32_t masks[QMLE_MAX_QUBITS];
   qmle_plan *exec = plan;
   if (meas_type == QMLE_MEAS_EXPVAL_Z) {
     if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !obs_wires) return QMLE_ERR_INVALID_ARG;
-    if (plan->expval_child) exec = plan->expval_child;
+    uint32_t wm[QMLE_MAX_QUBITS];
     for (int k = 0; k < n_obs; ++k) {
-      if (obs_wires[k] < 0 || obs_wires[k] >= n) return QMLE_ERR_WIRE_RANGE;
-      // Z on the wire, pulled back through the gates folded into the measurement
-      const uint32_t wm = exec == plan ? 1u << obs_wires[k] : pull_back_z(plan->absorbed, obs_wires[k]);
-      uint32_t pm = 0;
-      for (int w = 0; w < n; ++w)
-        if (wm & (1u << w)) pm |= 1u << (n - 1 - w);
-      masks[k] = pm;
+      if (obs_wires[k] < 0 || obs_wires[k] >= plan->n) return QMLE_ERR_WIRE_RANGE;
+      wm[k] = 1u << obs_wires[k];
     }
+    const int rc = build_obs_masks(plan, &exec, wm, n_obs, masks);
+    if (rc != QMLE_OK) return rc;
   }
   return run_batch_masks(exec, d_angles, batch, meas_type, masks, n_obs, d_out, d_workspace,
                          workspace_bytes, (hipStream_t)stream_);
+}
+
+int qmle_run_batch_parity(qmle_plan *plan, const float *d_angles, int batch,
+                          const uint32_t *wire_masks, int n_obs, float *d_out, void *d_workspace,
+                          size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || !d_out || !d_workspace || !wire_masks || n_obs < 1 ||
+      n_obs > QMLE_MAX_QUBITS)
+    return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  uint32_t masks[QMLE_MAX_QUBITS];
+  qmle_plan *exec = plan;
+  const int rc = build_obs_masks(plan, &exec, wire_masks, n_obs, masks);
+  if (rc != QMLE_OK) return rc;
+  return run_batch_masks(exec, d_angles, batch, QMLE_MEAS_EXPVAL_Z, masks, n_obs, d_out,
+                         d_workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 // Simulate + measure; <Z> observables arrive as bit-position parity masks.

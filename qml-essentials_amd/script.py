@@ -98,6 +98,8 @@ class CompiledCall:
         if self.type == "expval":
             if self.obs and all(m is not None and len(m) == 1 for m in masks):
                 return self.plan.run(angles, "expval", [m[0] for m in masks])
+            if self.obs and all(m is not None for m in masks) and len(masks) <= 32:
+                return self.plan.run_parity(angles, masks)
             return simulation._general_expval(self.plan.run(angles, "state"), self.n_qubits, self.obs)
         return self.plan.run(angles, self.type)
 

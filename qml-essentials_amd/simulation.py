@@ -369,6 +369,8 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
             res = plan.run(angles, "expval", [m[0] for m in masks])
         elif not obs:
             res = torch.empty((B, 0), dtype=torch.float32, device=angles.device)
+        elif all(m is not None for m in masks) and len(obs) <= 32:
+            res = plan.run_parity(angles, masks)  # Z (x) Z ..: out of the last pass as well
         else:
             res = _general_expval(plan.run(angles, "state"), n_qubits, obs)
     else:
@@ -384,15 +386,18 @@ def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], 
     torch = N.require_gpu()
     masks = [z_parity_mask(o) for o in obs]
     single_z = bool(obs) and all(m is not None and len(m) == 1 for m in masks)
+    parity = bool(obs) and all(m is not None for m in masks) and len(obs) <= 32
     out = []
     from . import memory
     chunk = memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]),
-                                      "expval" if single_z else "state", False, len(obs),
+                                      "expval" if (single_z or parity) else "state", False, len(obs),
                                       n_ops=plan.n_ops)
     for r0 in range(0, table.shape[0], chunk):
         ang = torch.from_numpy(np.ascontiguousarray(table[r0:r0 + chunk])).cuda()
         if single_z:
             res = plan.run(ang, "expval", [m[0] for m in masks])
+        elif parity:
+            res = plan.run_parity(ang, masks)
         else:
             res = _general_expval(plan.run(ang, "state"), n_qubits, list(obs))
         out.append(res.cpu().numpy())

@@ -334,3 +334,31 @@ def test_trailing_permutation_gates_fold_into_z_observables(n, flags_kw):
         if n <= 16:
             assert np.array_equal(plan.run(ang, "probs").cpu().numpy(),
                                   ref.run(ang, "probs").cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [6, 13, 17, 19])
+def test_run_batch_parity_matches_oracle_and_standalone_kernel(n):
+    """qmle_run_batch_parity: Z-parity observables measured out of the last pass (with the
+    trailing CX layer folded in) == state + stand-alone parity kernel == oracle (n <= 13)."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(100 + n)
+    tape = _tail_tape(n, rng, 40, 10)
+    ops, angles, consts = tape_to_native(tape, n)
+    ang = torch.from_numpy(np.stack([angles, angles * 0.5]).astype(np.float32)).cuda()
+    groups = [[0, n - 1], [1], list(range(n)), [2, 3, n - 2], [n // 2, 0]]
+    plan = N.Plan(ops, n, len(angles), consts)
+    got = plan.run_parity(ang, groups).cpu().numpy()
+    states = N.Plan(ops, n, len(angles), consts, N.plan_flags(no_absorb=True)).run(ang, "state")
+    want = N.expval_parity(states, groups).cpu().numpy()
+    assert np.allclose(got, want, atol=2e-6), np.abs(got - want).max()
+    if n <= 13:
+        psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
+        idx = np.arange(2**n)
+        for k, g in enumerate(groups):
+            par = np.zeros_like(idx)
+            for w in g:
+                par ^= (idx >> (n - 1 - w)) & 1
+            assert abs(got[0, k] - np.sum(np.abs(psi) ** 2 * (1 - 2 * par))) < 2e-6
+    with pytest.raises(ValueError):
+        plan.run_parity(ang, [[n]])
