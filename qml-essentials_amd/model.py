@@ -536,7 +536,7 @@ class Model:
         return inputs, params
 
     def gradient(self, params=None, inputs=None, enc_params=None, wrt: str = "params",
-                 force_mean: bool = False) -> np.ndarray:
+                 force_mean: bool = False, data_reupload=None) -> np.ndarray:
         """d<Z_q>/d``wrt`` for every output qubit by the parameter-shift rule
         (:meth:`script.Script.gradient`); ``wrt`` in {"params", "inputs", "enc_params"}.
 
@@ -549,6 +549,8 @@ class Model:
         """
         if wrt not in ("params", "inputs", "enc_params"):
             raise ValueError(f"wrt must be 'params', 'inputs' or 'enc_params', got {wrt!r}")
+        if data_reupload is not None:  # call-time override, as in __call__ (model.py:1633-1634)
+            self.data_reupload = data_reupload
         self.execution_type = "expval"
         params = self._params_validation(params)
         inputs = self._inputs_validation(inputs)

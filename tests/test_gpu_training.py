@@ -1,0 +1,65 @@
+"""Training through the engine: the reference trains with ``jax.grad``
+(``tests/test_model.py:1082-1145``, ``docs/training.md``); here the cost gradient is the chain
+rule over ``Model.gradient`` (parameter-shift Jacobian on the GPU) and Adam runs on the host."""
+import numpy as np
+import pytest
+
+from qml_essentials_amd.model import Model
+
+pytestmark = pytest.mark.gpu
+
+
+def _adam(grad_fn, x, steps, lr=0.05):
+    m, v = np.zeros_like(x), np.zeros_like(x)
+    for t in range(1, steps + 1):
+        g = grad_fn(x)
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        x = x - lr * (m / (1 - 0.9**t)) / (np.sqrt(v / (1 - 0.999**t)) + 1e-8)
+    return x
+
+
+def test_training_step_circuit_1():
+    """test_model.py:1082-1094: one optimiser step on <Z> of Circuit_1."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_1")
+    x0 = np.array([0.0])
+
+    def cost(p):
+        return float(model(params=p, inputs=x0, force_mean=True))
+
+    def grad(p):
+        return np.asarray(model.gradient(params=p, inputs=x0, force_mean=True)).reshape(p.shape)
+
+    p0 = np.asarray(model.params, dtype=np.float64)
+    p1 = _adam(grad, p0, 1, lr=0.01)
+    assert p1.shape == p0.shape and cost(p1) < cost(p0)
+
+
+def test_fit_sine_with_data_reupload_override():
+    """test_model.py:1097-1145 (gradient with ``data_reupload`` given at call time) extended
+    to an actual fit: MSE to sin(x) on 5 points drops by > 10x in 60 Adam steps."""
+    model = Model(n_qubits=2, n_layers=2, circuit_type="Circuit_19", data_reupload=True)
+    xs = np.linspace(-np.pi, np.pi, 5)
+    ys = np.sin(xs)
+    dru = np.zeros(model.data_reupload.shape)
+    dru[0, 0, 0] = 1
+
+    def predict(p):
+        return np.asarray(model(params=p, inputs=xs, data_reupload=dru, force_mean=True))
+
+    def grad(p):
+        jac = np.asarray(model.gradient(params=p, inputs=xs, data_reupload=dru, force_mean=True))
+        jac = jac.reshape(len(xs), *p.shape[-2:])
+        return (2.0 / len(xs)) * np.tensordot(predict(p) - ys, jac, axes=(0, 0)).reshape(p.shape)
+
+    p0 = np.asarray(model.params, dtype=np.float64)
+    g0 = grad(p0)
+    assert g0.shape == p0.shape and np.abs(g0).max() > 1e-4
+    # the analytic chain-rule gradient agrees with central differences of the cost
+    cost = lambda p: float(np.mean((predict(p) - ys) ** 2))  # noqa: E731
+    e = np.zeros_like(p0)
+    idx = np.unravel_index(np.argmax(np.abs(g0)), p0.shape)
+    e[idx] = 1e-2
+    assert abs((cost(p0 + e) - cost(p0 - e)) / 2e-2 - g0[idx]) < 2e-3
+    p1 = _adam(grad, p0, 60)
+    assert cost(p1) < 0.1 * cost(p0), (cost(p0), cost(p1))
