@@ -63,3 +63,41 @@ def test_fit_sine_with_data_reupload_override():
     assert abs((cost(p0 + e) - cost(p0 - e)) / 2e-2 - g0[idx]) < 2e-3
     p1 = _adam(grad, p0, 60)
     assert cost(p1) < 0.1 * cost(p0), (cost(p0), cost(p1))
+
+
+def test_gate_mode_training_1000_epochs_within_reference_budget():
+    """test_model.py:1297-1333: 999 Adam epochs, 3-qubit Circuit_19, expval + force_mean on a
+    Fourier-series target must finish within the reference's 120 s budget (it takes seconds
+    here) and must actually learn."""
+    import time
+
+    model = Model(n_qubits=3, n_layers=1, circuit_type="Circuit_19")
+    deg = model.degree[0]
+    xs = np.linspace(0, 2 * np.pi, deg, endpoint=False)
+    rng = np.random.default_rng(0)
+    c = rng.uniform(-0.3, 0.3, size=(deg // 2 + 1,))
+    ys = sum(ck * np.cos(k * xs) for k, ck in enumerate(c)) / 2
+
+    def predict(p):
+        return np.asarray(model(params=p, inputs=xs, execution_type="expval", force_mean=True))
+
+    def grad(p):
+        jac = np.asarray(model.gradient(params=p, inputs=xs, force_mean=True))
+        jac = jac.reshape(len(xs), *p.shape[-2:])
+        return (2.0 / len(xs)) * np.tensordot(predict(p) - ys, jac, axes=(0, 0)).reshape(p.shape)
+
+    p = np.asarray(model.params, dtype=np.float64)
+    c0 = float(np.mean((predict(p) - ys) ** 2))
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    t0 = time.time()
+    for t in range(1, 1000):
+        g = grad(p)
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        p = p - 0.01 * (m / (1 - 0.9**t)) / (np.sqrt(v / (1 - 0.999**t)) + 1e-8)
+        model.params = p
+    elapsed = time.time() - t0
+    c1 = float(np.mean((predict(p) - ys) ** 2))
+    print(f"999 epochs: {elapsed:.1f} s, cost {c0:.4f} -> {c1:.5f}")
+    assert elapsed < 120, "Time limit of 120 seconds exceeded"
+    assert c1 < 0.2 * c0
