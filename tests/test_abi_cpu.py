@@ -110,3 +110,27 @@ def test_compute_without_gpu_fails_loudly():
     p = N.Plan([("H", [0], [], -1)], 1, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         p.run(None, "state")
+
+
+def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
+    """hipcc's resource-usage remarks, saved by ``__graft_entry__.build()``: no kernel may use
+    scratch or spill VGPRs (a 16-amplitude register tile that falls into scratch costs 3.5x --
+    seen once while restructuring the gate loop), and the tile kernels must stay at
+    >= 4 waves per SIMD, the occupancy their latency hiding was tuned for."""
+    import json
+    import os
+
+    import __graft_entry__ as G
+
+    if not os.path.exists(G.RESOURCES):
+        G.build(force=True)
+    res = json.load(open(G.RESOURCES))
+    assert len(res) >= 40
+    for name, r in res.items():
+        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+    tiles = {k: v for k, v in res.items() if "6k_tileILb" in k}
+    assert len(tiles) == 2
+    for name, r in tiles.items():
+        assert r["Occupancy"] >= 4 and r["VGPRs"] <= 128, (name, r)
+    direct = [v for k, v in res.items() if "k_direct_1q" in k]
+    assert direct and all(r["Occupancy"] == 8 for r in direct)
