@@ -269,6 +269,32 @@ int qmle_probs_diag_expval(const float *d_probs, int n_qubits, int batch,
                            qmle_stream stream);
 size_t qmle_probs_diag_expval_workspace_bytes(int n_obs);
 
+/* ---- adjoint differentiation ---------------------------------------------------------------
+ * Gradient of  C = sum_b sum_k weights[b][k] <Z..Z>_k(b)  with respect to every gate angle in
+ * ONE backward sweep (what jax.grad through Script.execute gives the reference,
+ * tests/test_jaqsi.py:131-141, tests/test_model.py:1097-1145, docs/training.md):
+ *   psi = U_N .. U_1 |0>,  lambda = (sum_k w_k Z_k) psi;  for k = N .. 1:
+ *   dC/dtheta_k = coef_k Im <lambda| G_k |psi>,  then  psi <- U_k^+ psi,  lambda <- U_k^+ lambda.
+ * `fwd` is the ordinary plan of the tape; `rev` is a QMLE_PLAN_NO_FUSION | QMLE_PLAN_NO_ABSORB
+ * plan of the REVERSED, DAGGERED tape (one gate per pass), `terms[r]` describes the
+ * generator of rev op r:  G = i^n_y X^{x_wires} Z^{z_wires} projected onto |1> on
+ * proj_wires (controls), or diag(consts[marks_off + i]) for the Golomb diagonal.
+ * d_grad float32 [batch][n_grad_slots] (zeroed by the call); out_slot < 0 = no derivative. */
+typedef struct qmle_adjoint_term {
+  int32_t out_slot;
+  uint32_t x_wires, z_wires, proj_wires; /* bit w = wire w */
+  int32_t n_y;
+  float coef;
+  int32_t marks_off;
+} qmle_adjoint_term;
+int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_fwd,
+                          const float *d_angles_rev, int batch, const float *d_weights,
+                          const uint32_t *obs_wire_masks, int n_obs,
+                          const qmle_adjoint_term *terms, int n_terms, float *d_grad,
+                          int n_grad_slots, void *d_workspace, size_t workspace_bytes,
+                          qmle_stream stream);
+size_t qmle_adjoint_workspace_bytes(const qmle_plan *fwd, const qmle_plan *rev, int batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,9 @@ SYMBOLS = [
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
+    ("qmle_adjoint_gradient", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
+                                   _VP, _I, _VP, _SZ, _VP]),
+    ("qmle_adjoint_workspace_bytes", _SZ, [_VP, _VP, _I]),
     ("qmle_sample_counts", _I, [_VP, _I, _I, _I, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _SZ,
                                 _VP]),
     ("qmle_sample_workspace_bytes", _SZ, [_I, _I]),
@@ -576,4 +579,43 @@ def probs_diag_expval(probs, obs: Sequence[Tuple[Sequence[int], Optional[Sequenc
             C.c_void_p(d_table.data_ptr()) if d_table is not None else None, len(obs),
             C.c_void_p(out[b0:].data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
             _stream_ptr()), "qmle_probs_diag_expval")
+    return out
+
+
+class AdjointTerm(C.Structure):
+    _fields_ = [("out_slot", C.c_int32), ("x_wires", C.c_uint32), ("z_wires", C.c_uint32),
+                ("proj_wires", C.c_uint32), ("n_y", C.c_int32), ("coef", C.c_float),
+                ("marks_off", C.c_int32)]
+
+
+def adjoint_gradient(fwd: Plan, rev: Plan, angles_fwd, angles_rev, weights,
+                     wire_groups: Sequence[Sequence[int]], terms, n_grad_slots: int):
+    """One backward sweep: d/d(angle) of sum_k weights[b, k] <Z..Z>_k -> float32 [B, n_grad_slots].
+    ``terms``: one ``(out_slot, x_wires, z_wires, proj_wires, n_y, coef, marks_off)`` per op of
+    ``rev`` (the reversed, daggered NO_FUSION plan)."""
+    torch = require_gpu()
+    B, n_obs = int(weights.shape[0]), len(wire_groups)
+    if weights.dim() != 2 or weights.shape[1] != n_obs:
+        raise ValueError(f"weights must be [B, {n_obs}], got {tuple(weights.shape)}")
+    masks = (C.c_uint32 * max(1, n_obs))()
+    for k, grp in enumerate(wire_groups):
+        m = 0
+        for wq in grp:
+            if not 0 <= int(wq) < fwd.n_qubits:
+                raise ValueError(f"wire {wq} out of range for {fwd.n_qubits} qubits")
+            m |= 1 << int(wq)
+        masks[k] = m
+    arr = (AdjointTerm * max(1, len(terms)))()
+    for i, t in enumerate(terms):
+        (arr[i].out_slot, arr[i].x_wires, arr[i].z_wires, arr[i].proj_wires, arr[i].n_y,
+         arr[i].coef, arr[i].marks_off) = t
+    dev = weights.device
+    out = torch.empty((B, n_grad_slots), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib().qmle_adjoint_workspace_bytes(fwd._h, rev._h, B), dtype=torch.uint8,
+                     device=dev)
+    check(lib().qmle_adjoint_gradient(
+        fwd._h, rev._h, C.c_void_p(angles_fwd.data_ptr()), C.c_void_p(angles_rev.data_ptr()), B,
+        C.c_void_p(weights.data_ptr()), masks, n_obs, arr, len(terms),
+        C.c_void_p(out.data_ptr()), int(n_grad_slots), C.c_void_p(ws.data_ptr()),
+        C.c_size_t(ws.numel()), _stream_ptr()), "qmle_adjoint_gradient")
     return out

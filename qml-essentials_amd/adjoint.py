@@ -1,0 +1,126 @@
+"""Adjoint differentiation: the gradient of a weighted sum of Z / Z-parity expectation values
+with respect to EVERY gate angle in one backward sweep (``qmle_adjoint_gradient``).
+
+What ``jax.grad`` through ``Script.execute`` gives the reference (``tests/test_jaqsi.py:131-141``,
+``tests/test_model.py:1097-1145``, ``docs/training.md``).  Cost: one forward simulation, then
+per gate one inverse-gate pass over [psi; lambda] and, per differentiable angle, one overlap
+``Im <lambda| G |psi>`` -- O(gates + angles) passes instead of the 2 x angles full circuits of
+the parameter-shift rule.
+
+This module only prepares the REVERSED, DAGGERED tape and the generator table; the sweep itself
+runs in the engine.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .simulation import LoweredTape, _Lowered, get_plan
+
+# rotation gates exp(-i theta/2 P): generator Pauli word per wire, (control?, word)
+_ROT = {"RX": (False, "X"), "RY": (False, "Y"), "RZ": (False, "Z"),
+        "CRX": (True, "X"), "CRY": (True, "Y"), "CRZ": (True, "Z"),
+        "RXX": (False, "XX"), "RYY": (False, "YY"), "RZZ": (False, "ZZ"), "RZX": (False, "ZX")}
+_SELF_INVERSE = {"Id", "PauliX", "PauliY", "PauliZ", "H", "CX", "CY", "CZ", "SWAP", "CCX", "CSWAP"}
+
+
+class AdjointUnsupported(NotImplementedError):
+    pass
+
+
+def _dagger_blob(blob: np.ndarray, dim: int) -> np.ndarray:
+    m = np.asarray(blob, dtype=np.float64).reshape(dim, dim, 2)
+    m = (m[..., 0] + 1j * m[..., 1]).conj().T
+    return np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
+
+
+def _term(out_slot=-1, x=0, z=0, proj=0, n_y=0, coef=0.0, marks_off=-1):
+    return (int(out_slot), int(x), int(z), int(proj), int(n_y), float(coef), int(marks_off))
+
+
+_BLOB_LEN = {"MAT1": 8, "MAT2": 32, "MAT4": 512}
+
+
+def _op_blobs(low: LoweredTape) -> List[Optional[np.ndarray]]:
+    out = []
+    for name, _w, _s, off in low.ops:
+        if off < 0:
+            out.append(None)
+        else:
+            size = _BLOB_LEN.get(name, 1 << low.n_qubits)  # DIAG_ALL: one mark per amplitude
+            out.append(low.consts[off:off + size])
+    return out
+
+
+def build_reverse(low: LoweredTape, blobs: List[Optional[np.ndarray]], want: Sequence[bool]):
+    """From the forward lowered tape: the reversed, daggered primitive tape (as ``_Lowered`` ops),
+    its per-slot values (negated forward columns) and one generator term per reverse op.
+
+    ``blobs[k]``: constant blob of forward op k (or None); ``want[s]``: forward slot s needs a
+    derivative.  Rot(phi, theta, omega) = RZ(omega) RY(theta) RZ(phi) is split into its three
+    rotations so that every primitive has at most one angle."""
+    prims = []  # forward order: (name, wires, fwd_slot | None, blob)
+    for (name, wires, slots, _off), blob in zip(low.ops, blobs):
+        if name == "Rot":
+            prims += [("RZ", wires, slots[0], None), ("RY", wires, slots[1], None),
+                      ("RZ", wires, slots[2], None)]
+        elif len(slots) > 1:
+            raise AdjointUnsupported(f"{name}: more than one angle per gate")
+        else:
+            prims.append((name, wires, slots[0] if slots else None, blob))
+    rev_ops, rev_values, terms = [], [], []
+    for name, wires, fslot, blob in reversed(prims):
+        params, out_blob, term = [], None, _term()
+        bit = lambda ws: sum(1 << int(w) for w in ws)  # noqa: E731
+        if fslot is not None:
+            params = [-np.asarray(low.values[fslot], dtype=np.float64)]
+        d = want[fslot] if fslot is not None else False
+        if name in _ROT:
+            ctrl, word = _ROT[name]
+            tw = wires[1:] if ctrl else wires
+            x = bit(w for w, p in zip(tw, word) if p in "XY")
+            z = bit(w for w, p in zip(tw, word) if p in "ZY")
+            if d:
+                term = _term(fslot, x, z, bit(wires[:1]) if ctrl else 0, word.count("Y"), 1.0)
+        elif name in ("CPhase", "ControlledPhaseShift"):
+            if d:  # dU = i |11><11| U
+                term = _term(fslot, 0, 0, bit(wires), 0, -2.0)
+        elif name == "DIAG_ALL":
+            out_blob = np.asarray(blob, dtype=np.float32)
+            if d:  # U = exp(-i M x): dU = -i M U
+                term = _term(fslot, coef=2.0, marks_off=0)  # offset patched below
+        elif name in _SELF_INVERSE:
+            pass
+        elif name == "S":
+            name, out_blob = "MAT1", np.array([1, 0, 0, 0, 0, 0, 0, -1], dtype=np.float32)
+        elif name in ("MAT1", "MAT2", "MAT4"):
+            out_blob = _dagger_blob(blob, 2 ** len(wires))
+        else:
+            raise AdjointUnsupported(f"no adjoint rule for {name}")
+        rev_ops.append(_Lowered((name, list(wires), params, out_blob)))
+        terms.append(term)
+    return rev_ops, terms
+
+
+def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
+                          weights: np.ndarray, want: Sequence[bool]) -> np.ndarray:
+    """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
+    (columns of slots that are not wanted stay zero)."""
+    torch = N.require_gpu()
+    if n_qubits < 3:
+        raise AdjointUnsupported("the per-gate streaming kernels need at least 3 qubits")
+    rev_ops, terms = build_reverse(low, _op_blobs(low), want)
+    rev = LoweredTape(rev_ops, n_qubits)
+    # patch the Golomb marks offsets now that the reverse const blob is laid out
+    fixed = []
+    for (name, _w, _s, off), t in zip(rev.ops, terms):
+        fixed.append(t[:6] + (off,) if (name == "DIAG_ALL" and t[0] >= 0) else t)
+    fwd_plan = get_plan(low)
+    rev_plan = get_plan(rev, N.PLAN_NO_FUSION | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB)
+    a_f = torch.from_numpy(low.angle_table(batch)).cuda()
+    a_r = torch.from_numpy(rev.angle_table(batch)).cuda()
+    w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()
+    return N.adjoint_gradient(fwd_plan, rev_plan, a_f, a_r, w, obs_groups, fixed,
+                              max(1, low.n_slots)).cpu().numpy()[:, : low.n_slots]

@@ -1463,6 +1463,95 @@ k_probs_diag_expval(const float *__restrict__ probs, uint64_t D, const DiagObs *
 }
 
 
+// ---- adjoint differentiation -------------------------------------------------------------
+struct ZSumArgs {
+  uint32_t mask[QMLE_MAX_QUBITS];  // bit-position parity masks
+  int n_obs;
+};
+// lambda[b][i] = (sum_k w[b][k] (-1)^{|i & mask_k|}) psi[b][i]
+__global__ void __launch_bounds__(256)
+k_zsum_apply(const float4 *__restrict__ psi, float4 *__restrict__ lam, int n,
+             const float *__restrict__ weights, ZSumArgs z) {
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float *w = weights + (size_t)b * z.n_obs;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+    const uint32_t i0 = (uint32_t)(k << 1);
+    float d0 = 0.f, d1 = 0.f;
+    for (int o = 0; o < z.n_obs; ++o) {
+      const float wk = w[o];
+      d0 += (__popc(i0 & z.mask[o]) & 1) ? -wk : wk;
+      d1 += (__popc((i0 | 1u) & z.mask[o]) & 1) ? -wk : wk;
+    }
+    const float4 v = psi[(size_t)b * chunks + k];
+    lam[(size_t)b * chunks + k] = make_float4(d0 * v.x, d0 * v.y, d1 * v.z, d1 * v.w);
+  }
+}
+
+struct AdjTerm {
+  uint32_t xmask, zmask, pmask;  // bit positions: flipped / sign / projected onto 1
+  const float *marks;            // != nullptr: G = diag(marks)
+};
+// partial[b][block] = sum_i conj(lambda_i) (X^x Z^z Pi_p psi)_i   (phase i^n_y applied later)
+__global__ void __launch_bounds__(256)
+k_adj_overlap(const float4 *__restrict__ psi_all, const float4 *__restrict__ lam_all, int n,
+              AdjTerm t, float2 *__restrict__ partial) {
+  __shared__ float red[16];
+  const int b = blockIdx.y;
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  const float4 *psi = psi_all + (size_t)b * chunks;
+  const float4 *lam = lam_all + (size_t)b * chunks;
+  const uint64_t xk = t.xmask >> 1;
+  const bool swap01 = t.xmask & 1u;
+  float re = 0.f, im = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < chunks; k += stride) {
+    const uint32_t i0 = (uint32_t)(k << 1);
+    if ((i0 & t.pmask & ~1u) != (t.pmask & ~1u)) continue;
+    const float4 l = lam[k];
+    float4 p = psi[k ^ xk];
+    if (swap01) p = make_float4(p.z, p.w, p.x, p.y);
+    // element e of this chunk: row i = i0 | e, source j = i ^ xmask
+    float s0, s1;
+    if (t.marks) {
+      s0 = t.marks[i0];
+      s1 = t.marks[i0 | 1u];
+    } else {
+      const uint32_t j0 = i0 ^ t.xmask, j1 = (i0 | 1u) ^ t.xmask;
+      s0 = (__popc(j0 & t.zmask) & 1) ? -1.f : 1.f;
+      s1 = (__popc(j1 & t.zmask) & 1) ? -1.f : 1.f;
+    }
+    if ((t.pmask & 1u)) s0 = 0.f;  // projector wants bit 0 = 1: even rows drop out
+    re += s0 * (l.x * p.x + l.y * p.y) + s1 * (l.z * p.z + l.w * p.w);
+    im += s0 * (l.x * p.y - l.y * p.x) + s1 * (l.z * p.w - l.w * p.z);
+  }
+  const float r = block_sum(re, red);
+  const float i = block_sum(im, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = make_float2(r, i);
+}
+// grad[b][slot] = coef * Im(i^n_y * sum)
+__global__ void __launch_bounds__(256)
+k_adj_final(const float2 *__restrict__ partial, int n_blocks, int n_y, float coef,
+            float *__restrict__ grad, int n_grad_slots, int slot) {
+  __shared__ double red[16];
+  const int b = blockIdx.x;
+  double re = 0.0, im = 0.0;
+  for (int k = threadIdx.x; k < n_blocks; k += blockDim.x) {
+    const float2 v = partial[(size_t)b * n_blocks + k];
+    re += v.x;
+    im += v.y;
+  }
+  const double r = block_sum_d(re, red);
+  const double i = block_sum_d(im, red);
+  if (threadIdx.x == 0) {
+    const int q = n_y & 3;
+    const double v = q == 0 ? i : q == 1 ? r : q == 2 ? -i : -r;
+    grad[(size_t)b * n_grad_slots + slot] = (float)(coef * v);
+  }
+}
+
+
 // <a_i|b_i> for separate arrays a, b: partial[i][block] = (re, im)
 __global__ void __launch_bounds__(256)
 k_overlap2_partial(const float4 *__restrict__ a_all, const float4 *__restrict__ b_all, int n,
@@ -2410,6 +2499,23 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
 
 // Apply the plan's passes IN PLACE to resident states (no |0..0> initialisation, no
 // measurement): the gate-application hot loop on its own (simulation.py:102-103).
+// One stage of a plan applied in place to resident states.
+static int run_stage_inplace(qmle_plan *plan, const Stage &st, float2 *d_states, const float *d_mats,
+                             const float *d_angles, int batch, hipStream_t stream) {
+  const int n = plan->n;
+  const size_t D = (size_t)1 << n;
+  if (st.kind == ST_TILE)
+    return launch_tile(plan, st, d_states, d_mats, d_angles, batch, false, TM_STORE, nullptr,
+                       nullptr, 0, stream);
+  if (st.kind == ST_DIRECT)
+    return launch_direct(plan, plan->dev_ops[st.op_begin], d_states, d_mats, batch, stream);
+  const LoweredOp &o = plan->dev_ops[st.op_begin];
+  hipLaunchKernelGGL(k_diag_all, dim3(grid_for(D / 2, 256), batch), dim3(256), 0, stream,
+                     reinterpret_cast<float4 *>(d_states), n, plan->dev.d_consts + o.mat_off,
+                     d_angles, plan->n_slots, o.slot);
+  return QMLE_OK;
+}
+
 int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
   if (!plan || batch < 1 || batch > 65535 || !d_states || !d_workspace) return QMLE_ERR_INVALID_ARG;
@@ -2427,23 +2533,123 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
                        plan->dev.d_build, plan->dev.d_groups, ng, d_angles, plan->n_slots,
                        plan->dev.d_consts, d_mats, plan->mat_floats);
   }
-  const int n = plan->n;
-  const size_t D = (size_t)1 << n;
   int stage_idx = -1;
   for (const Stage &st : plan->stages) {
     ProfScope prof_scope(plan, ++stage_idx, stream);
-    if (st.kind == ST_TILE) {
-      rc = launch_tile(plan, st, (float2 *)d_states, d_mats, d_angles, batch, false, TM_STORE,
-                       nullptr, nullptr, 0, stream);
-    } else if (st.kind == ST_DIRECT) {
-      rc = launch_direct(plan, plan->dev_ops[st.op_begin], (float2 *)d_states, d_mats, batch, stream);
-    } else {
-      const LoweredOp &o = plan->dev_ops[st.op_begin];
-      hipLaunchKernelGGL(k_diag_all, dim3(grid_for(D / 2, 256), batch), dim3(256), 0, stream,
-                         reinterpret_cast<float4 *>(d_states), n, plan->dev.d_consts + o.mat_off,
-                         d_angles, plan->n_slots, o.slot);
-      rc = QMLE_OK;
+    rc = run_stage_inplace(plan, st, (float2 *)d_states, d_mats, d_angles, batch, stream);
+    if (rc != QMLE_OK) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+// ---- adjoint gradient ------------------------------------------------------------------------
+static uint32_t wires_to_pos(uint32_t wires, int n) {
+  uint32_t m = 0;
+  for (int w = 0; w < n; ++w)
+    if (wires & (1u << w)) m |= 1u << (n - 1 - w);
+  return m;
+}
+static int adj_blocks(int n) {
+  const uint64_t chunks = (uint64_t)1 << (n - 1);
+  uint64_t b = (chunks + 256 * 8 - 1) / (256 * 8);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+struct AdjLayout { size_t states, lam, mats, ang2, partial, fwd_ws, total; };
+static AdjLayout adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
+  AdjLayout L;
+  const size_t sb = (size_t)batch * ((size_t)8 << fwd->n);
+  L.states = 0;
+  L.lam = sb;  // lambda DIRECTLY behind psi: one batch of 2B states for the backward gates
+  L.mats = align_up(2 * sb, 256);
+  L.ang2 = L.mats + ws_mats_bytes(rev, 2 * batch);
+  L.partial = L.ang2 + align_up((size_t)2 * batch * (rev->n_slots ? rev->n_slots : 1) * sizeof(float), 256);
+  L.fwd_ws = L.partial + align_up((size_t)batch * adj_blocks(fwd->n) * sizeof(float2), 256);
+  L.total = L.fwd_ws + workspace_bytes_one(fwd, batch, QMLE_MEAS_STATE, 0) + 256;
+  return L;
+}
+size_t qmle_adjoint_workspace_bytes(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
+  if (!fwd || !rev || batch < 1) return 0;
+  return adj_layout(fwd, rev, batch).total + 256;
+}
+
+int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_fwd,
+                          const float *d_angles_rev, int batch, const float *d_weights,
+                          const uint32_t *obs_wire_masks, int n_obs,
+                          const qmle_adjoint_term *terms, int n_terms, float *d_grad,
+                          int n_grad_slots, void *d_workspace, size_t workspace_bytes,
+                          qmle_stream stream_) {
+  if (!fwd || !rev || batch < 1 || 2 * batch > 65535 || !d_weights || !obs_wire_masks ||
+      n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !terms || !d_grad || n_grad_slots < 1 ||
+      !d_workspace || fwd->n != rev->n || n_terms != (int)rev->ops.size())
+    return QMLE_ERR_INVALID_ARG;
+  if ((fwd->n_slots > 0 && !d_angles_fwd) || (rev->n_slots > 0 && !d_angles_rev))
+    return QMLE_ERR_INVALID_ARG;
+  const int n = fwd->n;
+  for (const Stage &st : rev->stages)
+    if (st.src_ops.size() != 1) return QMLE_ERR_INVALID_ARG;  // rev must be a NO_FUSION plan
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = ensure_device_plan(rev);
+  if (rc != QMLE_OK) return rc;
+  char *ws = (char *)d_workspace;
+  const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+  const AdjLayout L = adj_layout(fwd, rev, batch);
+  if (workspace_bytes < mis + L.total) return QMLE_ERR_WORKSPACE;
+  ws += mis;
+  float2 *psi = (float2 *)(ws + L.states);
+  float2 *lam = (float2 *)(ws + L.lam);
+  float *mats = (float *)(ws + L.mats);
+  float *ang2 = (float *)(ws + L.ang2);
+  float2 *partial = (float2 *)(ws + L.partial);
+  const size_t D = (size_t)1 << n;
+
+  // forward: psi = U_N .. U_1 |0>
+  rc = run_batch_masks(fwd, d_angles_fwd, batch, QMLE_MEAS_STATE, nullptr, 0, psi, ws + L.fwd_ws,
+                       workspace_bytes - mis - L.fwd_ws, stream);
+  if (rc != QMLE_OK) return rc;
+  // lambda = (sum_k w_k Z..Z_k) psi
+  ZSumArgs z;
+  z.n_obs = n_obs;
+  for (int k = 0; k < n_obs; ++k) {
+    if (obs_wire_masks[k] == 0 || (n < 32 && (obs_wire_masks[k] >> n))) return QMLE_ERR_WIRE_RANGE;
+    z.mask[k] = wires_to_pos(obs_wire_masks[k], n);
+  }
+  hipLaunchKernelGGL(k_zsum_apply, dim3(grid_for(D / 2, 256, 4096), batch), dim3(256), 0, stream,
+                     (const float4 *)psi, (float4 *)lam, n, d_weights, z);
+  HIPCHK(hipMemsetAsync(d_grad, 0, (size_t)batch * n_grad_slots * sizeof(float), stream));
+  // the backward gates act on [psi; lambda] as one batch of 2B states: duplicate the angles
+  if (rev->n_slots > 0) {
+    const size_t ab = (size_t)batch * rev->n_slots * sizeof(float);
+    HIPCHK(hipMemcpyAsync(ang2, d_angles_rev, ab, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemcpyAsync((char *)ang2 + ab, d_angles_rev, ab, hipMemcpyDeviceToDevice, stream));
+  }
+  if (!rev->groups.empty()) {
+    const int ng = (int)rev->groups.size();
+    hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, 2 * batch), dim3(64), 0, stream,
+                       rev->dev.d_build, rev->dev.d_groups, ng, ang2, rev->n_slots,
+                       rev->dev.d_consts, mats, rev->mat_floats);
+  }
+  const int nb = adj_blocks(n);
+  for (const Stage &st : rev->stages) {
+    const int r = st.src_ops[0];
+    const qmle_adjoint_term &t = terms[r];
+    if (t.out_slot >= 0) {
+      if (t.out_slot >= n_grad_slots) return QMLE_ERR_SLOT_RANGE;
+      AdjTerm a;
+      a.xmask = wires_to_pos(t.x_wires, n);
+      a.zmask = wires_to_pos(t.z_wires, n);
+      a.pmask = wires_to_pos(t.proj_wires, n);
+      a.marks = t.marks_off >= 0 ? rev->dev.d_consts + t.marks_off : nullptr;
+      if (t.marks_off >= 0 && (size_t)t.marks_off + D > rev->consts.size()) return QMLE_ERR_INVALID_ARG;
+      hipLaunchKernelGGL(k_adj_overlap, dim3(nb, batch), dim3(256), 0, stream, (const float4 *)psi,
+                         (const float4 *)lam, n, a, partial);
+      hipLaunchKernelGGL(k_adj_final, dim3(batch), dim3(nb >= 256 ? 256 : 64), 0, stream,
+                         (const float2 *)partial, nb, t.n_y, t.coef, d_grad, n_grad_slots,
+                         t.out_slot);
     }
+    rc = run_stage_inplace(rev, st, psi, mats, ang2, 2 * batch, stream);
     if (rc != QMLE_OK) return rc;
   }
   HIPCHK(hipGetLastError());

@@ -536,7 +536,8 @@ class Model:
         return inputs, params
 
     def gradient(self, params=None, inputs=None, enc_params=None, wrt: str = "params",
-                 force_mean: bool = False, data_reupload=None) -> np.ndarray:
+                 force_mean: bool = False, data_reupload=None,
+                 method: str = "parameter-shift", cotangent=None) -> np.ndarray:
         """d<Z_q>/d``wrt`` for every output qubit by the parameter-shift rule
         (:meth:`script.Script.gradient`); ``wrt`` in {"params", "inputs", "enc_params"}.
 
@@ -546,7 +547,19 @@ class Model:
         which any cost gradient follows by the chain rule on the host.  Shape:
         ``(*eff_batch_shape, n_outputs, *shape_of(wrt))`` (batch axes of size 1 dropped;
         ``force_mean`` averages over the outputs like ``__call__``).
+
+        ``method="adjoint"`` uses adjoint differentiation (:mod:`adjoint`): one backward sweep
+        per output, or a single sweep for ``force_mean`` / an explicit ``cotangent`` of shape
+        ``(B, n_outputs)`` -- then the result is the vector-Jacobian product
+        ``sum_k cotangent[b, k] d<out_k>_b / d wrt`` of shape ``(*eff_batch_shape, *shape_of(wrt))``,
+        i.e. the gradient of any cost whose derivative with respect to the outputs is
+        ``cotangent``.  Same numbers as the parameter-shift rule at O(gates) instead of
+        O(gates x angles) cost.
         """
+        if method not in ("parameter-shift", "adjoint"):
+            raise ValueError(f"method must be 'parameter-shift' or 'adjoint', got {method!r}")
+        if cotangent is not None and method != "adjoint":
+            raise ValueError("cotangent needs method='adjoint'")
         if wrt not in ("params", "inputs", "enc_params"):
             raise ValueError(f"wrt must be 'params', 'inputs' or 'enc_params', got {wrt!r}")
         if data_reupload is not None:  # call-time override, as in __call__ (model.py:1633-1634)
@@ -567,10 +580,30 @@ class Model:
                    None, None, None)
         argnum = {"params": 0, "inputs": 1, "enc_params": 4}[wrt]
         kwargs = dict(noise_params=self.noise_params, gate_mode="unitary")
-        (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
-                                      in_axes=in_axes if B > 1 else None, argnums=(argnum,))
-        if B == 1:
-            jac = jac[None]
+        if method == "adjoint":
+            n_out = len(obs)
+            ax = in_axes if B > 1 else None
+            if cotangent is not None or force_mean:
+                w = (np.full((B, n_out), 1.0 / n_out) if cotangent is None
+                     else np.asarray(cotangent, dtype=np.float64).reshape(B, n_out))
+                (g,) = self.script.vjp(obs, w, args=args, kwargs=kwargs, in_axes=ax,
+                                       argnums=(argnum,))
+                jac = (g if B > 1 else g[None])[:, None]       # (B, 1, *leaf)
+                force_mean = True                              # the output axis is already reduced
+            else:
+                cols = []
+                for k in range(n_out):
+                    w = np.zeros((B, n_out))
+                    w[:, k] = 1.0
+                    (g,) = self.script.vjp(obs, w, args=args, kwargs=kwargs, in_axes=ax,
+                                           argnums=(argnum,))
+                    cols.append(g if B > 1 else g[None])
+                jac = np.stack(cols, axis=1)
+        else:
+            (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
+                                          in_axes=in_axes if B > 1 else None, argnums=(argnum,))
+            if B == 1:
+                jac = jac[None]
         leaf = jac.shape[2:]
         if wrt in ("params", "inputs") and in_axes[argnum] is None and leaf and leaf[0] == 1:
             jac = jac.reshape(jac.shape[:2] + leaf[1:])  # drop the dummy batch axis of the arg

@@ -567,7 +567,9 @@ class DiagonalQubitUnitary(Operation):
                 f"DiagonalQubitUnitary expects {2 ** len(wl)} diagonal entries "
                 f"for {len(wl)} wire(s), got shape {marks.shape}"
             )
-        self._marks, self._scale = marks, scale
+        self._marks = marks
+        self._param_names = ("_scale",)   # instance-level: x is this gate's (differentiable) angle
+        self._store_param("_scale", x)
         self.diag = None if np.ndim(scale) else np.exp(-1j * marks * scale)
         kw.setdefault("name", "DiagU")
         Operation.__init__(self, wires=wl, **kw)

@@ -219,22 +219,10 @@ class Script:
                  (-3 * np.pi / 2, (np.sqrt(2) - 1) / (4 * np.sqrt(2)))),
     }
 
-    def gradient(self, obs: List[Operation], *, args: tuple = (), kwargs: Optional[dict] = None,
-                 in_axes: Optional[Tuple] = None, argnums: Tuple[int, ...] = (0,)):
-        """Jacobian of ``execute(type="expval", obs=obs, ...)`` with respect to the array
-        arguments ``argnums`` by the parameter-shift rule (exact, no finite differences).
-
-        What ``jax.grad`` through ``Script.execute`` provides in the reference
-        (``tests/test_jaqsi.py:131-141,764-786``), done the way this engine is good at:
-        every shifted circuit is one more row of the batch, so one engine call evaluates
-        all ``2 x (#rotation gates)`` (4 per controlled rotation) shifted copies of every
-        sample.  Gate angles may be sums / products of the arguments (``inputs * enc_params``);
-        the chain rule uses the tangents tracked by :class:`batching.Batched`.
-
-        Returns a tuple with one array per entry of ``argnums`` of shape
-        ``(B, n_obs, *arg_shape)`` (``arg_shape`` without its batch axis); ``B = 1`` and the
-        axis is dropped when ``in_axes`` is None.
-        """
+    def _trace_for_gradient(self, obs, args, kwargs, in_axes, argnums):
+        """Record the tape with the ``argnums`` arguments as differentiable leaves.  Returns
+        ``(tape, lowered tape, n_qubits, B, slots, leaf_shapes, batched)`` where ``slots`` lists
+        ``(angle slot, shift rule, tangent terms)`` for every angle that depends on a leaf."""
         kwargs = {} if kwargs is None else kwargs
         args = tuple(to_numpy(a) for a in args)
         batched = in_axes is not None
@@ -263,30 +251,81 @@ class Script:
         tape = self._record(*wrapped, **kwargs)
         n_qubits = self._n_qubits or simulation.infer_n_qubits(tape, obs)
         low = simulation.LoweredTape(tape, n_qubits)
-        base = low.angle_table(B).astype(np.float64)
 
         # differentiable slots: (slot, rule, tangent terms)
         slots, s = [], 0
         for op_ in tape:
-            if op_.lower(n_qubits) is None:
+            lowered = op_.lower(n_qubits)
+            if lowered is None:
                 continue
             tans = op_.parameter_tangents
-            for j, _ in enumerate(op_.parameters):
+            for j in range(len(lowered[2])):  # one angle slot per lowered parameter
                 t = tans[j] if j < len(tans) else []
                 if t is None:
                     raise NotImplementedError(
                         f"{op_.name}: parameter is a non-linear function of the arguments; "
                         "cannot apply the chain rule")
                 if t:
-                    if op_._shift_rule is None:
-                        raise NotImplementedError(f"{op_.name} has no parameter-shift rule")
-                    slots.append((s, self._SHIFT_RULES[op_._shift_rule], t))
+                    slots.append((s, op_._shift_rule, t, op_.name))
                 s += 1
+        return tape, low, n_qubits, B, slots, leaf_shapes, batched
+
+    def vjp(self, obs: List[Operation], cotangent, *, args: tuple = (),
+            kwargs: Optional[dict] = None, in_axes: Optional[Tuple] = None,
+            argnums: Tuple[int, ...] = (0,)):
+        """Gradient of ``sum_k cotangent[b, k] * <obs_k>_b`` with respect to the array arguments
+        ``argnums`` by ADJOINT differentiation: one backward sweep for all angles
+        (:mod:`adjoint`).  ``obs`` must be Z / Z-parity observables; ``cotangent`` has shape
+        ``(B, n_obs)`` (``(n_obs,)`` without ``in_axes``).  Returns one array per ``argnums``
+        entry of shape ``(B, *arg_shape)`` (no ``B`` axis without ``in_axes``)."""
+        from . import adjoint
+
+        masks = [z_parity_mask(o) for o in obs]
+        if not obs or any(m is None for m in masks):
+            raise adjoint.AdjointUnsupported("adjoint differentiation needs Z / Z-parity observables")
+        tape, low, n_qubits, B, slots, leaf_shapes, batched = self._trace_for_gradient(
+            obs, args, kwargs, in_axes, argnums)
+        if any(isinstance(o, KrausChannel) for o in tape):
+            raise adjoint.AdjointUnsupported("adjoint differentiation of noisy circuits")
+        w = np.asarray(cotangent, dtype=np.float32).reshape(B, len(obs))
+        want = [False] * low.n_slots
+        for s_, _rule, _t, _name in slots:
+            want[s_] = True
+        grads = {k: np.zeros((B,) + tuple(shp)) for k, shp in leaf_shapes.items()}
+        if slots:
+            d = adjoint.adjoint_slot_gradient(low, n_qubits, B, masks, w, want)  # [B, n_slots]
+            for s_, _rule, tangent, _name in slots:
+                for lid, flat, coef in tangent:  # gate angles are scalars: one leaf element each
+                    g = grads[lid].reshape(B, -1)
+                    g[:, int(flat)] += d[:, s_] * np.asarray(coef, dtype=np.float64).reshape(B)
+        return tuple(grads[k] if batched else grads[k][0] for k in argnums)
+
+    def gradient(self, obs: List[Operation], *, args: tuple = (), kwargs: Optional[dict] = None,
+                 in_axes: Optional[Tuple] = None, argnums: Tuple[int, ...] = (0,)):
+        """Jacobian of ``execute(type="expval", obs=obs, ...)`` with respect to the array
+        arguments ``argnums`` by the parameter-shift rule (exact, no finite differences).
+
+        What ``jax.grad`` through ``Script.execute`` provides in the reference
+        (``tests/test_jaqsi.py:131-141,764-786``), done the way this engine is good at:
+        every shifted circuit is one more row of the batch, so one engine call evaluates
+        all ``2 x (#rotation gates)`` (4 per controlled rotation) shifted copies of every
+        sample.  Gate angles may be sums / products of the arguments (``inputs * enc_params``);
+        the chain rule uses the tangents tracked by :class:`batching.Batched`.
+
+        Returns a tuple with one array per entry of ``argnums`` of shape
+        ``(B, n_obs, *arg_shape)`` (``arg_shape`` without its batch axis); ``B = 1`` and the
+        axis is dropped when ``in_axes`` is None.
+        """
+        tape, low, n_qubits, B, slots, leaf_shapes, batched = self._trace_for_gradient(
+            obs, args, kwargs, in_axes, argnums)
+        base = low.angle_table(B).astype(np.float64)
         grads = {k: np.zeros((B, len(obs)) + tuple(shp)) for k, shp in leaf_shapes.items()}
         if slots:
             rows = []
-            for slot, rule, _ in slots:
-                for shift, _c in rule:
+            for slot, rule_name, _t, op_name in slots:
+                if rule_name is None:
+                    raise NotImplementedError(f"{op_name} has no parameter-shift rule")
+                for shift, _c in self._SHIFT_RULES[rule_name]:
                     t = base.copy()
                     t[:, slot] += shift
                     rows.append(t)
@@ -295,9 +334,9 @@ class Script:
             vals = simulation.run_expval_table(plan, table, obs, n_qubits)  # (rows*B, n_obs)
             vals = vals.reshape(-1, B, len(obs))
             r = 0
-            for slot, rule, tangent in slots:
+            for slot, rule_name, tangent, _op_name in slots:
                 d = np.zeros((B, len(obs)))
-                for _shift, coef in rule:
+                for _shift, coef in self._SHIFT_RULES[rule_name]:
                     d += coef * vals[r]
                     r += 1
                 for lid, flat, coef in tangent:
