@@ -556,8 +556,13 @@ class Model:
         ``cotangent``.  Same numbers as the parameter-shift rule at O(gates) instead of
         O(gates x angles) cost.
         """
+        if method == "auto":  # measured cross-over (profiles/r01_gradients.md): the per-gate
+            # backward passes are launch-bound below ~18 qubits, bandwidth-bound above
+            method = "adjoint" if (self.n_qubits >= 18 and self.noise_params is None
+                                   and (force_mean or cotangent is not None)) else "parameter-shift"
         if method not in ("parameter-shift", "adjoint"):
-            raise ValueError(f"method must be 'parameter-shift' or 'adjoint', got {method!r}")
+            raise ValueError(
+                f"method must be 'parameter-shift', 'adjoint' or 'auto', got {method!r}")
         if cotangent is not None and method != "adjoint":
             raise ValueError("cotangent needs method='adjoint'")
         if wrt not in ("params", "inputs", "enc_params"):
