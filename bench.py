@@ -227,6 +227,8 @@ def main():
         "algorithmic_bytes_per_launch": round(dom["algo"] / max(1, dom["launches"])),
         "bytes_moved_per_launch": round(dom["moved"] / max(1, dom["launches"])),
         "moved_GBps": round(dom["moved"] / (dom["ms"] * 1e-3) / 1e9, 1) if dom["ms"] > 0 else 0.0,
+        "moved_frac": round(dom["moved"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        if dom["ms"] > 0 else 0.0,
         "note": "algorithmic bytes = sum of the per-gate bytes (SURVEY 8-d) of the reference "
                 "gates one launch applies; a fused pass applies many gates per HBM round trip, "
                 "so achieved may exceed the HBM peak; moved_GBps is the real stream rate",
@@ -245,6 +247,9 @@ def main():
                    "gates_folded_into_observables": folded,
                    "parallelism": f"batch-sharded x{size}"},
         "statevectors_per_s": round(total_states / elapsed, 2),
+        # transparency: `value` counts every gate of the reference tape; this one leaves out the
+        # trailing CX layer that <Z> folds into its observables instead of applying to the state
+        "gate_applies_per_s_state_applied_only": round((n_gates - folded) * total_states / elapsed, 1),
         "roofline": roofline,
     }
     if not a.skip_aux and size == 1:
