@@ -109,8 +109,6 @@ def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_group
     """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
     (columns of slots that are not wanted stay zero)."""
     torch = N.require_gpu()
-    if n_qubits < 3:
-        raise AdjointUnsupported("the per-gate streaming kernels need at least 3 qubits")
     rev_ops, terms = build_reverse(low, _op_blobs(low), want)
     rev = LoweredTape(rev_ops, n_qubits)
     # patch the Golomb marks offsets now that the reverse const blob is laid out

@@ -834,6 +834,94 @@ __global__ void k_tile(const TileArgs a) {
   tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
 }
 
+// ---- whole-circuit adjoint in LDS (n <= 13) ----------------------------------------------
+// One workgroup per sample keeps psi AND lambda in LDS: forward circuit (fused gate groups),
+// lambda = (sum_k w_k Z_k) psi, then for every gate of the reversed, daggered tape the
+// generator overlap and the inverse gate on both vectors.  No HBM traffic beyond the angle
+// tables and the gradient row; one launch instead of ~(2 gates + 2 angles) launches.
+struct AdjTermDev {
+  int32_t out_slot;
+  uint32_t xmask, zmask, pmask;  // bit positions
+  int32_t n_y;
+  float coef;
+  int32_t marks_off;             // offset in the reverse plan's const blob, or -1
+  int32_t pad;
+};
+struct AdjLdsArgs {
+  TileArgs fwd;                  // the forward plan's whole-state stage
+  const LoweredOp *rev_ops;      // reverse tape, global bit positions, one gate each
+  const AdjTermDev *terms;
+  int n_rev;
+  const float *rev_mats;
+  uint32_t rev_mat_floats;
+  const float *rev_angles;
+  int rev_n_slots;
+  const float *rev_consts;
+  const float *weights;          // [B][n_obs]
+  uint32_t zmask[QMLE_MAX_QUBITS];
+  int n_obs;
+  float *grad;
+  int n_grad_slots;
+};
+
+template <bool DENSE4>
+__global__ void k_adjoint_lds(const AdjLdsArgs a) {
+  extern __shared__ float4 smem4[];
+  const int T = a.fwd.T;
+  float2 *psi = reinterpret_cast<float2 *>(smem4);
+  float2 *lam = psi + (1u << T);
+  float *red = reinterpret_cast<float *>(lam + (1u << T));
+  OpSlot *slots = reinterpret_cast<OpSlot *>(red + 288);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.y;
+  const uint32_t cnt = 1u << T;
+
+  if (a.fwd.slots_in_lds) tile_stage_slots(a.fwd, slots, b);
+  for (uint32_t e = tid; e < cnt; e += nt) psi[e] = make_float2(0.f, 0.f);
+  __syncthreads();
+  if (tid == 0) psi[sw(0)] = make_float2(1.f, 0.f);
+  __syncthreads();
+  tile_compute<DENSE4, false>(a.fwd, psi, slots, b);
+
+  const float *w = a.weights + (size_t)b * a.n_obs;
+  for (uint32_t i = tid; i < cnt; i += nt) {
+    float d = 0.f;
+    for (int o = 0; o < a.n_obs; ++o) d += (__popc(i & a.zmask[o]) & 1) ? -w[o] : w[o];
+    const float2 v = psi[sw(i)];
+    lam[sw(i)] = make_float2(d * v.x, d * v.y);
+  }
+  __syncthreads();
+
+  const float *mrow = a.rev_mats + (size_t)b * a.rev_mat_floats;
+  const float *ang = a.rev_angles + (size_t)b * a.rev_n_slots;
+  for (int r = 0; r < a.n_rev; ++r) {
+    const AdjTermDev t = a.terms[r];
+    if (t.out_slot >= 0) {
+      const float *marks = t.marks_off >= 0 ? a.rev_consts + t.marks_off : nullptr;
+      float re = 0.f, im = 0.f;
+      for (uint32_t i = tid; i < cnt; i += nt) {
+        if ((i & t.pmask) != t.pmask) continue;
+        const uint32_t j = i ^ t.xmask;
+        const float2 l = lam[sw(i)], p = psi[sw(j)];
+        const float sgn = marks ? marks[i] : ((__popc(j & t.zmask) & 1) ? -1.f : 1.f);
+        re += sgn * (l.x * p.x + l.y * p.y);
+        im += sgn * (l.x * p.y - l.y * p.x);
+      }
+      const float sr = block_sum(re, red);
+      const float si = block_sum(im, red);
+      if (tid == 0) {
+        const int q = t.n_y & 3;
+        const float v = q == 0 ? si : q == 1 ? sr : q == 2 ? -si : -sr;
+        a.grad[(size_t)b * a.n_grad_slots + t.out_slot] = t.coef * v;
+      }
+    }
+    const LoweredOp o = a.rev_ops[r];
+    lds_apply(psi, T, o, mrow, a.rev_consts, ang);
+    lds_apply(lam, T, o, mrow, a.rev_consts, ang);
+    __syncthreads();
+  }
+}
+
 // ---- prefetching tile kernel ------------------------------------------------------------
 // EXPERIMENT, opt-in (QMLE_PLAN_PREFETCH): in k_tile a workgroup's HBM traffic stops while it
 // runs its gate groups.  k_tile_pf gives every workgroup a contiguous run of tiles and TWO
@@ -1902,9 +1990,9 @@ int tile_threads(int T) {  // one register-tile work item (16 amplitudes) per th
   return t;
 }
 
-int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
-                const float *angles, int batch, bool init_zero, int meas, void *out,
-                const uint32_t *obs_masks, int n_obs, hipStream_t stream) {
+static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *states,
+                               const float *mats, const float *angles, bool init_zero, int meas,
+                               void *out, const uint32_t *obs_masks, int n_obs) {
   TileArgs a;
   std::memset(&a, 0, sizeof(a));
   a.states = states;
@@ -1928,6 +2016,13 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
   if (obs_masks) std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
   a.op_begin = st.op_begin;
+  return a;
+}
+
+int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
+                const float *angles, int batch, bool init_zero, int meas, void *out,
+                const uint32_t *obs_masks, int n_obs, hipStream_t stream) {
+  TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs);
   a.slots_in_lds = tile_lds_bytes(st.T, st.L, a.n_ops) <= 160 * 1024 ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   static bool attr_set = false;
@@ -2557,7 +2652,7 @@ static int adj_blocks(int n) {
   if (b > 1024) b = 1024;
   return (int)b;
 }
-struct AdjLayout { size_t states, lam, mats, ang2, partial, fwd_ws, total; };
+struct AdjLayout { size_t states, lam, mats, ang2, partial, fwd_ws, lds_ops, lds_terms, lds_fmats, total; };
 static AdjLayout adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
   AdjLayout L;
   const size_t sb = (size_t)batch * ((size_t)8 << fwd->n);
@@ -2567,7 +2662,10 @@ static AdjLayout adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batc
   L.ang2 = L.mats + ws_mats_bytes(rev, 2 * batch);
   L.partial = L.ang2 + align_up((size_t)2 * batch * (rev->n_slots ? rev->n_slots : 1) * sizeof(float), 256);
   L.fwd_ws = L.partial + align_up((size_t)batch * adj_blocks(fwd->n) * sizeof(float2), 256);
-  L.total = L.fwd_ws + workspace_bytes_one(fwd, batch, QMLE_MEAS_STATE, 0) + 256;
+  L.lds_ops = L.fwd_ws + workspace_bytes_one(fwd, batch, QMLE_MEAS_STATE, 0) + 256;
+  L.lds_terms = L.lds_ops + align_up(rev->lowered.size() * sizeof(LoweredOp) + 16, 256);
+  L.lds_fmats = L.lds_terms + align_up(rev->lowered.size() * sizeof(AdjTermDev) + 16, 256);
+  L.total = L.lds_fmats + ws_mats_bytes(fwd, batch) + 256;
   return L;
 }
 size_t qmle_adjoint_workspace_bytes(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
@@ -2598,6 +2696,99 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
   const AdjLayout L = adj_layout(fwd, rev, batch);
   if (workspace_bytes < mis + L.total) return QMLE_ERR_WORKSPACE;
   ws += mis;
+  for (int k = 0; k < n_obs; ++k)
+    if (obs_wire_masks[k] == 0 || (n < 32 && (obs_wire_masks[k] >> n))) return QMLE_ERR_WIRE_RANGE;
+  for (int r = 0; r < n_terms; ++r)
+    if (terms[r].out_slot >= n_grad_slots) return QMLE_ERR_SLOT_RANGE;
+
+  // ---- n <= 13: psi and lambda both fit in one workgroup's LDS -> a single launch ----------
+  static const bool lds_off = std::getenv("QMLE_ADJOINT_NO_LDS") != nullptr;  // A/B switch
+  bool lds_ok = !lds_off && fwd->whole_state_lds && n <= 13 && fwd->stages.size() == 1;
+  for (const LoweredOp &o : rev->lowered) lds_ok = lds_ok && o.kind != LK_4Q;
+  if (lds_ok) {
+    rc = ensure_device_plan(fwd);
+    if (rc != QMLE_OK) return rc;
+    const Stage &fst = fwd->stages[0];
+    const int R = (int)rev->lowered.size();
+    std::vector<AdjTermDev> tdev((size_t)(R ? R : 1));
+    for (int r = 0; r < R; ++r) {
+      if (rev->lowered_src[r].size() != 1) return QMLE_ERR_INVALID_ARG;
+      const qmle_adjoint_term &t = terms[rev->lowered_src[r][0]];
+      AdjTermDev &d = tdev[r];
+      d.out_slot = t.out_slot;
+      d.xmask = wires_to_pos(t.x_wires, n);
+      d.zmask = wires_to_pos(t.z_wires, n);
+      d.pmask = wires_to_pos(t.proj_wires, n);
+      d.n_y = t.n_y;
+      d.coef = t.coef;
+      d.marks_off = t.marks_off;
+      d.pad = 0;
+      if (t.marks_off >= 0 && (size_t)t.marks_off + ((size_t)1 << n) > rev->consts.size())
+        return QMLE_ERR_INVALID_ARG;
+    }
+    LoweredOp *d_rops = (LoweredOp *)(ws + L.lds_ops);
+    AdjTermDev *d_terms = (AdjTermDev *)(ws + L.lds_terms);
+    float *fmats = (float *)(ws + L.lds_fmats);
+    float *rmats = (float *)(ws + L.mats);
+    if (R) {
+      HIPCHK(hipMemcpyAsync(d_rops, rev->lowered.data(), (size_t)R * sizeof(LoweredOp),
+                            hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(d_terms, tdev.data(), (size_t)R * sizeof(AdjTermDev),
+                            hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));  // tdev dies with this frame
+    }
+    HIPCHK(hipMemsetAsync(d_grad, 0, (size_t)batch * n_grad_slots * sizeof(float), stream));
+    if (!fwd->groups.empty()) {
+      const int ng = (int)fwd->groups.size();
+      hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, batch), dim3(64), 0, stream,
+                         fwd->dev.d_build, fwd->dev.d_groups, ng, d_angles_fwd, fwd->n_slots,
+                         fwd->dev.d_consts, fmats, fwd->mat_floats);
+    }
+    if (!rev->groups.empty()) {
+      const int ng = (int)rev->groups.size();
+      hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, batch), dim3(64), 0, stream,
+                         rev->dev.d_build, rev->dev.d_groups, ng, d_angles_rev, rev->n_slots,
+                         rev->dev.d_consts, rmats, rev->mat_floats);
+    }
+    AdjLdsArgs a;
+    a.fwd = fill_tile_args(fwd, fst, nullptr, fmats, d_angles_fwd, true, TM_STORE, nullptr,
+                           nullptr, 0);
+    const size_t lds_base = ((size_t)16 << n) + 288 * sizeof(float);
+    a.fwd.slots_in_lds = lds_base + (size_t)a.fwd.n_ops * sizeof(OpSlot) <= 160 * 1024 ? 1 : 0;
+    const size_t lds = lds_base + (a.fwd.slots_in_lds ? (size_t)a.fwd.n_ops * sizeof(OpSlot) : 0);
+    a.rev_ops = d_rops;
+    a.terms = d_terms;
+    a.n_rev = R;
+    a.rev_mats = rmats;
+    a.rev_mat_floats = rev->mat_floats;
+    a.rev_angles = d_angles_rev;
+    a.rev_n_slots = rev->n_slots;
+    a.rev_consts = rev->dev.d_consts;
+    a.weights = d_weights;
+    a.n_obs = n_obs;
+    for (int k = 0; k < n_obs; ++k) a.zmask[k] = wires_to_pos(obs_wire_masks[k], n);
+    a.grad = d_grad;
+    a.n_grad_slots = n_grad_slots;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    bool has_dense4 = false;
+    for (int g = fst.grp_begin; g < fst.grp_end; ++g) has_dense4 |= fwd->op_groups[g].kind == GK_DENSE4;
+    // all loops are strided, so the sweeps may use more threads than the 2^(n-4) register-tile
+    // work items of the forward groups: one 64-lane wave per 256 amplitudes, at least 4 waves
+    int threads = tile_threads(n);
+    if (threads < 256 && n >= 8) threads = 256;
+    if (has_dense4) hipLaunchKernelGGL(k_adjoint_lds<true>, dim3(1, batch), dim3(threads), lds, stream, a);
+    else hipLaunchKernelGGL(k_adjoint_lds<false>, dim3(1, batch), dim3(threads), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
+  if (n < 3) return QMLE_ERR_UNSUPPORTED;  // the per-gate streaming kernels move float4 pairs
   float2 *psi = (float2 *)(ws + L.states);
   float2 *lam = (float2 *)(ws + L.lam);
   float *mats = (float *)(ws + L.mats);
@@ -2612,10 +2803,7 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
   // lambda = (sum_k w_k Z..Z_k) psi
   ZSumArgs z;
   z.n_obs = n_obs;
-  for (int k = 0; k < n_obs; ++k) {
-    if (obs_wire_masks[k] == 0 || (n < 32 && (obs_wire_masks[k] >> n))) return QMLE_ERR_WIRE_RANGE;
-    z.mask[k] = wires_to_pos(obs_wire_masks[k], n);
-  }
+  for (int k = 0; k < n_obs; ++k) z.mask[k] = wires_to_pos(obs_wire_masks[k], n);
   hipLaunchKernelGGL(k_zsum_apply, dim3(grid_for(D / 2, 256, 4096), batch), dim3(256), 0, stream,
                      (const float4 *)psi, (float4 *)lam, n, d_weights, z);
   HIPCHK(hipMemsetAsync(d_grad, 0, (size_t)batch * n_grad_slots * sizeof(float), stream));
@@ -2636,7 +2824,6 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     const int r = st.src_ops[0];
     const qmle_adjoint_term &t = terms[r];
     if (t.out_slot >= 0) {
-      if (t.out_slot >= n_grad_slots) return QMLE_ERR_SLOT_RANGE;
       AdjTerm a;
       a.xmask = wires_to_pos(t.x_wires, n);
       a.zmask = wires_to_pos(t.z_wires, n);

@@ -189,3 +189,34 @@ def test_golomb_encoding_adjoint_input_gradient():
     fd_x = (f(th, 0.9 + e) - f(th, 0.9 - e)) / (2 * e)
     fd_0 = (f(th + [e, 0], 0.9) - f(th - [e, 0], 0.9)) / (2 * e)
     assert abs(gx - fd_x) < 2e-3 and abs(g[0] - fd_0) < 2e-3
+
+
+def test_adjoint_tiny_registers_and_streaming_path(monkeypatch):
+    """n = 1, 2 (LDS-resident sweep only) and the per-gate streaming sweep forced at n = 6
+    (QMLE_ADJOINT_NO_LDS is read once per process, so the streaming path is exercised through
+    a 15-qubit circuit instead)."""
+    def one(th):
+        op.RX(th[0], wires=0); op.RY(th[1], wires=0); op.RZ(th[2], wires=0); op.RX(th[3], wires=0)
+
+    s = Script(one, n_qubits=1)
+    obs = [op.PauliZ(wires=0, record=False)]
+    th = np.array([0.3, 1.1, -0.7, 2.0])
+    (jac,) = s.gradient(obs, args=(th,))
+    (g,) = s.vjp(obs, np.ones(1), args=(th,))
+    assert np.allclose(g, jac[0], atol=2e-6)
+
+    def big(th):
+        for q in range(15):
+            op.RY(th[q], wires=q)
+        for q in range(14):
+            op.CRX(th[15 + q], wires=[q, q + 1])
+        op.ControlledPhaseShift(th[29], wires=[14, 0]); op.RXX(th[30], wires=[3, 9])
+        op.Rot(th[31], th[32], th[33], wires=7)
+
+    s = Script(big, n_qubits=15)
+    obs = [op.PauliZ(wires=q, record=False) for q in (0, 7, 14)]
+    th = np.random.default_rng(3).uniform(0, 6.28, 34)
+    (jac,) = s.gradient(obs, args=(th,))
+    w = np.array([0.5, -1.0, 2.0])
+    (g,) = s.vjp(obs, w, args=(th,))
+    assert np.allclose(g, w @ jac, atol=4e-6)
