@@ -101,3 +101,46 @@ def test_gate_mode_training_1000_epochs_within_reference_budget():
     print(f"999 epochs: {elapsed:.1f} s, cost {c0:.4f} -> {c1:.5f}")
     assert elapsed < 120, "Time limit of 120 seconds exceeded"
     assert c1 < 0.2 * c0
+
+
+def test_torch_autograd_bridge_trains_with_torch_optim():
+    """``differentiable(model)``: loss.backward() runs one adjoint sweep; gradients equal the
+    parameter-shift chain rule, torch.optim.Adam fits the sine (the jax.grad + optax workflow of
+    test_model.py:20-70,1297-1333 on PyTorch)."""
+    import torch
+
+    from qml_essentials_amd.torch_bridge import differentiable
+
+    model = Model(n_qubits=3, n_layers=2, circuit_type="Circuit_19", trainable_frequencies=True)
+    f = differentiable(model)
+    xs = np.linspace(-np.pi, np.pi, 9)
+    x = torch.tensor(xs.reshape(-1, 1), dtype=torch.float32, device="cuda", requires_grad=True)
+    y = torch.sin(torch.tensor(xs, dtype=torch.float32, device="cuda"))
+    params = torch.tensor(np.asarray(model.params[0]), dtype=torch.float32, device="cuda",
+                          requires_grad=True)
+    enc = torch.tensor(np.asarray(model.enc_params), dtype=torch.float32, device="cuda",
+                       requires_grad=True)
+    loss = ((f(params, x, enc, force_mean=True) - y) ** 2).mean()
+    loss.backward()
+    # reference gradient: parameter-shift Jacobians + chain rule on the host
+    p_np, e_np = params.detach().cpu().numpy(), enc.detach().cpu().numpy()
+    pred = np.asarray(model(params=p_np, inputs=xs, enc_params=e_np, force_mean=True))
+    dl = 2.0 * (pred - np.sin(xs)) / len(xs)
+    for wrt, t in (("params", params), ("enc_params", enc)):
+        jac = np.asarray(model.gradient(params=p_np, inputs=xs, enc_params=e_np, wrt=wrt,
+                                        force_mean=True)).reshape(len(xs), -1)
+        assert np.allclose(t.grad.cpu().numpy().reshape(-1), dl @ jac, atol=1e-5), wrt
+    jx = np.asarray(model.gradient(params=p_np, inputs=xs, enc_params=e_np, wrt="inputs",
+                                   force_mean=True)).reshape(len(xs))
+    assert np.allclose(x.grad.cpu().numpy().reshape(-1), dl * jx, atol=1e-5)
+    assert float(enc.grad.abs().max()) > 1e-6        # test_trainable_frequencies
+
+    opt = torch.optim.Adam([params, enc], lr=0.05)
+    first = None
+    for _ in range(80):
+        opt.zero_grad()
+        loss = ((f(params, x.detach(), enc, force_mean=True) - y) ** 2).mean()
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+    assert float(loss.detach()) < 0.1 * first, (first, float(loss.detach()))
