@@ -1,0 +1,181 @@
+"""The reference's ``tests/test_model.py`` cases that need no JAX / pulse machinery, run
+against this backend with the reference's own inputs and assertions (file:line per test)."""
+import numpy as np
+import pytest
+
+from qml_essentials_amd.ansaetze import Ansaetze
+from qml_essentials_amd.gates import Gates
+from qml_essentials_amd.model import Model
+from qml_essentials_amd.utils import key
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transform_input():
+    """test_model.py:73-103: enc_params scale the input; a replaced ``transform_input``
+    (arccos) is honoured -> <Z> of RX(arccos x)|0> is x."""
+    x = np.linspace(-1, 1, 8)
+    model = Model(n_qubits=1, n_layers=1, circuit_type="No_Ansatz", encoding="RX",
+                  data_reupload=False)
+    inputs, enc = np.array([[0.5, -0.2]]), np.array([2.0, 3.0])
+    assert np.allclose(model.transform_input(inputs, enc), enc * inputs)
+    model.transform_input = lambda inputs, enc_params: np.arccos(inputs)
+    assert np.allclose(x, model(model.params, x, pulse_params=None), atol=1e-6)
+
+
+def test_batching_density_every_ansatz():
+    """test_model.py:107-130: batched == sequential density for a parameter batch."""
+    for ansatz in Ansaetze.get_available(parameterized_only=True):
+        model = Model(n_qubits=2, n_layers=1, circuit_type=ansatz.__name__)
+        model.initialize_params(key(1000), repeat=3)
+        params = model.params
+        res = np.stack([model(params=params[i], execution_type="density") for i in range(3)])
+        assert res.shape == (3, 4, 4)
+        assert np.allclose(res, model(params=params, execution_type="density"), atol=1e-6), \
+            ansatz.__name__
+
+
+def test_repeat_batch_axis():
+    """test_model.py:134-150: zipped (not crossed) parameter / input batches."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19",
+                  repeat_batch_axis=[False, True, True])
+    k = model.initialize_params(key(1000), repeat=10)
+    res = model(inputs=k.generator().uniform(size=(10, 1)))
+    assert res.shape == (10, 2)
+
+
+def test_large_parameter_batch_is_deterministic():
+    """test_model.py:154-191 (multiprocessing_expval): 40000 parameter sets, 6 qubits, 6
+    layers; two evaluations agree exactly."""
+    outs = []
+    for _ in range(2):
+        model = Model(n_qubits=6, n_layers=6, circuit_type="Circuit_19")
+        model.initialize_params(key(1000), repeat=40000)
+        outs.append(model(params=model.params, execution_type="expval"))
+    assert outs[0].shape == outs[1].shape == (40000, 6) and (outs[0] == outs[1]).all()
+
+
+def test_random_key():
+    """test_model.py:195-202."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", random_seed=1000)
+    key_a = model.random_key
+    key_b = model.initialize_params(key_a, repeat=10)
+    assert repr(key_a) != repr(key_b) and repr(key_b) != repr(model.random_key)
+
+
+@pytest.mark.parametrize("sp", [Gates.H, [Gates.H, Gates.H], "H", ["H", "H"], None])
+def test_state_preparation(sp):
+    """test_model.py:206-236."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", state_preparation=sp,
+                  remove_zero_encoding=False)
+    out = model(model.params)
+    assert out.shape == (2,) and np.all(np.abs(out) <= 1 + 1e-6)
+
+
+@pytest.mark.parametrize("init", ["random", "zeros", "zero-controlled", "pi-controlled", "pi"])
+def test_initialization_strategies_with_shots(init):
+    """test_model.py:532-567 (shots=1024, output_qubit=0)."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", data_reupload=True,
+                  initialization=init, output_qubit=0, shots=1024)
+    out = model(model.params, inputs=None, noise_params=None, execution_type="expval")
+    assert np.ndim(out) == 0 and -1 <= float(out) <= 1
+    if init == "zeros":
+        assert float(out) == 1.0          # identity circuit: every shot reads 0
+
+
+@pytest.mark.parametrize("inputs", [0.0, np.zeros(5), np.arange(5)])
+@pytest.mark.parametrize("rze", [True, False])
+def test_inputs(inputs, rze):
+    """test_model.py:571-594: scalar / zero / range inputs with and without zero-encoding
+    removal give the same numbers."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", remove_zero_encoding=rze)
+    out = model(model.params, inputs=inputs, noise_params=None, execution_type="expval")
+    other = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", remove_zero_encoding=not rze)
+    assert np.allclose(out, other(model.params, inputs=inputs), atol=1e-6)
+
+
+def test_re_initialization():
+    """test_model.py:598-615."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19",
+                  initialization_domain=[-2 * np.pi, 0], random_seed=1000)
+    assert model.params.max() <= 0
+    before = model.params.copy()
+    model.initialize_params(key(1001))
+    assert not np.allclose(model.params, before, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (1, 3), (2, 1), (3, 2), (20, 1), None])
+def test_multi_input(shape):
+    """test_model.py:744-793: one encoding gate per feature, shots = 1024, batch axis first."""
+    rng = np.random.default_rng(0)
+    inputs = None if shape is None else 2 * np.pi * rng.random(shape)
+    encoding = Gates.RX if inputs is None else [Gates.RX for _ in range(inputs.shape[1])]
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", data_reupload=True,
+                  initialization="random", encoding=encoding, output_qubit=0, shots=1024)
+    out = model(model.params, inputs=inputs, noise_params=None, execution_type="expval")
+    if inputs is None:
+        assert np.ndim(out) == 0
+    elif np.ndim(out) > 0:
+        assert out.shape[0] == inputs.shape[0]
+    else:
+        assert inputs.shape[0] == 1
+
+
+NOISE = {"BitFlip": 0.1, "PhaseFlip": 0.2, "AmplitudeDamping": 0.3, "PhaseDamping": 0.4,
+         "Depolarizing": 0.5, "MultiQubitDepolarizing": 0.6}
+
+
+@pytest.mark.parametrize("noise,et", [(None, "density"), (NOISE, "density"), (None, "expval")])
+def test_local_state(noise, et):
+    """test_model.py:847-924: noise_params / execution_type set on the object or in the call
+    persist on the model."""
+    def fresh():
+        return Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", data_reupload=True,
+                     initialization="random", output_qubit=0)
+
+    model = fresh()
+    assert model.noise_params is None and model.execution_type == "expval"
+    expect = None if noise is None else {**{k: (None if k == "ThermalRelaxation" else 0.0) for k in (
+        "BitFlip", "PhaseFlip", "Depolarizing", "MultiQubitDepolarizing", "AmplitudeDamping",
+        "PhaseDamping", "GateError", "ThermalRelaxation", "StatePreparation", "Measurement")},
+        **noise}
+    model.noise_params = None if noise is None else dict(noise)
+    model.execution_type = et
+    model(model.params, inputs=None, noise_params=None)
+    assert model.noise_params == expect and model.execution_type == et
+    model = fresh()
+    out = model(model.params, inputs=None, noise_params=None if noise is None else dict(noise),
+                execution_type=et)
+    assert model.noise_params == expect and model.execution_type == et
+    if et == "density":
+        assert out.shape == (2, 2) and np.isclose(np.trace(out).real, 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("inputs,et,oq,shots,fm,shape", [
+    (np.array(0.1), "expval", [0, 1], None, False, (2,)),
+    (np.array([0.1, 0.2, 0.3]), "expval", [0, 1], None, False, (3, 2)),
+    (np.array([0.1, 0.2, 0.3]), "expval", [0, 1], None, True, (3,)),
+    (None, "density", -1, None, False, (4, 4)),
+    (np.array([0.1, 0.2, 0.3]), "density", -1, None, False, (3, 4, 4)),
+    (np.array([0.1, 0.2, 0.3]), "density", 0, None, False, (3, 2, 2)),
+    (np.array([0.1, 0.2, 0.3]), "probs", -1, 1024, False, (3, 2, 2)),
+    (np.array([0.1, 0.2, 0.3]), "probs", 0, 1024, False, (3, 2)),
+    (np.array([0.1, 0.2, 0.3]), "probs", [0, 1], 1024, True, (3, 2)),
+])
+def test_output_shapes(inputs, et, oq, shots, fm, shape):
+    """test_model.py:928-1053."""
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_19", data_reupload=True,
+                  initialization="random", output_qubit=oq, shots=shots)
+    out = model(model.params, inputs=inputs, force_mean=fm, noise_params=None, execution_type=et)
+    assert out.shape == shape
+
+
+def test_parity():
+    """test_model.py:1057-1079 plus the value: <Z0 Z1> of the product state = <Z0><Z1>."""
+    a = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_1", output_qubit=[[0, 1]])
+    b = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_1", output_qubit=-1)
+    ra = a(params=a.params, inputs=None, force_mean=True)
+    rb = b(params=a.params, inputs=None, force_mean=True)
+    assert not np.allclose(ra, rb)
+    zs = b(params=a.params, inputs=None)
+    assert np.isclose(ra, zs[0] * zs[1], atol=1e-6)      # Circuit_1 has no entangling gate

@@ -33,5 +33,5 @@ if __name__ == "__main__":
     F = N.plan_flags
     run(24, 32, 0, "auto n24")
     run(24, 32, F(no_absorb=True), "auto n24, no folding")
-    for T, L in ((11, 4), (11, 3), (10, 3), (12, 3), (12, 4), (13, 5)):
+    for T, L in ((12, 4), (13, 4), (13, 5), (14, 4), (14, 5), (14, 6)):
         run(24, 32, F(tile_bits=T, low_bits=L), f"T{T} L{L}")
