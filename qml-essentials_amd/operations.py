@@ -277,6 +277,14 @@ def conj_lower(op_: "Operation", n_qubits: int, offset: int):
     return ("MAT1" if len(wires) == 1 else "MAT2"), wires, [], blob
 
 
+def prod(*ops: "Operation") -> "Operation":
+    """Generalised product of operations: Kronecker product on disjoint wires, matrix product
+    where wires overlap (module-level form of :meth:`Operation.prod`)."""
+    if not ops:
+        raise ValueError("prod() needs at least one operation")
+    return ops[0].prod(*ops[1:])
+
+
 def embed_matrix(mat: np.ndarray, wires: Sequence[int], all_wires: Sequence[int]) -> np.ndarray:
     """Embed ``mat`` (on ``wires``) into the space spanned by ``all_wires`` (first = MSB)."""
     n, k = len(all_wires), len(wires)

@@ -179,3 +179,30 @@ def test_parity():
     assert not np.allclose(ra, rb)
     zs = b(params=a.params, inputs=None)
     assert np.isclose(ra, zs[0] * zs[1], atol=1e-6)      # Circuit_1 has no entangling gate
+
+
+def test_gate_operations_in_circuits():
+    """test_jaqsi.py:1386-1404,1437-1450,1575-1588: dagger / power / scaled operators / product
+    observables through Script.execute."""
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd.script import Script
+
+    def undo():
+        op.RX(0.5, wires=0)
+        op.RX(0.5, wires=0).dagger()
+
+    z0 = [op.PauliZ(0, record=False)]
+    assert np.allclose(Script(undo).execute(type="expval", obs=z0), 1, atol=1e-6)
+    assert np.allclose(Script(lambda: op.PauliX(wires=0).power(2)).execute(type="expval", obs=z0), 1,
+                       atol=1e-6)
+    half_x = [op.Operation(wires=0, matrix=0.5 * np.asarray(op.PauliX(0, record=False).matrix),
+                           record=False)]
+    assert np.allclose(Script(lambda: op.H(wires=0)).execute(type="expval", obs=half_x), 0.5,
+                       atol=1e-6)
+
+    def plus_plus():
+        op.H(wires=0)
+        op.H(wires=1)
+
+    xx = op.prod(op.PauliX(wires=0, record=False), op.PauliX(wires=1, record=False))
+    assert np.allclose(Script(plus_plus, n_qubits=2).execute(type="expval", obs=[xx]), 1.0, atol=1e-6)
