@@ -1,0 +1,47 @@
+"""HBM model + batch chunking (``memory.py``): the properties the reference asserts for its host
+RAM model in ``tests/test_jaqsi.py:1711-1816`` that carry over to the engine's HBM model."""
+import numpy as np
+import pytest
+
+from qml_essentials_amd import memory
+
+
+@pytest.fixture(autouse=True)
+def _free_hbm(monkeypatch):
+    monkeypatch.setattr(memory, "available_memory_bytes", lambda: 200 * 1024**3)
+
+
+def test_estimate_peak_bytes_basic_and_scaling():
+    e1 = memory.estimate_peak_bytes(5, 1, "state", False)
+    e100 = memory.estimate_peak_bytes(5, 100, "state", False)
+    assert 0 < e1 < e100 <= e1 * 200
+    assert memory.estimate_peak_bytes(5, 100, "density", True) > e100
+    assert memory.estimate_peak_bytes(19, 10, "state", False) > \
+        memory.estimate_peak_bytes(14, 10, "state", False) * 10
+    # a noisy tape materialises vec(rho) per sample even when only probabilities come back
+    assert memory.estimate_peak_bytes(8, 5, "probs", True) > memory.estimate_peak_bytes(8, 5, "probs", False)
+
+
+def test_compute_chunk_size():
+    assert memory.compute_chunk_size(2, 10, "state", False) == 10
+    c = memory.compute_chunk_size(n_qubits=30, batch_size=1000000, type="density",
+                                  use_density=True, n_obs=0)
+    assert 1 <= c < 1000000
+    assert memory.compute_chunk_size(n_qubits=30, batch_size=100, type="density", use_density=True,
+                                     n_obs=0, memory_fraction=0.00001) >= 1
+    # expval at <= 14 qubits never leaves LDS: a huge batch still fits
+    assert memory.compute_chunk_size(6, 209498, "expval", False, 6, n_ops=30) == 209498
+    # ... while statevector outputs of the same batch at 24 qubits do not (128 MiB each)
+    assert memory.compute_chunk_size(24, 4096, "state", False) < 4096
+
+
+def test_execute_chunked_concatenates_uneven_chunks():
+    calls = []
+
+    def run(s, e):
+        calls.append((s, e))
+        return np.arange(s, e, dtype=np.float32)[:, None] * np.ones((1, 3), dtype=np.float32)
+
+    out = memory.execute_chunked(run, 7, 3)          # chunks of 3, 3, 1
+    assert calls == [(0, 3), (3, 6), (6, 7)] and out.shape == (7, 3)
+    assert np.array_equal(out[:, 0], np.arange(7))
