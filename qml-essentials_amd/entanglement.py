@@ -161,3 +161,41 @@ class Entanglement:
                                       kwargs)
         p0 = N.marginal_probs(states, list(range(n)))[:, 0].cpu().numpy()
         return float((1 - p0).mean())
+
+    @classmethod
+    def concentratable_entanglement_estimation(cls, model: Model, n_samples: int, random_key=None,
+                                               scale: bool = False, **kwargs: Any) -> float:
+        """Concentratable entanglement from Bell-basis measurements on TWO copies (2n qubits
+        instead of the swap test's 3n; ``entanglement.py:579-684``):
+        ``1 - <(1/2^n) prod_i (I + SWAP_i)>``.  After CX(i, i+n) H(i) every ``I + SWAP_i`` is
+        ``diag(2, 2, 2, 0)``, so the expectation value is the probability that no pair
+        ``(i, i+n)`` reads ``11`` -- evaluated matrix-free on the 4^n probabilities."""
+        n = model.n_qubits
+        if scale:
+            n_samples = (2**n) * n_samples
+
+        def bell_basis(params, inputs, pulse_params=None, random_key=None, **kw):
+            def vari():
+                model._variational(params, inputs, **kw)
+
+            copy_to_tape(vari, offset=0)
+            copy_to_tape(vari, offset=n)
+            for i in range(n):
+                op.CX(wires=[i, i + n])
+                op.H(wires=i)
+
+        params = cls._sample_params(model, n_samples, random_key)
+        inputs = model._inputs_validation(kwargs.get("inputs", None))
+        states = cls._register_states(js.Script(f=bell_basis, n_qubits=2 * n), params, inputs,
+                                      kwargs)
+        x = np.arange(4**n)
+        no_11 = (((x >> n) & x & (2**n - 1)) == 0).astype(np.float32)
+        vals = []
+        for b0 in range(0, states.shape[0], 4096):
+            probs = N.probs(states[b0:b0 + 4096])
+            vals.append(N.probs_diag_expval(probs, [(list(range(2 * n)), no_11)])[:, 0])
+        torch = N.require_gpu()
+        ent = 1.0 - torch.cat(vals).double()
+        log.debug("Variance of measure: %s", float(ent.var()) if ent.numel() > 1 else 0.0)
+        return float(ent.mean())
+
