@@ -476,3 +476,19 @@ def test_concentratable_entanglement_estimation_equals_swap_test():
                Entanglement.concentratable_entanglement_estimation):
         assert 0.0 <= fn(deepcopy(model), n_samples=None) <= 1.0
         assert 0.0 <= fn(deepcopy(model), n_samples=10, scale=True) <= 1.0
+
+
+def test_expressibility_scaling_and_haar_cache():
+    """test_expressiblity.py:83-111 (cached == uncached Haar integral) and :192-215 (scale=True
+    gives n_bins * n_qubits = 8 bins)."""
+    from qml_essentials_amd.expressibility import Expressibility
+    from qml_essentials_amd.model import Model
+
+    _, ya = Expressibility.haar_integral(n_qubits=2, n_bins=10, cache=True)
+    _, yb = Expressibility.haar_integral(n_qubits=2, n_bins=10, cache=False)
+    assert abs(float(np.mean(Expressibility.kullback_leibler_divergence(ya, yb)))) < 1e-3
+    model = Model(n_qubits=2, n_layers=1, circuit_type="Circuit_1")
+    _, z = Expressibility.state_fidelities(n_bins=4, n_samples=10, model=model, scale=True)
+    assert z.shape == (8,)
+    _, y = Expressibility.haar_integral(n_qubits=model.n_qubits, n_bins=4, cache=False, scale=True)
+    assert y.shape == (8,)
