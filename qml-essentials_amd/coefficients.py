@@ -9,8 +9,9 @@ expectation values is done with NumPy on the host.
 ``FCC`` (Fourier-coefficient correlation, ``coefficients.py:966-1650``) sits downstream:
 its cost is again the ``B_I x B_P`` batch of circuit evaluations (grid points x parameter
 samples) on the engine; the correlation of the resulting ``(n_freq, n_samples)`` matrix is
-small dense linear algebra done here on the host.  ``FourierTree`` (analytic) and
-``Datasets`` are out of scope.
+small dense linear algebra done here on the host.  ``Datasets`` generates the synthetic
+Fourier-series targets the reference trains on (``coefficients.py:1652-1788``).
+``FourierTree`` (analytic) is out of scope.
 """
 from __future__ import annotations
 
@@ -333,3 +334,39 @@ class FCC:
         assert fp.shape[0] == m.shape[0], (
             "Correlation matrix size must match the number of Fourier coefficients.")
         return fp * m[:, None] * m[None, :]
+
+
+class Datasets:
+    """Synthetic training targets: a random real Fourier series on the model's own spectrum."""
+
+    @classmethod
+    def generate_fourier_series(cls, random_key, model: Model, coefficients_min: float = 0.0,
+                                coefficients_max: float = 1.0, zero_centered: bool = False):
+        """``[x, f(x), c]``: grid points ``(*degree, D)``, series values ``(*degree)`` and the
+        (conjugate-symmetric, fftshift-ordered) coefficients ``(*degree)`` with
+        ``fftshift(fftn(f)) == c`` (``coefficients.py:1654-1757``).  The flattened spectrum
+        is ``[conj(c_M..c_1), c_0, c_1..c_M]`` with ``c_0`` real (or 0), drawn by
+        :meth:`uniform_circle`."""
+        D = model.n_input_feat
+        grid = np.stack(np.meshgrid(*[np.arange(0, 2 * np.pi, 2 * np.pi / d)
+                                      for d in model.degree])).T.reshape(-1, D)
+        freqs = np.stack(np.meshgrid(*[np.asarray(f) for f in model.frequencies])).T.reshape(-1, D)
+        half = cls.uniform_circle(random_key, size=math.prod(model.degree) // 2 + 1,
+                                  low=coefficients_min, high=coefficients_max)
+        half[0] = 0.0 if zero_centered else half[0].real
+        coeffs = np.concatenate([np.conj(half[1:][::-1]), half])
+        values = np.real((np.exp(1j * (grid @ freqs.T)) * coeffs).sum(axis=1) / coeffs.size)
+        shape = tuple(model.degree)
+        return [grid.reshape(*shape, -1), values.reshape(shape), coeffs.reshape(shape)]
+
+    @classmethod
+    def uniform_circle(cls, random_key, size, low: float = 0.0, high: float = 1.0) -> np.ndarray:
+        """Complex numbers uniform on the disc / annulus: sqrt(U[low, high]) e^{2 pi i U}
+        (``coefficients.py:1759-1788``)."""
+        from .utils import as_key
+
+        size = (size,) if isinstance(size, (int, np.integer)) else tuple(np.asarray(size).tolist())
+        k_r, k_phi = as_key(random_key).split()
+        r = np.sqrt(k_r.generator().uniform(low, high, size=size))
+        return r * np.exp(2j * np.pi * k_phi.generator().uniform(size=size))
+

@@ -92,3 +92,33 @@ def test_mask_and_flat_frequencies():
     assert flat.shape == (9, 2) and keep.tolist() == [4, 5, 7, 8]
     assert flat[keep].tolist() == [[0, 0], [0, 1], [1, 0], [1, 1]]
     assert FCC.calculate_fcc(np.array([[np.nan, -0.5], [0.25, np.nan]])) == 0.375
+
+
+@pytest.mark.parametrize("n_feat,strategy,cmin,cmax,zero", [
+    (2, "hamming", 0.0, 1.0, False), (3, "hamming", 0.0, 1.0, False),
+    (1, "hamming", 0.1, 0.9, False), (1, "hamming", 0.0, 1.0, True),
+    (1, "binary", 0.0, 1.0, False), (1, "ternary", 0.0, 1.0, False)])
+def test_fourier_series_dataset(n_feat, strategy, cmin, cmax, zero):
+    """test_coefficients.py:1205-1330: shapes, FFT consistency, symmetry and coefficient range
+    of ``Datasets.generate_fourier_series`` (host only)."""
+    from qml_essentials_amd.ansaetze import Encoding
+    from qml_essentials_amd.coefficients import Datasets
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.utils import key
+
+    model = Model(n_qubits=2, n_layers=1, encoding=Encoding(strategy, ["RY"] * n_feat))
+    k = key(1000)
+    for _ in range(20):
+        x, f, c = Datasets.generate_fourier_series(k, model=model, coefficients_min=cmin,
+                                                   coefficients_max=cmax, zero_centered=zero)
+        k, _ = k.split()
+        c_hat = np.fft.fftshift(np.fft.fftn(f, axes=list(range(model.n_input_feat))))
+        assert np.allclose(c, c_hat, atol=1e-6)
+        assert x.shape == (*model.degree, model.n_input_feat)
+        assert f.shape == tuple(model.degree) == c.shape
+        flat = c.reshape(-1)
+        assert np.allclose(flat, np.conj(flat[::-1]), atol=1e-12)       # real-valued series
+        mid = flat[flat.size // 2]
+        assert abs(mid.imag) < 1e-12 and (not zero or mid == 0)
+        mags = np.abs(np.delete(flat, flat.size // 2)) ** 2
+        assert mags.min() >= cmin - 1e-9 and mags.max() <= cmax + 1e-9

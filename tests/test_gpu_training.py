@@ -71,12 +71,11 @@ def test_gate_mode_training_1000_epochs_within_reference_budget():
     here) and must actually learn."""
     import time
 
+    from qml_essentials_amd.coefficients import Datasets
+
     model = Model(n_qubits=3, n_layers=1, circuit_type="Circuit_19")
-    deg = model.degree[0]
-    xs = np.linspace(0, 2 * np.pi, deg, endpoint=False)
-    rng = np.random.default_rng(0)
-    c = rng.uniform(-0.3, 0.3, size=(deg // 2 + 1,))
-    ys = sum(ck * np.cos(k * xs) for k, ck in enumerate(c)) / 2
+    xs, ys, _ = Datasets.generate_fourier_series(random_key=model.random_key, model=model)
+    xs = xs.reshape(-1)
 
     def predict(p):
         return np.asarray(model(params=p, inputs=xs, execution_type="expval", force_mean=True))
