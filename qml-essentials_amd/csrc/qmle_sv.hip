@@ -94,6 +94,37 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   return t;
 }
 
+// Wave-level reduce-scatter of N <= 64 per-lane values: afterwards lane l holds the wave total of
+// value l (lanes >= N hold garbage-free zeros).  Step with mask m: every lane keeps the half of
+// the remaining index range selected by its own lane bit m and adds the partner's copy of it --
+// 32+16+8+4+2+1 = 63 exchanges for any N <= 64, instead of 6 per value for N separate wave sums.
+template <int N>
+__device__ __forceinline__ float wave_reduce_scatter(const float (&v)[N]) {
+  static_assert(N >= 1 && N <= 64, "at most one value per lane");
+  const int lane = threadIdx.x & (kWave - 1);
+  float a[32];
+  {
+    const bool up = lane & 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float lo = j < N ? v[j] : 0.f, hi = j + 32 < N ? v[j + 32] : 0.f;
+      if (j + 32 < N) a[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 32, kWave);
+      else if (j < N) a[j] = (up ? 0.f : lo) + __shfl_xor(up ? lo : 0.f, 32, kWave);
+      else a[j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+    const bool up = lane & m;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      const float lo = a[j], hi = a[j + m];
+      a[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, kWave);
+    }
+  }
+  return a[0];
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
@@ -631,11 +662,8 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
       for (int j = 0; j < 10; ++j) v[j] = ((tid >> j) & 1) ? -tot : tot;
       v[10] = h0; v[11] = h1; v[12] = h2; v[13] = h3; v[14] = tot;
       const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
-#pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        const float r = wave_sum(v[k]);
-        if (lane == 0) red[w * 15 + k] = r;
-      }
+      const float mine = wave_reduce_scatter<15>(v);  // lane k: this wave's total of v[k]
+      if (lane < 15) red[w * 15 + lane] = mine;
       tile_sync<RAW>();
       float *row = red + 240;  // 33 floats
       if (tid < 15) {
@@ -1815,11 +1843,8 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
   }
   const int lane = tid & (kWave - 1), w = tid / kWave;
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 37; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0) red[w * 37 + k] = v;
-  }
+  const float mine = wave_reduce_scatter<37>(acc);  // lane l: this wave's total of sum l
+  if (lane < 37) red[w * 37 + lane] = mine;
   __syncthreads();
   if (tid < 37) {
     float v = 0.f;
