@@ -70,12 +70,13 @@ def build_reverse(low: LoweredTape, blobs: List[Optional[np.ndarray]], want: Seq
             raise AdjointUnsupported(f"{name}: more than one angle per gate")
         else:
             prims.append((name, wires, slots[0] if slots else None, blob))
-    rev_ops, rev_values, terms = [], [], []
+    rev_ops, rev_src, terms = [], [], []
     for name, wires, fslot, blob in reversed(prims):
         params, out_blob, term = [], None, _term()
         bit = lambda ws: sum(1 << int(w) for w in ws)  # noqa: E731
         if fslot is not None:
             params = [-np.asarray(low.values[fslot], dtype=np.float64)]
+            rev_src.append(fslot)
         d = want[fslot] if fslot is not None else False
         if name in _ROT:
             ctrl, word = _ROT[name]
@@ -101,7 +102,16 @@ def build_reverse(low: LoweredTape, blobs: List[Optional[np.ndarray]], want: Seq
             raise AdjointUnsupported(f"no adjoint rule for {name}")
         rev_ops.append(_Lowered((name, list(wires), params, out_blob)))
         terms.append(term)
-    return rev_ops, terms
+    return rev_ops, terms, rev_src
+
+
+def patch_marks(rev: LoweredTape, terms):
+    """Golomb terms point at their marks inside the reverse tape's const blob."""
+    return [t[:6] + (off,) if (name == "DIAG_ALL" and t[0] >= 0) else t
+            for (name, _w, _s, off), t in zip(rev.ops, terms)]
+
+
+REV_FLAGS = N.PLAN_NO_FUSION | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB
 
 
 def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
@@ -109,14 +119,11 @@ def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_group
     """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
     (columns of slots that are not wanted stay zero)."""
     torch = N.require_gpu()
-    rev_ops, terms = build_reverse(low, _op_blobs(low), want)
+    rev_ops, terms, _ = build_reverse(low, _op_blobs(low), want)
     rev = LoweredTape(rev_ops, n_qubits)
-    # patch the Golomb marks offsets now that the reverse const blob is laid out
-    fixed = []
-    for (name, _w, _s, off), t in zip(rev.ops, terms):
-        fixed.append(t[:6] + (off,) if (name == "DIAG_ALL" and t[0] >= 0) else t)
+    fixed = patch_marks(rev, terms)
     fwd_plan = get_plan(low)
-    rev_plan = get_plan(rev, N.PLAN_NO_FUSION | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB)
+    rev_plan = get_plan(rev, REV_FLAGS)
     a_f = torch.from_numpy(low.angle_table(batch)).cuda()
     a_r = torch.from_numpy(rev.angle_table(batch)).cuda()
     w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()

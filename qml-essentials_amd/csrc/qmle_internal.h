@@ -131,6 +131,10 @@ struct qmle_plan {
   std::vector<qmle_op> absorbed;        // the folded gates, tape order
   double absorbed_algo_bytes = 0;       // their SURVEY 8-d bytes (credited to the last stage)
   double extra_algo_last_stage = 0;     // child side of the same number
+  // adjoint sweep in LDS: device copies of the reverse tape (global positions) and its generator
+  // terms, uploaded once per (plan, terms) -- owned by the REVERSE plan
+  void *adj_blob = nullptr;
+  uint64_t adj_hash = 0;
 };
 
 namespace qmle {

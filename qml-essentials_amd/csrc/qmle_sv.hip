@@ -2281,6 +2281,7 @@ qmle_plan *qmle_plan_expval_child(qmle_plan *plan) { return plan ? plan->expval_
 int qmle_plan_destroy(qmle_plan *plan) {
   if (!plan) return QMLE_OK;
   if (plan->expval_child) (void)qmle_plan_destroy(plan->expval_child);
+  if (plan->adj_blob) (void)hipFree(plan->adj_blob);
   if (plan->dev.blob) (void)hipFree(plan->dev.blob);
   delete plan;
   return QMLE_OK;
@@ -2751,17 +2752,28 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
       if (t.marks_off >= 0 && (size_t)t.marks_off + ((size_t)1 << n) > rev->consts.size())
         return QMLE_ERR_INVALID_ARG;
     }
-    LoweredOp *d_rops = (LoweredOp *)(ws + L.lds_ops);
-    AdjTermDev *d_terms = (AdjTermDev *)(ws + L.lds_terms);
+    // reverse tape + terms live in a blob owned by the reverse plan (uploaded when they change)
+    uint64_t hsh = 1469598103934665603ull;
+    for (size_t i = 0; i < tdev.size() * sizeof(AdjTermDev); ++i)
+      hsh = (hsh ^ ((const unsigned char *)tdev.data())[i]) * 1099511628211ull;
+    hsh ^= (uint64_t)R * 0x9E3779B97F4A7C15ull;
+    const size_t ops_b = align_up((size_t)(R ? R : 1) * sizeof(LoweredOp), 256);
+    if (!rev->adj_blob || rev->adj_hash != hsh) {
+      if (rev->adj_blob) (void)hipFree(rev->adj_blob);
+      rev->adj_blob = nullptr;
+      HIPCHK(hipMalloc(&rev->adj_blob, ops_b + (size_t)(R ? R : 1) * sizeof(AdjTermDev)));
+      if (R) {
+        HIPCHK(hipMemcpy(rev->adj_blob, rev->lowered.data(), (size_t)R * sizeof(LoweredOp),
+                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((char *)rev->adj_blob + ops_b, tdev.data(), (size_t)R * sizeof(AdjTermDev),
+                         hipMemcpyHostToDevice));
+      }
+      rev->adj_hash = hsh;
+    }
+    LoweredOp *d_rops = (LoweredOp *)rev->adj_blob;
+    AdjTermDev *d_terms = (AdjTermDev *)((char *)rev->adj_blob + ops_b);
     float *fmats = (float *)(ws + L.lds_fmats);
     float *rmats = (float *)(ws + L.mats);
-    if (R) {
-      HIPCHK(hipMemcpyAsync(d_rops, rev->lowered.data(), (size_t)R * sizeof(LoweredOp),
-                            hipMemcpyHostToDevice, stream));
-      HIPCHK(hipMemcpyAsync(d_terms, tdev.data(), (size_t)R * sizeof(AdjTermDev),
-                            hipMemcpyHostToDevice, stream));
-      HIPCHK(hipStreamSynchronize(stream));  // tdev dies with this frame
-    }
     HIPCHK(hipMemsetAsync(d_grad, 0, (size_t)batch * n_grad_slots * sizeof(float), stream));
     if (!fwd->groups.empty()) {
       const int ng = (int)fwd->groups.size();

@@ -656,7 +656,8 @@ class Model:
     def _is_cuda(x) -> bool:
         return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
-    def _forward_device(self, params, inputs, enc_params, execution_type, force_mean):
+    def _forward_device(self, params, inputs, enc_params, execution_type, force_mean,
+                        _want_call: bool = False):
         """``__call__`` for CUDA-tensor ``params`` / ``inputs``: nothing per sample happens on
         the host and the result stays on the GPU (a ``torch`` tensor).  Falls back to the host
         path (returns ``NotImplemented``) for partial-wire density / probs or non-affine angles."""
@@ -739,6 +740,8 @@ class Model:
             leaves.append(p); divs.append(1); mods.append(B_P if B_P > 1 else 1)
         if dev_inputs:
             leaves.append(x); divs.append(B_P if cross else 1); mods.append(B_I if B_I > 1 else 1)
+        if _want_call:  # (Model.vjp_device) hand the compiled call + its leaves to the caller
+            return cc, leaves, divs, mods, B
         lo, hi = 0, B
         sharded = distributed.enabled() and B >= distributed.world()[1]
         if sharded:
@@ -751,6 +754,35 @@ class Model:
         if et in ("expval", "probs") and force_mean and result.dim() > 0 and self._result_shape[0] > 1:
             result = result.mean(dim=-1)
         return result
+
+    def vjp_device(self, params, inputs, cotangent, enc_params=None, force_mean: bool = False):
+        """Device-resident adjoint gradient: ``params`` / ``inputs`` are CUDA tensors (as for
+        ``__call__``), ``cotangent`` a CUDA tensor ``(B, n_outputs)`` (``(B,)`` with
+        ``force_mean``).  Returns ``(grad_params, grad_inputs)`` as CUDA tensors shaped like the
+        arguments (None for an argument that is not a CUDA tensor): the gradient of
+        ``sum_b sum_k cotangent[b, k] * out[b, k]``.  Nothing per sample happens on the host:
+        angle table, forward pass, backward sweep and the chain rule all run on the GPU."""
+        import torch
+
+        got = self._forward_device(params, inputs, enc_params, "expval", force_mean,
+                                   _want_call=True)
+        if got is NotImplemented:
+            raise NotImplementedError("this call has no compiled device path")
+        cc, leaves, divs, mods, B = got
+        n_out = len(cc.obs)
+        cot = cotangent.to(device=leaves[0].device, dtype=torch.float32)
+        if force_mean and n_out > 1:
+            cot = (cot.reshape(B, 1) / n_out).expand(B, n_out)
+        cot = cot.reshape(B, n_out).contiguous()
+        grads = cc.vjp(leaves, divs, mods, B, cot)
+        out = {k: g for k, g in zip(cc.leaf_ids, grads)}
+        gp = out.get(0)
+        if gp is not None and self._is_cuda(params):
+            gp = gp.reshape(tuple(params.shape))
+        gx = out.get(1)
+        if gx is not None and self._is_cuda(inputs):
+            gx = gx.reshape(tuple(inputs.shape))
+        return (gp if self._is_cuda(params) else None, gx if self._is_cuda(inputs) else None)
 
     # Host arrays take the compiled device path too: the circuit is recorded once per
     # structure (what the reference's jit cache does, script.py:475-490), later calls upload

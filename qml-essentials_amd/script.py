@@ -61,7 +61,7 @@ class CompiledCall:
             if op_.lower(self.n_qubits) is None:
                 continue
             tans = op_.parameter_tangents
-            for j, _ in enumerate(op_.parameters):
+            for j in range(len(op_.lower(self.n_qubits)[2])):  # one slot per lowered parameter
                 t = tans[j] if j < len(tans) else []
                 if t is None:
                     raise NotAffine(op_.name)
@@ -85,6 +85,9 @@ class CompiledCall:
         self.d_ptr, self.d_arg, self.d_idx = i32(ptr), i32(arg), i32(idx)
         self.d_coef, self.d_const = f32(coef), f32(const)
         self.leaf_ids = leaf_ids
+        self._low, self._map = low, (ptr, arg, idx, coef)   # host copies for the adjoint path
+        self._leaf_sizes = {order[k]: int(np.prod(np.shape(args[k]))) for k in leaf_ids}
+        self._adj = None
 
     def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0):
         """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order."""
@@ -102,6 +105,65 @@ class CompiledCall:
                 return self.plan.run_parity(angles, masks)
             return simulation._general_expval(self.plan.run(angles, "state"), self.n_qubits, self.obs)
         return self.plan.run(angles, self.type)
+
+    def _adjoint_setup(self):
+        """Reverse tape, generator terms and the chain-rule matrices -- built once."""
+        import torch
+
+        from . import adjoint
+
+        ptr, arg, idx, coef = self._map
+        low = self._low
+        want = [ptr[s_ + 1] > ptr[s_] for s_ in range(low.n_slots)]
+        rev_ops, terms, rev_src = adjoint.build_reverse(low, adjoint._op_blobs(low), want)
+        rev = simulation.LoweredTape(rev_ops, self.n_qubits)
+        dev = self.d_const.device
+        mats = []
+        for k in range(len(self.leaf_ids)):  # angle_s = const_s + sum_t coef_t * leaf[arg_t][idx_t]
+            m = np.zeros((max(1, low.n_slots), self._leaf_sizes[k]), dtype=np.float32)
+            for s_ in range(low.n_slots):
+                for t in range(ptr[s_], ptr[s_ + 1]):
+                    if arg[t] == k:
+                        m[s_, idx[t]] += coef[t]
+            mats.append(torch.from_numpy(m).to(dev))
+        self._adj = dict(
+            rev_plan=simulation.get_plan(rev, adjoint.REV_FLAGS),
+            terms=adjoint.patch_marks(rev, terms),
+            perm=torch.tensor(rev_src if rev_src else [0], dtype=torch.int64, device=dev),
+            n_rev_slots=rev.n_slots, mats=mats)
+        return self._adj
+
+    def vjp(self, leaves, divs, mods, batch: int, weights):
+        """Adjoint gradient of ``sum_k weights[b, k] <obs_k>_b`` with respect to the device
+        leaves -> list of CUDA tensors shaped like ``leaves`` (a leaf shared by the whole batch
+        receives the sum over the batch).  Angle table, forward pass, backward sweep and the
+        chain rule all stay on the GPU."""
+        import torch
+
+        masks = [z_parity_mask(o) for o in self.obs]
+        if self.type != "expval" or not self.obs or any(m is None for m in masks):
+            raise NotImplementedError("adjoint differentiation needs Z / Z-parity observables")
+        adj = self._adj or self._adjoint_setup()
+        strides = [int(np.prod(t.shape[1:], dtype=np.int64)) for t in leaves]
+        angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
+                                self.d_coef, self.d_const, self.n_slots, batch, 0)
+        if adj["n_rev_slots"]:
+            rev_angles = (-angles.index_select(1, adj["perm"])).contiguous()
+        else:
+            rev_angles = torch.zeros((batch, 1), dtype=torch.float32, device=angles.device)
+        d = N.adjoint_gradient(self.plan, adj["rev_plan"], angles, rev_angles, weights, masks,
+                               adj["terms"], max(1, self.n_slots))              # [B, n_slots]
+        out = []
+        for k, leaf in enumerate(leaves):
+            g = d @ adj["mats"][k]                                               # [B, leaf size]
+            rows = int(leaf.shape[0])
+            if rows == 1:
+                g = g.sum(dim=0, keepdim=True)
+            elif not (divs[k] == 1 and rows == batch):
+                row = (torch.arange(batch, device=g.device) // int(divs[k])) % int(mods[k])
+                g = torch.zeros((rows, g.shape[1]), dtype=g.dtype, device=g.device).index_add_(0, row, g)
+            out.append(g.reshape(tuple(leaf.shape)))
+        return out
 
 
 class Script:

@@ -38,17 +38,27 @@ def differentiable(model, method: str = "adjoint"):
     class _Fn(torch.autograd.Function):
         @staticmethod
         def forward(ctx, params, inputs, enc_params, force_mean):
+            ctx.save_for_backward(params, inputs if isinstance(inputs, torch.Tensor) else None,
+                                  enc_params if isinstance(enc_params, torch.Tensor) else None)
+            ctx.force_mean = bool(force_mean)
+            # CUDA tensors in, nothing noisy: forward AND backward stay on the GPU
+            ctx.on_device = (method == "adjoint" and params.is_cuda and model.noise_params is None
+                             and model.shots is None
+                             and (inputs is None or (isinstance(inputs, torch.Tensor) and inputs.is_cuda)))
             p, x, e = _np(params), _np(inputs), _np(enc_params)
             if p.ndim == 3 and p.shape[0] != 1:
                 raise NotImplementedError("differentiable(): one parameter set per call")
+            ctx.host = (p, x, e)
+            if ctx.on_device:
+                out = model(params=params.detach(), inputs=None if inputs is None else inputs.detach(),
+                            enc_params=e, execution_type="expval", force_mean=force_mean)
+                if isinstance(out, torch.Tensor):
+                    ctx.n_out = int(model._result_shape[0])
+                    return out.to(torch.float32)
+                ctx.on_device = False
             out = np.asarray(model(params=p, inputs=x, enc_params=e, execution_type="expval",
                                    force_mean=force_mean))
-            ctx.save_for_backward(params, inputs if isinstance(inputs, torch.Tensor) else None,
-                                  enc_params if isinstance(enc_params, torch.Tensor) else None)
-            ctx.host = (p, x, e)
-            ctx.force_mean = bool(force_mean)
             ctx.n_out = int(model._result_shape[0])
-            ctx.out_shape = out.shape
             return torch.as_tensor(out, dtype=torch.float32, device="cuda")
 
         @staticmethod
@@ -76,6 +86,17 @@ def differentiable(model, method: str = "adjoint"):
                     return np.einsum("bk,bkj->bj", cot, jac)
 
             grads = [None, None, None, None]
+            if ctx.on_device and not (enc_params is not None and ctx.needs_input_grad[2]):
+                try:
+                    gp, gx = model.vjp_device(
+                        params.detach(), None if inputs is None else inputs.detach(),
+                        grad_out.reshape(B, -1) if not ctx.force_mean else grad_out.reshape(B),
+                        enc_params=e, force_mean=ctx.force_mean)
+                    grads[0] = gp if ctx.needs_input_grad[0] else None
+                    grads[1] = gx if (inputs is not None and ctx.needs_input_grad[1]) else None
+                    return tuple(grads)
+                except (NotImplementedError, AdjointUnsupported):
+                    pass
             if ctx.needs_input_grad[0]:
                 grads[0] = torch.as_tensor(vjp("params").sum(axis=0).reshape(tuple(params.shape)),
                                            dtype=params.dtype, device=params.device)
