@@ -121,6 +121,8 @@ typedef enum qmle_meas {
 #define QMLE_PLAN_FORCE_TILE 4u     /* never use the direct per-gate kernels          */
 #define QMLE_PLAN_NO_REGTILE 8u     /* one LDS sweep per gate inside a tile (debug/A-B) */
 #define QMLE_PLAN_PREFETCH 16u      /* experiment: double-buffered LDS-DMA tile kernel (slower) */
+#define QMLE_PLAN_NO_MERGE 64u      /* keep every 1-qubit gate its own operator (no RY.RZ.RY products):
+                                       the fused adjoint sweep needs one generator per gate */
 #define QMLE_PLAN_NO_ABSORB 32u     /* <Z>: simulate trailing CX / SWAP / diagonal gates instead of
                                        folding them into the observables (A-B, tests)   */
 /* bits 8..15: tile qubits T override (0 = auto); bits 16..23: low-bit count L override */

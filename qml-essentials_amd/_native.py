@@ -54,6 +54,7 @@ PLAN_FORCE_TILE = 4
 PLAN_NO_REGTILE = 8
 PLAN_PREFETCH = 16
 PLAN_NO_ABSORB = 32
+PLAN_NO_MERGE = 64
 
 
 def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0,
@@ -151,9 +152,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+class Unsupported(NotImplementedError):
+    """QMLE_ERR_UNSUPPORTED: the engine has no kernel for this request (callers may fall back
+    to another plan shape)."""
+
+
 def check(status: int, what: str = "") -> None:
     if status == OK:
         return
+    if status == -10:
+        raise Unsupported(f"{what}: {lib().qmle_status_string(status).decode()} (qmle status -10)")
     msg = lib().qmle_status_string(status).decode()
     raise _STATUS_EXC.get(status, RuntimeError)(f"{what}: {msg} (qmle status {status})")
 

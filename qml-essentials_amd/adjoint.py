@@ -111,7 +111,23 @@ def patch_marks(rev: LoweredTape, terms):
             for (name, _w, _s, off), t in zip(rev.ops, terms)]
 
 
+# one streaming pass per gate (always possible) ...
 REV_FLAGS = N.PLAN_NO_FUSION | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB
+# ... or fused tile passes over [psi; lambda]: every gate stays its own operator (one generator
+# per gate), tiles of 2^12 amplitudes so that both states fit in one workgroup's LDS
+REV_FLAGS_FUSED = (N.PLAN_NO_MERGE | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB
+                   | N.plan_flags(tile_bits=12, low_bits=4))
+
+
+def run_sweep(fwd_plan, rev: LoweredTape, a_f, a_r, w, obs_groups, terms, n_grad_slots):
+    """The backward sweep with fused tile passes where the engine supports the tape (1-qubit and
+    controlled 1-qubit gates), else with one streaming pass per gate."""
+    try:
+        return N.adjoint_gradient(fwd_plan, get_plan(rev, REV_FLAGS_FUSED), a_f, a_r, w, obs_groups,
+                                  terms, n_grad_slots)
+    except N.Unsupported:
+        return N.adjoint_gradient(fwd_plan, get_plan(rev, REV_FLAGS), a_f, a_r, w, obs_groups,
+                                  terms, n_grad_slots)
 
 
 def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
@@ -123,9 +139,8 @@ def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_group
     rev = LoweredTape(rev_ops, n_qubits)
     fixed = patch_marks(rev, terms)
     fwd_plan = get_plan(low)
-    rev_plan = get_plan(rev, REV_FLAGS)
     a_f = torch.from_numpy(low.angle_table(batch)).cuda()
     a_r = torch.from_numpy(rev.angle_table(batch)).cuda()
     w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()
-    return N.adjoint_gradient(fwd_plan, rev_plan, a_f, a_r, w, obs_groups, fixed,
-                              max(1, low.n_slots)).cpu().numpy()[:, : low.n_slots]
+    return run_sweep(fwd_plan, rev, a_f, a_r, w, obs_groups, fixed,
+                     max(1, low.n_slots)).cpu().numpy()[:, : low.n_slots]

@@ -114,6 +114,7 @@ struct qmle_plan {
   std::vector<qmle::LoweredOp> lowered;   // after 1-q merging, global positions
   std::vector<std::vector<int>> lowered_src;  // reference ops per lowered op
   std::vector<qmle::LoweredOp> dev_ops;   // per stage, stage-local positions
+  std::vector<int> dev_src;               // source op of every dev_op (-1 if merged from several)
   std::vector<qmle::OpGroup> op_groups;   // register-tile groups of the tile stages
   std::vector<qmle::BuildOp> build_ops;
   std::vector<qmle::BuildGroup> groups;
@@ -135,6 +136,10 @@ struct qmle_plan {
   // terms, uploaded once per (plan, terms) -- owned by the REVERSE plan
   void *adj_blob = nullptr;
   uint64_t adj_hash = 0;
+  // fused adjoint tile passes: per dev_op derivative index / generator type, per stage term
+  // -> (gradient column, coefficient) tables
+  void *adjf_blob = nullptr;
+  uint64_t adjf_hash = 0;
 };
 
 namespace qmle {

@@ -97,7 +97,9 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
   const int nops = st.op_end - st.op_begin;
   st.grp_begin = (int)p->op_groups.size();
   std::vector<LoweredOp> src(p->dev_ops.begin() + st.op_begin, p->dev_ops.begin() + st.op_end);
+  std::vector<int> src_id(p->dev_src.begin() + st.op_begin, p->dev_src.begin() + st.op_end);
   std::vector<LoweredOp> out;
+  std::vector<int> out_id;
   out.reserve(nops);
   std::vector<char> done(nops, 0);
   const bool regs_ok = st.T >= 4 && !(p->flags & QMLE_PLAN_NO_REGTILE);
@@ -145,6 +147,7 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
       g.n_ops = 1;
       for (int j = 0; j < 4; ++j) g.bits[j] = (uint8_t)sorted[j];
       out.push_back(o);
+      out_id.push_back(src_id[first]);
       done[first] = 1;
       ++n_done;
       p->op_groups.push_back(g);
@@ -154,6 +157,7 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
       g.kind = GK_SWEEP;
       g.n_ops = 1;
       out.push_back(src[first]);
+      out_id.push_back(src_id[first]);
       done[first] = 1;
       ++n_done;
       p->op_groups.push_back(g);
@@ -189,12 +193,14 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
       o.t0 = local_of[(int)o.t0];
       if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
       out.push_back(o);
+      out_id.push_back(src_id[i]);
       done[i] = 1;
       ++n_done;
     }
     p->op_groups.push_back(g);
   }
   std::copy(out.begin(), out.end(), p->dev_ops.begin() + st.op_begin);
+  std::copy(out_id.begin(), out_id.end(), p->dev_src.begin() + st.op_begin);
   st.grp_end = (int)p->op_groups.size();
 }
 
@@ -357,7 +363,7 @@ int compile_plan(qmle_plan *p) {
     // commutation-aware merge: an uncontrolled 1-q gate multiplies onto the
     // previous uncontrolled 1-q matrix on the same wire if nothing touched that
     // wire in between (gates on disjoint wires commute).
-    if (fuse && lo.kind == LK_1Q && lo.nc == 0) {
+    if (fuse && !(p->flags & QMLE_PLAN_NO_MERGE) && lo.kind == LK_1Q && lo.nc == 0) {
       const int prev = last_touch[lo.t0];
       if (prev >= 0) {
         LoweredOp &pl = p->lowered[prev];
@@ -412,6 +418,7 @@ int compile_plan(qmle_plan *p) {
     p->tile_L = L;
     p->stages.clear();
     p->dev_ops.clear();
+    p->dev_src.clear();
     p->op_groups.clear();
     p->consts.resize(n_user_consts);  // drop permuted-matrix copies of a previous candidate
     const size_t nl = p->lowered.size();
@@ -440,6 +447,7 @@ int compile_plan(qmle_plan *p) {
           st.kind = ST_DIAG_ALL;
           st.op_begin = (int)p->dev_ops.size();
           p->dev_ops.push_back(fo);
+          p->dev_src.push_back(p->lowered_src[first].size() == 1 ? p->lowered_src[first][0] : -1);
           st.op_end = (int)p->dev_ops.size();
           st.src_ops = p->lowered_src[first];
           p->stages.push_back(st);
@@ -481,6 +489,7 @@ int compile_plan(qmle_plan *p) {
       if (direct_ok) {
         st.kind = ST_DIRECT;
         p->dev_ops.push_back(m0);
+        p->dev_src.push_back(p->lowered_src[members[0]].size() == 1 ? p->lowered_src[members[0]][0] : -1);
       } else {
         st.kind = ST_TILE;
         // pad the tile with the lowest free bit positions
@@ -505,6 +514,7 @@ int compile_plan(qmle_plan *p) {
             if (o.c1 >= 0) o.c1 = local_of[(int)o.c1];
           }
           p->dev_ops.push_back(o);
+          p->dev_src.push_back(p->lowered_src[mi].size() == 1 ? p->lowered_src[mi][0] : -1);
         }
       }
       st.op_end = (int)p->dev_ops.size();

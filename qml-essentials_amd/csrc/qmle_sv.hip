@@ -950,6 +950,169 @@ __global__ void k_adjoint_lds(const AdjLdsArgs a) {
   }
 }
 
+// ---- fused adjoint tile pass (n >= 14) ----------------------------------------------------
+// The backward sweep with the forward path's machinery: a pass stages the SAME tile of psi and
+// of lambda in LDS, walks the register-tile groups of the reversed, daggered tape, and for every
+// gate first takes the generator overlap Im <lambda| G |psi> on the 16 + 16 amplitudes a thread
+// holds (G = X / Y / Z on the target, restricted to control = 1; P1 = |1><1| for CPhase), then
+// applies the inverse gate to both.  One HBM round trip of the two states per ~20 gates instead
+// of one per gate plus one per angle.
+//   LoweredOp::slot (unused by 1-qubit ops) carries the stage-local index of the derivative
+//   (-1: none), LoweredOp::pad the generator type.
+enum AdjGen : int { AG_NONE = 0, AG_X = 1, AG_Y = 2, AG_Z = 3, AG_P1 = 4 };
+
+// Im <y| G |x> on the 16 + 16 amplitudes of a register tile: G x by the gate appliers themselves
+// (the generator as a 2x2 "gate"), so the only gate-shaped code in the sweep is reg_dispatch.
+// With a control the applier leaves the control = 0 rows alone; those are taken out again with
+// a second application whose matrix is zero ((Pbar + P G) x - Pbar x = P G x).
+__device__ __forceinline__ Mat2 gen_matrix(int gtype) {
+  Mat2 g;
+  const float2 z = make_float2(0.f, 0.f), one = make_float2(1.f, 0.f);
+  g.m00 = g.m01 = g.m10 = g.m11 = z;
+  if (gtype == AG_X) { g.m01 = one; g.m10 = one; }
+  else if (gtype == AG_Y) { g.m01 = make_float2(0.f, -1.f); g.m10 = make_float2(0.f, 1.f); }
+  else if (gtype == AG_Z) { g.m00 = one; g.m11 = make_float2(-1.f, 0.f); }
+  else { g.m11 = one; }  // AG_P1
+  return g;
+}
+__device__ __forceinline__ float reg_im_dot(const float2 (&y)[16], const float2 (&t)[16]) {
+  float im = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) im += y[c].x * t[c].y - y[c].y * t[c].x;
+  return im;
+}
+
+struct AdjTileArgs {
+  TileArgs t;               // stage of the reverse plan: groups, ops, matrices of sample b
+  float2 *lam;              // [B][2^n]  (t.states = psi)
+  const int32_t *term_idx;  // per dev_op of the stage: stage-local derivative index or -1
+  const int32_t *gtype;     // per dev_op of the stage: AdjGen
+  float *partial;           // [B][tiles][n_terms]
+  int n_terms;
+};
+
+__global__ void __launch_bounds__(256) k_tile_adj(const AdjTileArgs A) {
+  extern __shared__ float4 smem4[];
+  const TileArgs &a = A.t;
+  const int T = a.T, L = a.L;
+  float2 *s0 = reinterpret_cast<float2 *>(smem4);
+  float2 *s1 = s0 + (1u << T);
+  uint32_t *lut = reinterpret_cast<uint32_t *>(s1 + (1u << T));
+  const uint32_t lut_n = (1u << (T - L)) < 4u ? 4u : (1u << (T - L));
+  OpSlot *slots = reinterpret_cast<OpSlot *>(lut + lut_n);
+  float *ov = reinterpret_cast<float *>(slots + a.n_ops);  // [waves][n_terms]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & (kWave - 1), w = tid / kWave, nw = nt / kWave;
+  const int b = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
+  const size_t D = (size_t)1 << a.n;
+  const uint64_t base = tile_base(a, tile);
+  tile_build_lut(a, lut);
+  {  // op descriptors + sample b's inverse-gate matrices + derivative bookkeeping -> LDS
+    const float *mrow0 = a.mats + (size_t)b * a.mat_floats;
+    for (int k = tid; k < a.n_ops; k += nt) {
+      // LoweredOp as four words: {kind, flags, t0, t1}, {c0, c1, nc, pad}, mat_off, slot
+      uint4 o = *reinterpret_cast<const uint4 *>(a.ops + a.op_begin + k);
+      const float4 lo4 = *reinterpret_cast<const float4 *>(mrow0 + o.z);
+      const float4 hi4 = *reinterpret_cast<const float4 *>(mrow0 + o.z + 4);
+      o.y = (o.y & 0x00ffffffu) | ((uint32_t)A.gtype[k] << 24);  // pad  <- generator type
+      o.w = (uint32_t)A.term_idx[k];                              // slot <- derivative index
+      *reinterpret_cast<uint4 *>(&slots[k].op) = o;
+      *reinterpret_cast<float4 *>(slots[k].m) = lo4;
+      *reinterpret_cast<float4 *>(slots[k].m + 4) = hi4;
+    }
+    for (int k = tid; k < nw * A.n_terms; k += nt) ov[k] = 0.f;
+  }
+  __syncthreads();
+  const uint32_t half = 1u << (T - 1), lowmask = (1u << L) - 1u;
+  float2 *st0 = a.states + (size_t)b * D, *st1 = A.lam + (size_t)b * D;
+  for (uint32_t jc = tid; jc < half; jc += nt) {
+    const uint32_t j = jc * 2u;
+    const uint64_t g = base | lut[j >> L] | (j & lowmask);
+    reinterpret_cast<float4 *>(s0)[sw(j) >> 1] = *reinterpret_cast<const float4 *>(st0 + g);
+    reinterpret_cast<float4 *>(s1)[sw(j) >> 1] = *reinterpret_cast<const float4 *>(st1 + g);
+  }
+  __syncthreads();
+
+  for (int gi = 0; gi < a.n_groups; ++gi) {
+    const OpGroup g = a.groups[gi];  // GK_REG4 only (checked on the host)
+    const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+    uint32_t off[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      off[c] = sw(((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
+                  ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
+    const uint32_t cnt = 1u << (T - 4);
+    for (uint32_t i = tid; i < cnt; i += nt) {
+      const uint32_t bs = sw(ins0(ins0(ins0(ins0(i, b0), b1), b2), b3));
+      float2 x[16], y[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        x[c] = s0[bs ^ off[c]];
+        y[c] = s1[bs ^ off[c]];
+      }
+      for (int k = 0; k < g.n_ops; ++k) {
+        const OpSlot *sl = slots + (g.op_begin - a.op_begin + k);
+        const LoweredOp op = sl->op;
+        const Mat2 m = load_mat2(sl->m);
+        const int cb = op.nc ? op.c0 : -1;
+        if (op.slot >= 0) {
+          float2 t[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) t[c] = x[c];
+          reg_dispatch<0>(t, gen_matrix(op.pad), cb, op.t0);
+          float im = reg_im_dot(y, t);
+          if (cb >= 0) {
+            // rows with control = 0 are untouched by both applications -> they cancel
+            Mat2 zero = gen_matrix(AG_P1);
+            zero.m11 = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = x[c];
+            reg_dispatch<1>(t, zero, cb, op.t0);
+            im -= reg_im_dot(y, t);
+          }
+          im = wave_sum(im);
+          if (lane == 0) ov[w * A.n_terms + op.slot] += im;
+        }
+        if (op.flags & LF_PERMX) { reg_dispatch<2>(x, m, cb, op.t0); reg_dispatch<2>(y, m, cb, op.t0); }
+        else if (op.flags & LF_DIAG) { reg_dispatch<1>(x, m, cb, op.t0); reg_dispatch<1>(y, m, cb, op.t0); }
+        else { reg_dispatch<0>(x, m, cb, op.t0); reg_dispatch<0>(y, m, cb, op.t0); }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        s0[bs ^ off[c]] = x[c];
+        s1[bs ^ off[c]] = y[c];
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t jc = tid; jc < half; jc += nt) {
+    const uint32_t j = jc * 2u;
+    const uint64_t g = base | lut[j >> L] | (j & lowmask);
+    *reinterpret_cast<float4 *>(st0 + g) = reinterpret_cast<float4 *>(s0)[sw(j) >> 1];
+    *reinterpret_cast<float4 *>(st1 + g) = reinterpret_cast<float4 *>(s1)[sw(j) >> 1];
+  }
+  for (int k = tid; k < A.n_terms; k += nt) {
+    float v = 0.f;
+    for (int i = 0; i < nw; ++i) v += ov[i * A.n_terms + k];
+    A.partial[((size_t)b * gridDim.x + tile) * A.n_terms + k] = v;
+  }
+}
+
+// grad[b][slot_k] = coef_k * sum_tiles partial[b][tile][k]; one block per (state, term)
+__global__ void __launch_bounds__(256)
+k_adj_tile_final(const float *__restrict__ partial, int n_tiles, int n_terms,
+                 const int32_t *__restrict__ slot_of, const float *__restrict__ coef_of,
+                 float *__restrict__ grad, int n_grad_slots) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, k = blockIdx.y;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x)
+    acc += partial[((size_t)b * n_tiles + i) * n_terms + k];
+  const double tot = block_sum_d(acc, red);
+  if (threadIdx.x == 0) grad[(size_t)b * n_grad_slots + slot_of[k]] = (float)(coef_of[k] * tot);
+}
+
 // ---- prefetching tile kernel ------------------------------------------------------------
 // EXPERIMENT, opt-in (QMLE_PLAN_PREFETCH): in k_tile a workgroup's HBM traffic stops while it
 // runs its gate groups.  k_tile_pf gives every workgroup a contiguous run of tiles and TWO
@@ -2282,6 +2445,7 @@ int qmle_plan_destroy(qmle_plan *plan) {
   if (!plan) return QMLE_OK;
   if (plan->expval_child) (void)qmle_plan_destroy(plan->expval_child);
   if (plan->adj_blob) (void)hipFree(plan->adj_blob);
+  if (plan->adjf_blob) (void)hipFree(plan->adjf_blob);
   if (plan->dev.blob) (void)hipFree(plan->dev.blob);
   delete plan;
   return QMLE_OK;
@@ -2678,7 +2842,7 @@ static int adj_blocks(int n) {
   if (b > 1024) b = 1024;
   return (int)b;
 }
-struct AdjLayout { size_t states, lam, mats, ang2, partial, fwd_ws, lds_ops, lds_terms, lds_fmats, total; };
+struct AdjLayout { size_t states, lam, mats, ang2, partial, fwd_ws, lds_ops, lds_terms, lds_fmats, tile_partial, total; };
 static AdjLayout adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
   AdjLayout L;
   const size_t sb = (size_t)batch * ((size_t)8 << fwd->n);
@@ -2691,7 +2855,14 @@ static AdjLayout adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batc
   L.lds_ops = L.fwd_ws + workspace_bytes_one(fwd, batch, QMLE_MEAS_STATE, 0) + 256;
   L.lds_terms = L.lds_ops + align_up(rev->lowered.size() * sizeof(LoweredOp) + 16, 256);
   L.lds_fmats = L.lds_terms + align_up(rev->lowered.size() * sizeof(AdjTermDev) + 16, 256);
-  L.total = L.lds_fmats + ws_mats_bytes(fwd, batch) + 256;
+  L.tile_partial = L.lds_fmats + ws_mats_bytes(fwd, batch) + 256;
+  size_t tp = 0;  // fused tile passes: [B][tiles][terms of the stage]
+  for (const Stage &st : rev->stages)
+    if (st.kind == ST_TILE && !rev->whole_state_lds) {
+      const size_t need = ((size_t)batch << (rev->n - st.T)) * (size_t)(st.op_end - st.op_begin) * sizeof(float);
+      if (need > tp) tp = need;
+    }
+  L.total = L.tile_partial + align_up(tp, 256) + 256;
   return L;
 }
 size_t qmle_adjoint_workspace_bytes(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
@@ -2712,8 +2883,14 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
   if ((fwd->n_slots > 0 && !d_angles_fwd) || (rev->n_slots > 0 && !d_angles_rev))
     return QMLE_ERR_INVALID_ARG;
   const int n = fwd->n;
-  for (const Stage &st : rev->stages)
-    if (st.src_ops.size() != 1) return QMLE_ERR_INVALID_ARG;  // rev must be a NO_FUSION plan
+  // rev is either a NO_FUSION plan (one streaming pass per gate) or a NO_MERGE plan (fused tile
+  // passes); both keep one source gate per lowered operator
+  const bool fused = (rev->flags & QMLE_PLAN_NO_MERGE) && !(rev->flags & QMLE_PLAN_NO_FUSION);
+  if (!fused)
+    for (const Stage &st : rev->stages)
+      if (st.src_ops.size() != 1) return QMLE_ERR_INVALID_ARG;
+  for (const auto &srcs : rev->lowered_src)
+    if (srcs.size() != 1) return QMLE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   int rc = ensure_device_plan(rev);
   if (rc != QMLE_OK) return rc;
@@ -2857,8 +3034,105 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
                        rev->dev.d_consts, mats, rev->mat_floats);
   }
   const int nb = adj_blocks(n);
+  // ---- fused plan: per-dev_op bookkeeping for the tile passes (cached on the reverse plan) ----
+  std::vector<int> st_term_begin, st_n_terms;
+  const int32_t *d_term_idx = nullptr, *d_gtype = nullptr, *d_slot_of = nullptr;
+  const float *d_coef_of = nullptr;
+  if (fused) {
+    const size_t nd = rev->dev_ops.size();
+    std::vector<int32_t> term_idx(nd ? nd : 1, -1), gtype(nd ? nd : 1, 0), slot_of;
+    std::vector<float> coef_of;
+    for (const Stage &st : rev->stages) {
+      st_term_begin.push_back((int)slot_of.size());
+      int cnt = 0;
+      if (st.kind == ST_TILE) {
+        if ((size_t)16 << st.T > (size_t)150 * 1024 || st.L < 1) return QMLE_ERR_UNSUPPORTED;
+        for (int g = st.grp_begin; g < st.grp_end; ++g)
+          if (rev->op_groups[g].kind != GK_REG4) return QMLE_ERR_UNSUPPORTED;
+        for (int k = st.op_begin; k < st.op_end; ++k) {
+          const int src = rev->dev_src[k];
+          if (src < 0) return QMLE_ERR_INVALID_ARG;
+          const qmle_adjoint_term &t = terms[src];
+          if (t.out_slot < 0) continue;
+          const LoweredOp &o = rev->dev_ops[k];
+          // a single-target generator whose projector is exactly the gate's control
+          const int nx = __builtin_popcount(t.x_wires), nz = __builtin_popcount(t.z_wires);
+          int gt;
+          if (t.marks_off >= 0 || nx > 1 || nz > 1 || (nx && nz && t.x_wires != t.z_wires))
+            return QMLE_ERR_UNSUPPORTED;
+          if (nx && nz) gt = AG_Y; else if (nx) gt = AG_X; else if (nz) gt = AG_Z; else gt = AG_P1;
+          if (o.kind != LK_1Q || o.nc > 1) return QMLE_ERR_UNSUPPORTED;
+          term_idx[k] = cnt++;
+          gtype[k] = gt;
+          slot_of.push_back(t.out_slot);
+          coef_of.push_back(t.coef);
+        }
+      }
+      st_n_terms.push_back(cnt);
+    }
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const void *ptr, size_t bytes) {
+      for (size_t i = 0; i < bytes; ++i) hsh = (hsh ^ ((const unsigned char *)ptr)[i]) * 1099511628211ull;
+    };
+    mix(term_idx.data(), term_idx.size() * 4);
+    mix(gtype.data(), gtype.size() * 4);
+    mix(slot_of.data(), slot_of.size() * 4);
+    mix(coef_of.data(), coef_of.size() * 4);
+    const size_t nt_tot = slot_of.size() ? slot_of.size() : 1;
+    const size_t o1 = align_up(term_idx.size() * 4, 256), o2 = o1 + align_up(gtype.size() * 4, 256),
+                 o3 = o2 + align_up(nt_tot * 4, 256);
+    if (!rev->adjf_blob || rev->adjf_hash != hsh) {
+      if (rev->adjf_blob) (void)hipFree(rev->adjf_blob);
+      rev->adjf_blob = nullptr;
+      HIPCHK(hipMalloc(&rev->adjf_blob, o3 + align_up(nt_tot * 4, 256)));
+      HIPCHK(hipMemcpy(rev->adjf_blob, term_idx.data(), term_idx.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy((char *)rev->adjf_blob + o1, gtype.data(), gtype.size() * 4, hipMemcpyHostToDevice));
+      if (!slot_of.empty()) {
+        HIPCHK(hipMemcpy((char *)rev->adjf_blob + o2, slot_of.data(), slot_of.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((char *)rev->adjf_blob + o3, coef_of.data(), coef_of.size() * 4, hipMemcpyHostToDevice));
+      }
+      rev->adjf_hash = hsh;
+    }
+    d_term_idx = (const int32_t *)rev->adjf_blob;
+    d_gtype = (const int32_t *)((char *)rev->adjf_blob + o1);
+    d_slot_of = (const int32_t *)((char *)rev->adjf_blob + o2);
+    d_coef_of = (const float *)((char *)rev->adjf_blob + o3);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile_adj,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+  }
+  float *tile_partial = (float *)(ws + L.tile_partial);
+  size_t si = 0;
   for (const Stage &st : rev->stages) {
-    const int r = st.src_ops[0];
+    const size_t stage_i = si++;
+    if (fused && st.kind == ST_TILE) {
+      AdjTileArgs A;
+      A.t = fill_tile_args(rev, st, psi, mats, ang2, false, TM_STORE, nullptr, nullptr, 0);
+      A.t.slots_in_lds = 1;
+      A.lam = lam;
+      A.term_idx = d_term_idx + st.op_begin;
+      A.gtype = d_gtype + st.op_begin;
+      A.partial = tile_partial;
+      A.n_terms = st_n_terms[stage_i];
+      const int threads = 256;
+      const size_t lut_n = ((size_t)1 << (st.T - st.L)) < 4 ? 4 : ((size_t)1 << (st.T - st.L));
+      const size_t lds = ((size_t)16 << st.T) + 4 * lut_n + (size_t)A.t.n_ops * sizeof(OpSlot) +
+                         (size_t)(threads / kWave) * (A.n_terms ? A.n_terms : 1) * sizeof(float);
+      if (lds > 160 * 1024) return QMLE_ERR_UNSUPPORTED;
+      const unsigned tiles = 1u << (n - st.T);
+      hipLaunchKernelGGL(k_tile_adj, dim3(tiles, batch), dim3(threads), lds, stream, A);
+      if (A.n_terms)
+        hipLaunchKernelGGL(k_adj_tile_final, dim3(batch, A.n_terms), dim3(256), 0, stream,
+                           (const float *)tile_partial, (int)tiles, A.n_terms,
+                           d_slot_of + st_term_begin[stage_i], d_coef_of + st_term_begin[stage_i],
+                           d_grad, n_grad_slots);
+      continue;
+    }
+    const int r = fused ? rev->dev_src[st.op_begin] : st.src_ops[0];
+    if (r < 0) return QMLE_ERR_INVALID_ARG;
     const qmle_adjoint_term &t = terms[r];
     if (t.out_slot >= 0) {
       AdjTerm a;

@@ -127,7 +127,7 @@ class CompiledCall:
                         m[s_, idx[t]] += coef[t]
             mats.append(torch.from_numpy(m).to(dev))
         self._adj = dict(
-            rev_plan=simulation.get_plan(rev, adjoint.REV_FLAGS),
+            rev=rev,
             terms=adjoint.patch_marks(rev, terms),
             perm=torch.tensor(rev_src if rev_src else [0], dtype=torch.int64, device=dev),
             n_rev_slots=rev.n_slots, mats=mats)
@@ -151,8 +151,10 @@ class CompiledCall:
             rev_angles = (-angles.index_select(1, adj["perm"])).contiguous()
         else:
             rev_angles = torch.zeros((batch, 1), dtype=torch.float32, device=angles.device)
-        d = N.adjoint_gradient(self.plan, adj["rev_plan"], angles, rev_angles, weights, masks,
-                               adj["terms"], max(1, self.n_slots))              # [B, n_slots]
+        from . import adjoint
+
+        d = adjoint.run_sweep(self.plan, adj["rev"], angles, rev_angles, weights, masks,
+                              adj["terms"], max(1, self.n_slots))               # [B, n_slots]
         out = []
         for k, leaf in enumerate(leaves):
             g = d @ adj["mats"][k]                                               # [B, leaf size]
