@@ -556,13 +556,12 @@ class Model:
         ``cotangent``.  Same numbers as the parameter-shift rule at O(gates) instead of
         O(gates x angles) cost.
         """
-        if method == "auto":  # measured (profiles/r01_gradients.md): the streaming backward sweep
-            # is launch-bound below ~18 qubits; up to 13 qubits psi and lambda live in LDS and
-            # the single-launch sweep wins as soon as there is a batch to spread over the CUs
+        if method == "auto":  # measured (profiles/r01_gradients.md): from 14 qubits the fused
+            # backward sweep beats the batched parameter shift 5-40x; below, psi and lambda live
+            # in LDS and the single-launch sweep wins once there is a batch to spread over the CUs
             n_in = 1 if inputs is None else int(np.asarray(to_numpy(inputs)).reshape(-1, self.n_input_feat).shape[0])
             ok = self.noise_params is None and (force_mean or cotangent is not None)
-            method = "adjoint" if ok and (self.n_qubits >= 18 or (self.n_qubits <= 13 and n_in >= 8)) \
-                else "parameter-shift"
+            method = "adjoint" if ok and (self.n_qubits >= 14 or n_in >= 8) else "parameter-shift"
         if method not in ("parameter-shift", "adjoint"):
             raise ValueError(
                 f"method must be 'parameter-shift', 'adjoint' or 'auto', got {method!r}")
