@@ -220,3 +220,19 @@ def test_adjoint_tiny_registers_and_streaming_path(monkeypatch):
     w = np.array([0.5, -1.0, 2.0])
     (g,) = s.vjp(obs, w, args=(th,))
     assert np.allclose(g, w @ jac, atol=4e-6)
+
+
+@pytest.mark.parametrize("ansatz,n", [("Hardware_Efficient", 14), ("Strongly_Entangling", 15),
+                                      ("Circuit_9", 14), ("Circuit_19", 16)])
+def test_fused_adjoint_tile_passes_match_parameter_shift(ansatz, n):
+    """n >= 14: the sweep runs as fused tile passes over [psi; lambda] (k_tile_adj) -- RX/RY/RZ,
+    Rot (split), CX, CZ, CRX generators and inverses inside register groups; compare with the
+    parameter-shift Jacobian for parameters, inputs and encoding weights."""
+    model = Model(n_qubits=n, n_layers=1, circuit_type=ansatz)
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0, 2 * np.pi, (2, 1))
+    cot = rng.normal(size=(2, n))
+    for wrt in ("params", "inputs", "enc_params"):
+        jac = np.asarray(model.gradient(inputs=x, wrt=wrt))
+        vjp = np.asarray(model.gradient(inputs=x, wrt=wrt, method="adjoint", cotangent=cot))
+        assert np.allclose(vjp, np.einsum("bk,bk...->b...", cot, jac), atol=1e-5), wrt
