@@ -12,6 +12,7 @@ runs in the engine.
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -130,17 +131,34 @@ def run_sweep(fwd_plan, rev: LoweredTape, a_f, a_r, w, obs_groups, terms, n_grad
                                   terms, n_grad_slots)
 
 
+_REV_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
 def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
                           weights: np.ndarray, want: Sequence[bool]) -> np.ndarray:
     """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
-    (columns of slots that are not wanted stay zero)."""
+    (columns of slots that are not wanted stay zero).  The reversed tape depends only on the
+    STRUCTURE of the forward tape (its angles are the negated forward columns), so it is built
+    once per structure."""
     torch = N.require_gpu()
-    rev_ops, terms, _ = build_reverse(low, _op_blobs(low), want)
-    rev = LoweredTape(rev_ops, n_qubits)
-    fixed = patch_marks(rev, terms)
-    fwd_plan = get_plan(low)
+    key = (low.key, tuple(bool(x) for x in want))
+    hit = _REV_CACHE.get(key)
+    if hit is None:
+        rev_ops, terms, rev_src = build_reverse(low, _op_blobs(low), want)
+        rev = LoweredTape(rev_ops, n_qubits)
+        hit = (rev, patch_marks(rev, terms),
+               torch.tensor(rev_src if rev_src else [0], dtype=torch.int64, device="cuda"))
+        _REV_CACHE[key] = hit
+        if len(_REV_CACHE) > 64:
+            _REV_CACHE.popitem(last=False)
+    else:
+        _REV_CACHE.move_to_end(key)
+    rev, fixed, perm = hit
     a_f = torch.from_numpy(low.angle_table(batch)).cuda()
-    a_r = torch.from_numpy(rev.angle_table(batch)).cuda()
+    if rev.n_slots:
+        a_r = (-a_f.index_select(1, perm)).contiguous()
+    else:
+        a_r = torch.zeros((batch, 1), dtype=torch.float32, device=a_f.device)
     w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()
-    return run_sweep(fwd_plan, rev, a_f, a_r, w, obs_groups, fixed,
+    return run_sweep(get_plan(low), rev, a_f, a_r, w, obs_groups, fixed,
                      max(1, low.n_slots)).cpu().numpy()[:, : low.n_slots]
