@@ -97,6 +97,25 @@ def expressibility_wallclock(n=12, samples=1024):
             "n_qubits": n, "pairs": samples}
 
 
+def adjoint_gradient_wallclock(n=20, layers=4):
+    """Extra: gradient of mean_q <Z_q> w.r.t. all parameters of BASELINE config 2's model
+    (20 qubits, 4 layers, 300 parameters) by the fused adjoint sweep, CUDA tensors in and out."""
+    from qml_essentials_amd.model import Model
+
+    m = Model(n, layers, "Hardware_Efficient")
+    p = torch.tensor(np.asarray(m.params[0]), dtype=torch.float32, device="cuda")
+    x = torch.tensor([[0.5]], dtype=torch.float32, device="cuda")
+    cot = torch.ones((1,), dtype=torch.float32, device="cuda")
+    m.vjp_device(p, x, cot, force_mean=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g, _ = m.vjp_device(p, x, cot, force_mean=True)
+    torch.cuda.synchronize()
+    return {"ms": round((time.perf_counter() - t0) / 10 * 1e3, 3), "n_qubits": n,
+            "n_params": int(p.numel()), "finite": bool(torch.isfinite(g).all())}
+
+
 def cpu_baseline(n, params_row, budget_s):
     """Oracle C/OpenMP port on a bounded sample of the same workload (rank 0, N=1)."""
     from oracle import c_port, circuits as OC
@@ -260,6 +279,11 @@ def main():
             result["k1_single_gate_28q"] = {"error": str(e)}
     if expr is not None:
         result["expressibility_12q_1024pairs"] = expr
+        if size == 1:
+            try:
+                result["adjoint_gradient_20q"] = adjoint_gradient_wallclock()
+            except Exception as e:  # extras never break the headline line
+                result["adjoint_gradient_20q"] = {"error": str(e)}
     distributed.barrier()
     print(json.dumps(result), flush=True)
 
