@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 120 /* 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 121 /* 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -174,13 +174,17 @@ int qmle_run_batch_parity(qmle_plan *plan, const float *d_angles, int batch,
  * leaf_{arg[t]}[row_k(b)][idx[t]], terms of slot s = [ptr[s], ptr[s+1]); row_k(b) =
  * ((b + batch_offset) / div_k) % mod_k  (cartesian inputs x params batch, model.py:1449-1481).
  * d_leaves / strides / div / mod are HOST arrays of n_leaves <= 8 entries; everything d_* is
- * device memory.  Replaces the host-side angle arithmetic when params / inputs already
- * live in HBM. */
+ * device memory.  The sum runs in fp64; d_period (may be NULL) holds one double per slot: where
+ * > 0 the angle is reduced into (-period/2, period/2] before the float32 store (4 pi for the
+ * rotation gates, which depend on angle / 2 only -- binary / ternary encodings scale inputs
+ * by up to 3^(n-1), ansaetze/encodings of model.py:804-816).  Replaces the host-side angle
+ * arithmetic when params / inputs already live in HBM. */
 int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
                       const int32_t *leaf_div, const int32_t *leaf_mod, int n_leaves,
                       const int32_t *d_ptr, const int32_t *d_arg, const int32_t *d_idx,
-                      const float *d_coef, const float *d_const, int n_slots, int64_t batch,
-                      int64_t batch_offset, float *d_out, qmle_stream stream);
+                      const float *d_coef, const float *d_const, const double *d_period,
+                      int n_slots, int64_t batch, int64_t batch_offset, float *d_out,
+                      qmle_stream stream);
 
 /* Apply the plan's passes in place to resident states [batch][2^n] complex64 (no
  * initialisation, no measurement) -- the per-gate loop simulation.py:102-103 alone.

@@ -96,8 +96,8 @@ SYMBOLS = [
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_run_batch_parity", _I, [_VP, _VP, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_build_angles", _I, [C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
-                               C.POINTER(C.c_int32), _I, _VP, _VP, _VP, _VP, _VP, _I, C.c_int64,
-                               C.c_int64, _VP, _VP]),
+                               C.POINTER(C.c_int32), _I, _VP, _VP, _VP, _VP, _VP, _VP, _I,
+                               C.c_int64, C.c_int64, _VP, _VP]),
     ("qmle_apply_inplace", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_profile_begin", _I, [_VP, _I]),
     ("qmle_profile_end", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
@@ -345,8 +345,9 @@ class Plan:
 
 
 def build_angles(leaves, strides, divs, mods, d_ptr, d_arg, d_idx, d_coef, d_const, n_slots,
-                 batch, batch_offset=0, out=None):
-    """Angle table [batch, n_slots] on device from device-resident leaf tensors."""
+                 batch, batch_offset=0, out=None, d_period=None):
+    """Angle table [batch, n_slots] on device from device-resident leaf tensors;
+    ``d_period`` [n_slots] float64: slots reduced into (-period/2, period/2]."""
     torch = require_gpu()
     k = len(leaves)
     dev = d_const.device
@@ -361,6 +362,7 @@ def build_angles(leaves, strides, divs, mods, d_ptr, d_arg, d_idx, d_coef, d_con
     check(lib().qmle_build_angles(lp, ls, ld, lm, k, C.c_void_p(d_ptr.data_ptr()),
                                   C.c_void_p(d_arg.data_ptr()), C.c_void_p(d_idx.data_ptr()),
                                   C.c_void_p(d_coef.data_ptr()), C.c_void_p(d_const.data_ptr()),
+                                  C.c_void_p(d_period.data_ptr() if d_period is not None else None),
                                   int(n_slots), int(batch), int(batch_offset),
                                   C.c_void_p(out.data_ptr()), _stream_ptr()), "qmle_build_angles")
     return out

@@ -33,7 +33,12 @@ class Batched:
     __slots__ = ("data", "tan")
 
     def __init__(self, data: np.ndarray, tan=None):
-        self.data = np.asarray(data)
+        data = np.asarray(data)
+        if data.dtype.kind == "f" and data.dtype.itemsize < 8:
+            # host angle arithmetic runs in fp64 (inputs * 3**q reaches 1e4 rad); the angle
+            # table is cast to float32 once, after the reduction mod 4 pi
+            data = data.astype(np.float64)
+        self.data = data
         self.tan = tan
 
     @classmethod
@@ -236,10 +241,12 @@ def param_tangent(x: Any):
 
 def to_numpy(x: Any):
     """Host ndarray view of numpy / torch / list input (None passes through)."""
-    if x is None or isinstance(x, (np.ndarray, Batched)):
+    if x is None or isinstance(x, Batched):
         return x
     if hasattr(x, "detach"):
-        return x.detach().cpu().numpy()
-    if isinstance(x, (list, tuple, numbers.Number, np.generic)):
-        return np.asarray(x)
+        x = x.detach().cpu().numpy()
+    elif isinstance(x, (list, tuple, numbers.Number, np.generic)):
+        x = np.asarray(x)
+    if isinstance(x, np.ndarray) and x.dtype.kind == "f" and x.dtype.itemsize < 8:
+        return x.astype(np.float64)  # host angle arithmetic in fp64, see Batched.__init__
     return x  # dicts (noise_params passed positionally), PRNG keys, strings: not array data

@@ -2075,20 +2075,25 @@ struct AngleLeaves {
 __global__ void __launch_bounds__(256)
 k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restrict__ arg,
                const int *__restrict__ idx, const float *__restrict__ coef,
-               const float *__restrict__ cst, int n_slots, long long batch, long long b_offset,
-               float *__restrict__ out) {
+               const float *__restrict__ cst, const double *__restrict__ period, int n_slots,
+               long long batch, long long b_offset, float *__restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch * n_slots) return;
   const long long b = i / n_slots;
   const int s = (int)(i - b * n_slots);
   const long long gb = b + b_offset;
-  float acc = cst[s];
+  // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
+  // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
+  // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
+  double acc = (double)cst[s];
   for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
     const int k = arg[t];
     const long long row = (gb / lv.div[k]) % lv.mod[k];
-    acc = fmaf(coef[t], lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
+    acc = fma((double)coef[t], (double)lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
   }
-  out[i] = acc;
+  const double per = period ? period[s] : 0.0;
+  if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
+  out[i] = (float)acc;
 }
 
 
@@ -3157,8 +3162,9 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
 int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
                       const int32_t *leaf_div, const int32_t *leaf_mod, int n_leaves,
                       const int32_t *d_ptr, const int32_t *d_arg, const int32_t *d_idx,
-                      const float *d_coef, const float *d_const, int n_slots, int64_t batch,
-                      int64_t batch_offset, float *d_out, qmle_stream stream) {
+                      const float *d_coef, const float *d_const, const double *d_period,
+                      int n_slots, int64_t batch, int64_t batch_offset, float *d_out,
+                      qmle_stream stream) {
   if (n_leaves < 0 || n_leaves > 8 || n_slots < 0 || batch < 1 || !d_out || !d_ptr || !d_const)
     return QMLE_ERR_INVALID_ARG;
   if (n_slots == 0) return QMLE_OK;
@@ -3173,7 +3179,7 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
   }
   const uint64_t total = (uint64_t)batch * (uint64_t)n_slots;
   hipLaunchKernelGGL(k_build_angles, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     lv, d_ptr, d_arg, d_idx, d_coef, d_const, n_slots, (long long)batch,
+                     lv, d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, (long long)batch,
                      (long long)batch_offset, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;

@@ -140,7 +140,10 @@ class Model:
     @execution_type.setter
     def execution_type(self, value: str) -> None:
         k = len(self.output_qubit)
-        shapes = {"density": (2**k, 2**k), "expval": (k,), "probs": (2,) * k, "state": (2**k,)}
+        # "state" ignores output_qubit (warning below), so its shape is the full register; the
+        # reference sizes it by output_qubit (model.py:365) and then fails in its own reshape
+        shapes = {"density": (2**k, 2**k), "expval": (k,), "probs": (2,) * k,
+                  "state": (2**self.n_qubits,)}
         if value not in shapes:
             raise ValueError(f"Invalid execution type: {value}.")
         self._result_shape = shapes[value]

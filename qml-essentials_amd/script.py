@@ -84,6 +84,9 @@ class CompiledCall:
         f32 = lambda v: torch.tensor(v if len(v) else [0.0], dtype=torch.float32, device=dev)
         self.d_ptr, self.d_arg, self.d_idx = i32(ptr), i32(arg), i32(idx)
         self.d_coef, self.d_const = f32(coef), f32(const)
+        # rotation angles wrap at 4 pi (the gates depend on angle / 2); a DIAG_ALL scale does not
+        self.d_period = torch.tensor([4.0 * np.pi if per else 0.0 for per in low.ops_periodic] or [0.0],
+                                     dtype=torch.float64, device=dev)
         self.leaf_ids = leaf_ids
         self._low, self._map = low, (ptr, arg, idx, coef)   # host copies for the adjoint path
         self._leaf_sizes = {order[k]: int(np.prod(np.shape(args[k]))) for k in leaf_ids}
@@ -93,7 +96,8 @@ class CompiledCall:
         """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order."""
         strides = [int(np.prod(t.shape[1:], dtype=np.int64)) for t in leaves]
         angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
-                                self.d_coef, self.d_const, self.n_slots, batch, batch_offset)
+                                self.d_coef, self.d_const, self.n_slots, batch, batch_offset,
+                                d_period=self.d_period)
         if self.n_slots == 0:
             import torch
             angles = torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device)
@@ -146,7 +150,8 @@ class CompiledCall:
         adj = self._adj or self._adjoint_setup()
         strides = [int(np.prod(t.shape[1:], dtype=np.int64)) for t in leaves]
         angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
-                                self.d_coef, self.d_const, self.n_slots, batch, 0)
+                                self.d_coef, self.d_const, self.n_slots, batch, 0,
+                                d_period=self.d_period)
         if adj["n_rev_slots"]:
             rev_angles = (-angles.index_select(1, adj["perm"])).contiguous()
         else:

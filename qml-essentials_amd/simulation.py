@@ -216,6 +216,7 @@ class LoweredTape:
 
     def __init__(self, tape: Sequence[Operation], n_qubits: int):
         self.ops, self.values, blobs = [], [], []
+        self.ops_periodic = []  # per slot: the gate is 4 pi-periodic in this angle
         h = hashlib.blake2b(digest_size=16)
         h.update(str(n_qubits).encode())
         const_len = 0
@@ -228,6 +229,7 @@ class LoweredTape:
             for p in params:
                 slots.append(len(self.values))
                 self.values.append(p)
+                self.ops_periodic.append(name != "DIAG_ALL")  # Golomb: exp(-i marks x), any marks
             off = -1
             if blob is not None:
                 off = const_len
@@ -245,10 +247,14 @@ class LoweredTape:
         table = np.empty((batch, max(1, self.n_slots)), dtype=np.float32)
         if self.n_slots == 0:
             table[:] = 0
+        four_pi = 4.0 * np.pi
         for j, v in enumerate(self.values):
             col = np.asarray(v, dtype=np.float64)
             if col.ndim and col.shape[0] != batch:
                 raise ValueError(f"parameter column has batch {col.shape[0]}, expected {batch}")
+            if self.ops_periodic[j] and np.any(np.abs(col) > four_pi):
+                # gates depend on angle / 2 only: reduce in fp64 before the float32 cast
+                col = col - four_pi * np.rint(col / four_pi)
             table[:, j] = col
         return table[:, : self.n_slots] if self.n_slots else table[:, :0]
 
