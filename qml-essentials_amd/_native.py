@@ -55,11 +55,13 @@ PLAN_NO_REGTILE = 8
 PLAN_PREFETCH = 16
 PLAN_NO_ABSORB = 32
 PLAN_NO_MERGE = 64
+PLAN_NO_SPARSE = 128
 
 
 def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0,
-               prefetch=False, no_absorb=False):
+               prefetch=False, no_absorb=False, no_sparse=False):
     f = (PLAN_PREFETCH if prefetch else 0) | (PLAN_NO_ABSORB if no_absorb else 0)
+    f |= PLAN_NO_SPARSE if no_sparse else 0
     if no_fusion:
         f |= PLAN_NO_FUSION
     if force_global:

@@ -85,6 +85,14 @@ struct Stage {
   int8_t outer_bits[QMLE_MAX_QUBITS];  // ascending global positions of the rest
   std::vector<int> src_ops;            // reference tape indices covered
   double algo_bytes_per_state = 0;     // SURVEY 8-d bytes of the covered gates
+  // Known-zero tracking for runs that start from |0..0> (simulation.py:100): `zero_in` = bit
+  // positions p such that every amplitude with bit p set is exactly zero when the stage
+  // starts; `touched` = positions the stage's gates mix (non-diagonal targets), which leave
+  // the set.  A tile stage never reads such amplitudes, and -- when the next stage is a tile
+  // stage too (`next_tile`), which will not read them either -- never launches the tiles that
+  // hold nothing else.
+  uint32_t zero_in = 0, touched = 0;
+  bool next_tile = false;
 };
 
 struct StageProfile {  // optional HIP-event timing of every stage launch (bench.py)

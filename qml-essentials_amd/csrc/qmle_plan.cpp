@@ -523,6 +523,13 @@ int compile_plan(qmle_plan *p) {
       for (int mi : members) {
         done[mi] = 1;
         ++n_done;
+        const LoweredOp &lo = p->lowered[mi];  // global positions
+        if (lo.kind == LK_4Q) {
+          st.touched |= (1u << lo.t0) | (1u << lo.t1) | (1u << lo.c0) | (1u << lo.c1);
+        } else if (lo.kind != LK_DIAG_ALL && !(lo.flags & LF_DIAG)) {
+          st.touched |= 1u << lo.t0;  // controls keep their known-zero status
+          if (lo.t1 >= 0) st.touched |= 1u << lo.t1;
+        }
         for (int s : p->lowered_src[mi]) {
           st.src_ops.push_back(s);
           st.algo_bytes_per_state += algo_bytes(p->ops[s], n);
@@ -538,6 +545,14 @@ int compile_plan(qmle_plan *p) {
       st.L = L;
       for (int b = 0; b < n; ++b) st.tile_bits[b] = (int8_t)b;
       p->stages.push_back(st);
+    }
+    // known-zero bit positions along the execution order (|0..0> start)
+    uint32_t Z = n >= 32 ? ~0u : ((1u << n) - 1u);
+    for (size_t si = 0; si < p->stages.size(); ++si) {
+      Stage &st = p->stages[si];
+      st.zero_in = Z;
+      Z &= ~st.touched;
+      st.next_tile = si + 1 < p->stages.size() && p->stages[si + 1].kind == ST_TILE;
     }
 
   };
@@ -586,6 +601,7 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"L\":" << st.L << ",\"lds_round_trips\":" << (st.grp_end - st.grp_begin)
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
+       << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
     os << "],\"groups\":[";

@@ -49,11 +49,21 @@ __device__ __forceinline__ uint32_t ins0(uint32_t i, int p) {
 __device__ __forceinline__ uint64_t ins0_64(uint64_t i, int p) {
   return ((i >> p) << (p + 1)) | (i & ((1ull << p) - 1ull));
 }
+// Complex multiply-add on packed fp32: a * b (+ c) is exactly two VOP3P instructions --
+//   v_pk_mul/fma_f32 (a.x, a.x) * (b.x, b.y) [+ c]   and   v_pk_fma_f32 (-a.y, a.y) * (b.y, b.x) + ..
+// (op_sel picks the halves; a wave-uniform `a` -- a gate matrix entry -- keeps both pairs in
+// SGPRs).  Written on the two-lane vector type so that LLVM selects the packed forms; the
+// scalar formulation compiled to ~7 VALU instructions per complex multiply-add.
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  const v2f ar = {a.x, a.x}, ai = {-a.y, a.y}, bv = {b.x, b.y}, bs = {b.y, b.x};
+  const v2f r = __builtin_elementwise_fma(ai, bs, ar * bv);
+  return make_float2(r.x, r.y);
 }
 __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {  // a*b + c
-  return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y)));
+  const v2f ar = {a.x, a.x}, ai = {-a.y, a.y}, bv = {b.x, b.y}, bs = {b.y, b.x}, cv = {c.x, c.y};
+  const v2f r = __builtin_elementwise_fma(ai, bs, __builtin_elementwise_fma(ar, bv, cv));
+  return make_float2(r.x, r.y);
 }
 __device__ __forceinline__ float norm2(float2 a) { return a.x * a.x + a.y * a.y; }
 
@@ -436,6 +446,12 @@ struct TileArgs {
   uint32_t mat_floats;
   int n_ops, n, T, L, n_slots;
   int init_zero, meas, n_obs;
+  // known-zero input (Stage::zero_in, runs from |0..0>): amplitudes whose local index meets
+  // zin_local, and whole tiles whose index meets zin_outer, are exactly zero and never read.
+  // compact: the grid holds only the tiles that can be non-zero (blockIdx.x has the bits of
+  // tile_free deposited); the others are neither computed nor stored -- the next stage knows.
+  uint32_t zin_local, zin_outer, tile_free;
+  int compact;
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
@@ -795,7 +811,17 @@ __global__ void k_tile(const TileArgs a) {
   OpSlot *slots = reinterpret_cast<OpSlot *>(red + 288);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.y;
-  const uint32_t tile = blockIdx.x;
+  uint32_t tile = blockIdx.x;
+  if (a.compact) {  // blockIdx.x enumerates the tiles that can be non-zero
+    uint32_t rest = tile, free_bits = a.tile_free;
+    tile = 0;
+    while (rest) {
+      const uint32_t low = free_bits & (0u - free_bits);
+      if (rest & 1u) tile |= low;
+      free_bits ^= low;
+      rest >>= 1;
+    }
+  }
   const size_t D = (size_t)1 << a.n;
 
   const uint64_t base = tile_base(a, tile);
@@ -803,8 +829,8 @@ __global__ void k_tile(const TileArgs a) {
   const uint32_t half = 1u << (T - 1);
   const uint32_t lowmask = (1u << L) - 1u;
   float2 *st = a.states + (size_t)b * D;
-  if (a.init_zero && base != 0) {
-    // |0..0> lives in tile 0 alone and gates are linear: every other tile of the first pass
+  if (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0) {
+    // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
     // stays exactly zero -- write the zeros (state / probabilities / partial sums), skip the gates
     __syncthreads();
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -834,6 +860,19 @@ __global__ void k_tile(const TileArgs a) {
     for (uint32_t jc = tid; jc < half; jc += nt) reinterpret_cast<float4 *>(s)[jc] = z;
     __syncthreads();
     if (tid == 0 && base == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+  } else if (a.zin_local) {
+    // only the amplitudes that can be non-zero are read; the rest of the tile is zero-filled
+    const uint32_t zl = a.zin_local & ~1u;
+    const bool z0 = (a.zin_local & 1u) != 0;
+    for (uint32_t jc = tid; jc < half; jc += nt) {
+      const uint32_t j = jc * 2u;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((j & zl) == 0) {
+        v = *reinterpret_cast<const float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+        if (z0) v.z = v.w = 0.f;
+      }
+      reinterpret_cast<float4 *>(s)[sw(j) >> 1] = v;
+    }
   } else {
     // stage the tile through registers, 8 independent 16-byte loads in flight per lane
     if ((half % (8u * nt)) == 0) {
@@ -2185,7 +2224,8 @@ int tile_threads(int T) {  // one register-tile work item (16 amplitudes) per th
 
 static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *states,
                                const float *mats, const float *angles, bool init_zero, int meas,
-                               void *out, const uint32_t *obs_masks, int n_obs) {
+                               void *out, const uint32_t *obs_masks, int n_obs,
+                               bool from_zero = false) {
   TileArgs a;
   std::memset(&a, 0, sizeof(a));
   a.states = states;
@@ -2209,13 +2249,29 @@ static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *stat
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
   if (obs_masks) std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
   a.op_begin = st.op_begin;
+  if (from_zero && st.zero_in && !init_zero) {
+    for (int j = 0; j < st.T; ++j)
+      if (st.zero_in & (1u << st.tile_bits[j])) a.zin_local |= 1u << j;
+    for (int i = 0; i < p->n - st.T; ++i)
+      if (st.zero_in & (1u << st.outer_bits[i])) a.zin_outer |= 1u << i;
+  }
   return a;
+}
+
+// A run that starts from |0..0> keeps track of the amplitudes that are still exactly zero
+// (Stage::zero_in); the prefetching experiment does not.
+static bool plan_sparse(const qmle_plan *p) {
+  static const bool pf_env = std::getenv("QMLE_PREFETCH") != nullptr;
+  return !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)) && !pf_env;
 }
 
 int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
                 const float *angles, int batch, bool init_zero, int meas, void *out,
-                const uint32_t *obs_masks, int n_obs, hipStream_t stream) {
-  TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs);
+                const uint32_t *obs_masks, int n_obs, hipStream_t stream,
+                bool from_zero = false) {
+  from_zero = from_zero && plan_sparse(p);
+  TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs,
+                              from_zero);
   a.slots_in_lds = tile_lds_bytes(st.T, st.L, a.n_ops) <= 160 * 1024 ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   static bool attr_set = false;
@@ -2275,6 +2331,16 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     return QMLE_OK;
   }
   dim3 grid(tiles, (unsigned)batch);
+  if (from_zero && meas == TM_STORE && st.next_tile) {
+    // the zero tiles are not even launched: the next tile stage never reads them
+    const uint32_t all_outer = tiles - 1u;
+    const uint32_t zo = init_zero ? all_outer : a.zin_outer;
+    if (zo) {
+      a.compact = 1;
+      a.tile_free = all_outer & ~zo;
+      grid.x = 1u << __builtin_popcount(a.tile_free);
+    }
+  }
   if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(threads), lds, stream, a);
   else hipLaunchKernelGGL(k_tile<false>, grid, dim3(threads), lds, stream, a);
   HIPCHK(hipGetLastError());
@@ -2735,7 +2801,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
         const int tm = !last_fused ? TM_STORE : single_bits ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
-                         last_fused ? n_obs : 0, stream);
+                         last_fused ? n_obs : 0, stream, /*from_zero=*/true);
         initialised = true;
       } else {
         if (!initialised) {
