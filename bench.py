@@ -220,11 +220,11 @@ def main():
         f["launches"] += stage_cnt[i]
         per_launch_states = (B * a.steps) / max(1, stage_cnt[i])
         f["algo"] += st["algo_bytes_per_state"] * per_launch_states * stage_cnt[i]
-        moved = 16.0 * D if st["kind"] != "direct" else st["algo_bytes_per_state"]
-        if i == 0 and st["kind"] == "tile":
-            moved = 8.0 * D  # first pass starts from |0..0> in LDS: write only
-        if i == len(desc["stages"]) - 1 and st["kind"] == "tile" and i > 0:
-            moved = 8.0 * D  # last pass feeds <Z> straight from LDS: read only
+        # HBM bytes the plan compiler expects this stage to move in a run from |0..0>
+        # (known-zero amplitudes are never read, all-zero tiles never stored)
+        moved = st["read_bytes_from_zero"] + st["write_bytes_from_zero"]
+        if i == len(desc["stages"]) - 1 and st["kind"] == "tile":
+            moved = st["read_bytes_from_zero"]  # <Z> straight out of the last pass: nothing stored
         f["moved"] += moved * per_launch_states * stage_cnt[i]
     dom_name = max(fam, key=lambda k: fam[k]["ms"])
     dom = fam[dom_name]

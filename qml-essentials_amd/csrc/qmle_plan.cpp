@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <sstream>
 
 #include "qmle_internal.h"
@@ -584,6 +585,31 @@ int compile_plan(qmle_plan *p) {
   return QMLE_OK;
 }
 
+// HBM bytes per state a stage moves in a run from |0..0> (TM_STORE epilogue; a fused
+// measurement in the last stage writes nothing): known-zero amplitudes are not read, tiles of
+// zeros are not stored when the next stage is a tile stage (Stage::zero_in / next_tile).
+static double stage_read_bytes(const qmle_plan *p, size_t si) {
+  const Stage &st = p->stages[si];
+  const double D = std::ldexp(1.0, p->n);
+  const bool sparse = !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
+  if (st.kind != ST_TILE) return st.kind == ST_DIRECT ? 0.5 * st.algo_bytes_per_state : 8.0 * D;
+  if (si == 0) return 0.0;  // generated in LDS
+  if (!sparse) return 8.0 * D;
+  uint32_t z = st.zero_in;
+  int nz = __builtin_popcount(z & ~1u);  // 16-byte loads: bit 0 rides along
+  return 8.0 * std::ldexp(1.0, p->n - nz);
+}
+static double stage_write_bytes(const qmle_plan *p, size_t si) {
+  const Stage &st = p->stages[si];
+  const double D = std::ldexp(1.0, p->n);
+  const bool sparse = !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
+  if (st.kind != ST_TILE) return st.kind == ST_DIRECT ? 0.5 * st.algo_bytes_per_state : 8.0 * D;
+  if (!sparse || !st.next_tile) return 8.0 * D;
+  uint32_t outer = 0;
+  for (int i = 0; i < p->n - st.T; ++i) outer |= 1u << st.outer_bits[i];
+  return 8.0 * std::ldexp(1.0, p->n - __builtin_popcount(st.zero_in & outer));
+}
+
 std::string describe_plan(const qmle_plan *p) {
   std::ostringstream os;
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
@@ -602,6 +628,8 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
        << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
+       << ",\"read_bytes_from_zero\":" << stage_read_bytes(p, s)
+       << ",\"write_bytes_from_zero\":" << stage_write_bytes(p, s)
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
     os << "],\"groups\":[";

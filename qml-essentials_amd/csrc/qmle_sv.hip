@@ -901,6 +901,166 @@ __global__ void k_tile(const TileArgs a) {
   tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
 }
 
+// ---- measuring pass in registers -----------------------------------------------------------
+// Last pass of a <Z> / Z-parity run whose gates all sit on <= 4 bit positions (ONE register-tile
+// group): nothing is staged through LDS.  Every work item loads its 16 amplitudes straight from
+// HBM (only those that can be non-zero, TileArgs::zin_local), applies the gates in registers and
+// turns |a|^2 into the 16 Walsh-Hadamard sums over its 4 bits.  A workgroup walks 2^q tiles of
+// one state; the observable's sum over tiles is accumulated PER WORK ITEM (sign = parity of
+// the tile index under the observable's outer bits, one bit mask S for all observables,
+// updated with one XOR per tile), so the cross-lane signed reduction runs once per workgroup
+// instead of once per tile.  Row layout as TM_EXPVAL_MASKS: out[b][workgroup][k < n_obs].
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
+  extern __shared__ float4 smem4[];
+  OpSlot *slots = reinterpret_cast<OpSlot *>(smem4);
+  uint32_t *meta = reinterpret_cast<uint32_t *>(slots + a.n_ops);
+  uint32_t *m_thr = meta;        // [32] observable restricted to the work-item bits
+  uint32_t *m_reg = meta + 32;   // [32] ... to the 4 register bits
+  uint32_t *m_pack = meta + 64;  // [4]  the same, 8 x 4 bits per word
+  uint32_t *flipF = meta + 68;   // [32] bit k: observable k contains outer bit j
+  uint32_t *flipP = meta + 100;  // [32] prefix XOR of flipF
+  float *red = reinterpret_cast<float *>(meta + 132);  // [16][32]
+  const int T = a.T, tid = threadIdx.x, b = blockIdx.y;
+  const int n_outer = a.n - T;
+  const OpGroup g = a.groups[0];
+  const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+
+  tile_stage_slots(a, slots, b);
+  if (tid < 32) {
+    uint32_t mt = 0, mi = 0;
+    if (tid < a.n_obs) {
+      const uint32_t m = a.obs_mask[tid];
+      int tb = 0;
+      for (int j = 0; j < T; ++j) {
+        const uint32_t bitv = (m >> a.tile_bits[j]) & 1u;
+        if (j == b0) mi |= bitv;
+        else if (j == b1) mi |= bitv << 1;
+        else if (j == b2) mi |= bitv << 2;
+        else if (j == b3) mi |= bitv << 3;
+        else mt |= bitv << tb++;
+      }
+    }
+    m_thr[tid] = mt;
+    m_reg[tid] = mi;
+    uint32_t f = 0;
+    if (tid < n_outer)
+      for (int k = 0; k < a.n_obs; ++k) f |= ((a.obs_mask[k] >> a.outer_bits[tid]) & 1u) << k;
+    flipF[tid] = f;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    uint32_t pre = 0;
+    for (int j = 0; j <= tid; ++j) pre ^= flipF[j];
+    flipP[tid] = pre;
+    if (tid < 4) {
+      uint32_t w = 0;
+      for (int k = 0; k < 8; ++k) w |= m_reg[tid * 8 + k] << (4 * k);
+      m_pack[tid] = w;
+    }
+  }
+  __syncthreads();
+  const uint32_t mi0 = __builtin_amdgcn_readfirstlane(m_pack[0]);
+  const uint32_t mi1 = __builtin_amdgcn_readfirstlane(m_pack[1]);
+  const uint32_t mi2 = __builtin_amdgcn_readfirstlane(m_pack[2]);
+  const uint32_t mi3 = __builtin_amdgcn_readfirstlane(m_pack[3]);
+
+  // this work item's 16 amplitudes: local index lb | off(c), element offset gbase + goff(c)
+  const uint32_t lb = ins0(ins0(ins0(ins0((uint32_t)tid, b0), b1), b2), b3);
+  uint32_t gbase = 0;
+  for (int j = 0; j < T; ++j) gbase |= ((lb >> j) & 1u) << a.tile_bits[j];
+  const bool thread_ok = (lb & a.zin_local) == 0;
+  const uint32_t G0 = 1u << a.tile_bits[b0], G1 = 1u << a.tile_bits[b1];
+  const uint32_t G2 = 1u << a.tile_bits[b2], G3 = 1u << a.tile_bits[b3];
+  uint32_t c_ok = 0;  // register slots that can be non-zero
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t offl = ((c & 1) ? (1u << b0) : 0u) | ((c & 2) ? (1u << b1) : 0u) |
+                          ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u);
+    if ((offl & a.zin_local) == 0) c_ok |= 1u << c;
+  }
+  const float2 *st = a.states + ((size_t)b << a.n);
+
+  float A[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) A[k] = 0.f;
+
+  const uint32_t tile0 = blockIdx.x << q;
+  uint32_t S = 0;  // bit k: sign of observable k on the current tile
+  for (int j = 0; j < n_outer; ++j)
+    if ((tile0 >> j) & 1u) S ^= flipF[j];
+  S = __builtin_amdgcn_readfirstlane(S);
+
+  for (uint32_t it = 0; it < (1u << q); ++it) {
+    const uint32_t tile = tile0 + it;
+    if ((tile & a.zin_outer) == 0) {
+      const float2 *pt = st + tile_base(a, tile) + gbase;
+      float2 v[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t go = ((c & 1) ? G0 : 0u) | ((c & 2) ? G1 : 0u) | ((c & 4) ? G2 : 0u) |
+                            ((c & 8) ? G3 : 0u);
+        v[c] = make_float2(0.f, 0.f);
+        if (((c_ok >> c) & 1u) && thread_ok) v[c] = pt[go];
+      }
+      for (int k = 0; k < g.n_ops; ++k) {
+        const OpSlot *sl = slots + (g.op_begin - a.op_begin + k);
+        const LoweredOp op = sl->op;
+        const Mat2 m = load_mat2(sl->m);
+        const int cb = op.nc ? op.c0 : -1;
+        if (op.flags & LF_PERMX) reg_dispatch<2>(v, m, cb, op.t0);
+        else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
+        else reg_dispatch<0>(v, m, cb, op.t0);
+      }
+      v16f W;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) W[c] = norm2(v[c]);
+#pragma unroll
+      for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i & h) continue;
+          const float x = W[i], y = W[i | h];
+          W[i] = x + y;
+          W[i | h] = x - y;
+        }
+      }
+#pragma unroll
+      for (int k0 = 0; k0 < 32; k0 += 8) {
+        if (k0 < a.n_obs) {
+          const uint32_t pack = k0 == 0 ? mi0 : k0 == 8 ? mi1 : k0 == 16 ? mi2 : mi3;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float w = W[(pack >> (4 * k)) & 15u];  // wave-uniform register index
+            A[k0 + k] += ((S >> (k0 + k)) & 1u) ? -w : w;
+          }
+        }
+      }
+    }
+    // next tile: the bits 0 .. (trailing ones of it) of the tile index flip
+    const int tz = __builtin_ctz(~it);
+    S ^= __builtin_amdgcn_readfirstlane(flipP[tz < 31 ? tz : 31]);
+  }
+
+  // signed sum over the work items: parity of the work-item index under the observable
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    if (__popc((uint32_t)tid & m_thr[k]) & 1) A[k] = -A[k];
+  const int lane = tid & (kWave - 1), wv = tid / kWave, nw = (blockDim.x + kWave - 1) / kWave;
+  const float mine = wave_reduce_scatter<32>(A);
+  if (lane < 32) red[wv * 32 + lane] = mine;
+  __syncthreads();
+  float *po = reinterpret_cast<float *>(a.out) +
+              ((size_t)b * gridDim.x + blockIdx.x) * (QMLE_MAX_QUBITS + 1);
+  if (tid <= QMLE_MAX_QUBITS) {
+    float r = 0.f;
+    if (tid < a.n_obs)
+      for (int w = 0; w < nw; ++w) r += red[w * 32 + tid];
+    po[tid] = r;
+  }
+}
+
 // ---- whole-circuit adjoint in LDS (n <= 13) ----------------------------------------------
 // One workgroup per sample keeps psi AND lambda in LDS: forward circuit (fused gate groups),
 // lambda = (sum_k w_k Z_k) psi, then for every gate of the reversed, daggered tape the
@@ -2347,6 +2507,33 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   return QMLE_OK;
 }
 
+// k_reg_measure takes the last pass of a <Z> run when all its gates share one register-tile group
+static bool reg_measure_ok(const qmle_plan *p, const Stage &st, int n_obs) {
+  static const bool off = std::getenv("QMLE_NO_REG_MEASURE") != nullptr;
+  if (off || (p->flags & QMLE_PLAN_PREFETCH) || st.grp_end - st.grp_begin != 1) return false;
+  if (p->op_groups[st.grp_begin].kind != GK_REG4) return false;
+  return st.T >= 10 && st.T <= 14 && st.T < p->n && n_obs >= 1 && n_obs <= 32 &&
+         (size_t)(st.op_end - st.op_begin) * sizeof(OpSlot) <= 48 * 1024;
+}
+
+static int launch_reg_measure(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
+                              const float *angles, int batch, void *out, const uint32_t *obs_masks,
+                              int n_obs, hipStream_t stream, int *q_out) {
+  TileArgs a = fill_tile_args(p, st, states, mats, angles, false, TM_EXPVAL_MASKS, out, obs_masks,
+                              n_obs, plan_sparse(p));
+  a.slots_in_lds = 1;
+  const int n_outer = p->n - st.T;
+  // ~4096 workgroups per launch when the batch allows, at most 64 tiles per workgroup
+  int q = 0;
+  while (q < 6 && q < n_outer && (((uint64_t)batch << n_outer) >> (q + 1)) >= 4096) ++q;
+  const size_t lds = (size_t)a.n_ops * sizeof(OpSlot) + (132 + 16 * 32) * sizeof(uint32_t);
+  dim3 grid(1u << (n_outer - q), (unsigned)batch);
+  hipLaunchKernelGGL(k_reg_measure, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
+  HIPCHK(hipGetLastError());
+  *q_out = q;
+  return QMLE_OK;
+}
+
 template <int MODE>
 void launch_direct_mode(bool diag, bool nt, dim3 grid, hipStream_t stream, float4 *st, int n,
                         int pt, int pc, const float *mats, uint32_t mat_floats,
@@ -2793,12 +2980,18 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
     const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
     const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
     bool initialised = false;
+    int reg_q = -1;  // >= 0: the last pass ran as k_reg_measure with 2^reg_q tiles per row
     for (size_t si = 0; si < plan->stages.size(); ++si) {
       const Stage &st = plan->stages[si];
       ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE) {
         const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
         const int tm = !last_fused ? TM_STORE : single_bits ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
+        reg_q = -1;
+        if (last_fused && initialised && reg_measure_ok(plan, st, n_obs)) {
+          rc = launch_reg_measure(plan, st, stc, mats, ang, bc, d_partial, obs_masks, n_obs,
+                                  stream, &reg_q);
+        } else
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
                          last_fused ? n_obs : 0, stream, /*from_zero=*/true);
@@ -2832,8 +3025,8 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
                          reinterpret_cast<float2 *>((float *)d_out + (size_t)b0 * D), tc);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
       ObsBits ob;  // column of the 33-float row: the bit's sum, or (masks) the observable's own
-      for (int k = 0; k < n_obs; ++k) ob.bits[k] = single_bits ? obs_bits[k] : (int8_t)k;
-      const int tiles = 1 << (n - plan->stages.back().T);
+      for (int k = 0; k < n_obs; ++k) ob.bits[k] = (single_bits && reg_q < 0) ? obs_bits[k] : (int8_t)k;
+      const int tiles = (1 << (n - plan->stages.back().T)) >> (reg_q < 0 ? 0 : reg_q);
       hipLaunchKernelGGL(k_expval_final, dim3(bc, n_obs), dim3(256), 0, stream, (const float *)d_partial,
                          tiles, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {

@@ -413,3 +413,63 @@ def test_known_zero_amplitudes_are_skipped_bit_exactly(n, tile_bits, low_bits):
             assert np.array_equal(got, want), name
         psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
         assert np.abs(res["sparse"][0][0] - psi).max() < 2e-6, name
+
+
+@pytest.mark.parametrize("n,tile_bits,low_bits,B", [(16, 12, 4, 5), (17, 11, 3, 3), (18, 13, 5, 2), (20, 12, 4, 70)])
+def test_register_measuring_last_pass(n, tile_bits, low_bits, B):
+    """k_reg_measure: a last pass whose gates share one register-tile group runs without LDS
+    staging and accumulates the observables across tiles per work item.  Dense input (a
+    full-register diagonal separates a deep head from a 4-wire tail) and known-zero input
+    (shallow circuit), single-bit <Z> and parity observables, against the stored state (k_tile's
+    store epilogue, itself oracle-checked above) and, for the shallow circuit, the fp64 oracle."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(n * 31 + B)
+    ang = lambda: (float(rng.uniform(0, 6.28)),)
+    last4 = [n - 1 - p for p in (tile_bits - 1, tile_bits - 2, tile_bits - 3, tile_bits - 4)]  # wires of 4 tile bits
+    head = random_tape(n, 50, rng) + [("RY", [q], ang()) for q in range(n)]
+    tail = [("RX", [w], ang()) for w in last4] + [("CRY", [last4[0], last4[1]], ang()),
+                                                   ("CX", [last4[2], last4[3]], ()), ("RZ", [last4[1]], ang())]
+    marks = rng.integers(0, 50, size=1 << n).astype(np.float32)
+    x = 0.37
+    ops1, ang1, c1 = tape_to_native(head, n)
+    ops3, ang3, _ = tape_to_native(tail, n)
+    base = len(ang1) + 1
+    dense_ops = (ops1 + [("DIAG_ALL", [], [len(ang1)], len(c1))] +
+                 [(nm, w, [s_ + base for s_ in sl], off) for nm, w, sl, off in ops3])
+    dense_ang = np.concatenate([ang1, [x], ang3]).astype(np.float32)
+    dense_consts = np.concatenate([c1, marks]).astype(np.float32)
+    dense_oracle = None  # (the oracle applies a full-register diagonal as a 2^n x 2^n matrix)
+    shallow = [(g_, [q], ang()) for g_ in ("RY", "RZ") for q in range(n)]
+    sh_ops, sh_ang, sh_consts = tape_to_native(shallow, n)
+    cases = {"dense": (dense_ops, dense_ang, dense_consts, dense_oracle),
+             "shallow": (sh_ops, sh_ang, sh_consts, shallow)}
+    if n >= 20:
+        del cases["dense"]  # 2^20 marks: keep the oracle run short
+    for name, (ops, angles, consts, otape) in cases.items():
+        table = rng.uniform(0, 2 * np.pi, size=(B, len(angles))).astype(np.float32)
+        table[0] = angles
+        a_dev = torch.from_numpy(table).cuda()
+        flags = N.plan_flags(force_global=True, force_tile=True, tile_bits=tile_bits, low_bits=low_bits,
+                             no_absorb=True)
+        plan = N.Plan(ops, n, len(angles), consts, flags)
+        st = plan.describe()["stages"]
+        if name == "dense":  # (the shallow plan ends in a single-group pass for n - T <= 4)
+            assert st[-1]["kind"] == "tile" and st[-1]["lds_round_trips"] == 1 and len(st) >= 2, st[-1]
+        masks = [[0], [n - 1], [1, n - 2], last4[:2], last4, [0, last4[3], n - 1], list(range(n))]
+        ez = plan.run(a_dev, "expval", list(range(n))).cpu().numpy()
+        par = plan.run_parity(a_dev, masks).cpu().numpy()
+        psi = plan.run(a_dev, "state").cpu().numpy().astype(np.complex128)
+        pr = np.abs(psi) ** 2
+        idx = np.arange(1 << n)
+        for w in range(n):
+            sign = 1.0 - 2.0 * ((idx >> (n - 1 - w)) & 1)
+            assert np.abs(ez[:, w] - pr @ sign).max() < 2e-6, (name, w)
+        for k, mk in enumerate(masks):
+            par_bits = np.zeros(1 << n, dtype=np.int64)
+            for w in mk:
+                par_bits ^= (idx >> (n - 1 - w)) & 1
+            assert np.abs(par[:, k] - pr @ (1.0 - 2.0 * par_bits)).max() < 2e-6, (name, mk)
+        if otape is not None:
+            want = OE.simulate_and_measure(otape, n, "expval", [("PauliZ", [w]) for w in range(n)], np.complex128)
+            assert np.abs(ez[0] - want).max() < 3e-6, name
