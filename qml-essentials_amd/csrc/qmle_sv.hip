@@ -912,6 +912,20 @@ __global__ void k_tile(const TileArgs a) {
 // instead of once per tile.  Row layout as TM_EXPVAL_MASKS: out[b][workgroup][k < n_obs].
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ void reg_apply_group(float2 (&v)[16], const OpGroup &g,
+                                                const OpSlot *slots, int op_base) {
+  for (int k = 0; k < g.n_ops; ++k) {
+    const OpSlot *sl = slots + (g.op_begin - op_base + k);
+    const LoweredOp op = sl->op;
+    const Mat2 m = load_mat2(sl->m);
+    const int cb = op.nc ? op.c0 : -1;
+    if (op.flags & LF_PERMX) reg_dispatch<2>(v, m, cb, op.t0);
+    else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
+    else reg_dispatch<0>(v, m, cb, op.t0);
+  }
+}
+
+template <bool FOLD>
 __global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
   extern __shared__ float4 smem4[];
   OpSlot *slots = reinterpret_cast<OpSlot *>(smem4);
@@ -982,36 +996,76 @@ __global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
   }
   const float2 *st = a.states + ((size_t)b << a.n);
 
-  float A[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) A[k] = 0.f;
-
   const uint32_t tile0 = blockIdx.x << q;
   uint32_t S = 0;  // bit k: sign of observable k on the current tile
   for (int j = 0; j < n_outer; ++j)
     if ((tile0 >> j) & 1u) S ^= flipF[j];
   S = __builtin_amdgcn_readfirstlane(S);
 
+  // FOLD: few live inputs (<= 4 of the 16 register slots can be non-zero) -- the group's gates
+  // act on known zeros almost everywhere, so the work item's 16 outputs are sum_j in_j * (U e_j)
+  // and the columns U e_j are the same for the whole workgroup.  The gate code runs once, on
+  // the basis vectors, and parks the columns in LDS; a tile then costs `cols` complex
+  // multiply-adds per amplitude instead of the whole gate list.
+  const int cols = __popc(c_ok);
+  float2 *tcol = reinterpret_cast<float2 *>(red + 16 * 32);  // [4][16]
+  uint32_t ingo[4];  // element offset of live input j
+  {
+    int okc[4];  // register slot of live input j
+    uint32_t rest = c_ok;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      okc[j] = rest ? __builtin_ctz(rest) : 0;
+      rest &= rest - 1u;
+      ingo[j] = ((okc[j] & 1) ? G0 : 0u) | ((okc[j] & 2) ? G1 : 0u) | ((okc[j] & 4) ? G2 : 0u) |
+                ((okc[j] & 8) ? G3 : 0u);
+    }
+    if (FOLD) {
+      float2 v[16];
+      const int mine = okc[(tid & 3) < cols ? (tid & 3) : 0];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) v[c] = make_float2(c == mine ? 1.f : 0.f, 0.f);
+      reg_apply_group(v, g, slots, a.op_begin);
+      if (tid < cols) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tcol[tid * 16 + c] = v[c];
+      }
+      __syncthreads();
+    }
+  }
+
+  float A[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) A[k] = 0.f;
+
   for (uint32_t it = 0; it < (1u << q); ++it) {
     const uint32_t tile = tile0 + it;
     if ((tile & a.zin_outer) == 0) {
       const float2 *pt = st + tile_base(a, tile) + gbase;
       float2 v[16];
+      if (FOLD) {
+        float2 in[4];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const uint32_t go = ((c & 1) ? G0 : 0u) | ((c & 2) ? G1 : 0u) | ((c & 4) ? G2 : 0u) |
-                            ((c & 8) ? G3 : 0u);
-        v[c] = make_float2(0.f, 0.f);
-        if (((c_ok >> c) & 1u) && thread_ok) v[c] = pt[go];
-      }
-      for (int k = 0; k < g.n_ops; ++k) {
-        const OpSlot *sl = slots + (g.op_begin - a.op_begin + k);
-        const LoweredOp op = sl->op;
-        const Mat2 m = load_mat2(sl->m);
-        const int cb = op.nc ? op.c0 : -1;
-        if (op.flags & LF_PERMX) reg_dispatch<2>(v, m, cb, op.t0);
-        else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
-        else reg_dispatch<0>(v, m, cb, op.t0);
+        for (int j = 0; j < 4; ++j) {
+          in[j] = make_float2(0.f, 0.f);
+          if (j < cols && thread_ok) in[j] = pt[ingo[j]];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = cmul(tcol[c], in[0]);
+        for (int j = 1; j < cols; ++j) {
+          const float2 x = j == 1 ? in[1] : j == 2 ? in[2] : in[3];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] = cfma(tcol[j * 16 + c], x, v[c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const uint32_t go = ((c & 1) ? G0 : 0u) | ((c & 2) ? G1 : 0u) | ((c & 4) ? G2 : 0u) |
+                              ((c & 8) ? G3 : 0u);
+          v[c] = make_float2(0.f, 0.f);
+          if (((c_ok >> c) & 1u) && thread_ok) v[c] = pt[go];
+        }
+        reg_apply_group(v, g, slots, a.op_begin);
       }
       v16f W;
 #pragma unroll
@@ -2526,9 +2580,16 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, float2 *state
   // ~4096 workgroups per launch when the batch allows, at most 64 tiles per workgroup
   int q = 0;
   while (q < 6 && q < n_outer && (((uint64_t)batch << n_outer) >> (q + 1)) >= 4096) ++q;
-  const size_t lds = (size_t)a.n_ops * sizeof(OpSlot) + (132 + 16 * 32) * sizeof(uint32_t);
+  const size_t lds = (size_t)a.n_ops * sizeof(OpSlot) + (132 + 16 * 32 + 128) * sizeof(uint32_t);
   dim3 grid(1u << (n_outer - q), (unsigned)batch);
-  hipLaunchKernelGGL(k_reg_measure, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
+  // live register slots: the group bits that are not known-zero on input
+  int live_bits = 0;
+  const OpGroup &g = p->op_groups[st.grp_begin];
+  for (int j = 0; j < 4; ++j) live_bits += !((a.zin_local >> g.bits[j]) & 1u);
+  if (live_bits <= 2 && g.n_ops > 0)
+    hipLaunchKernelGGL(k_reg_measure<true>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
+  else
+    hipLaunchKernelGGL(k_reg_measure<false>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
   HIPCHK(hipGetLastError());
   *q_out = q;
   return QMLE_OK;

@@ -386,7 +386,8 @@ def _shallow_tapes(n, rng):
 def test_known_zero_amplitudes_are_skipped_bit_exactly(n, tile_bits, low_bits):
     """Runs from |0..0> do not read, compute or store amplitudes that are provably zero
     (Stage::zero_in, compact grids): results are bit-identical to the dense run
-    (QMLE_PLAN_NO_SPARSE) for state / probs / <Z> / parities, and match the oracle."""
+    (QMLE_PLAN_NO_SPARSE) for state / probs, equal to float32 rounding for <Z> / parities, and
+    match the oracle."""
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n * 100 + tile_bits)
@@ -409,8 +410,12 @@ def test_known_zero_amplitudes_are_skipped_bit_exactly(n, tile_bits, low_bits):
             if mode == "sparse" and name == "he":
                 st = plan.describe()["stages"]
                 assert len(st) >= 2 and st[0]["zero_in"] == (1 << n) - 1 and st[1]["zero_in"] != 0
-        for got, want in zip(res["sparse"], res["dense"]):
+        for got, want in zip(res["sparse"][:2], res["dense"][:2]):
             assert np.array_equal(got, want), name
+        # <Z> / parities: the measuring pass folds gates on known-zero inputs into per-workgroup
+        # columns (k_reg_measure<FOLD>) -- same numbers up to float32 rounding
+        for got, want in zip(res["sparse"][2:], res["dense"][2:]):
+            assert np.abs(got - want).max() < 1e-6, name
         psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
         assert np.abs(res["sparse"][0][0] - psi).max() < 2e-6, name
 
