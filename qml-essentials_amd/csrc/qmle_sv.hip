@@ -1038,18 +1038,30 @@ __global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
 #pragma unroll
   for (int k = 0; k < 32; ++k) A[k] = 0.f;
 
+  // FOLD: the (few) inputs of the next tile are requested before this tile is worked on
+  float2 nxt[4];
+  auto fetch = [&](uint32_t tile) {
+    const float2 *pt = st + tile_base(a, tile) + gbase;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nxt[j] = make_float2(0.f, 0.f);
+      if (j < cols && thread_ok && (tile & a.zin_outer) == 0) nxt[j] = pt[ingo[j]];
+    }
+  };
+  if (FOLD) fetch(tile0);
+
   for (uint32_t it = 0; it < (1u << q); ++it) {
     const uint32_t tile = tile0 + it;
+    float2 in[4];
+    if (FOLD) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) in[j] = nxt[j];
+      if (it + 1 < (1u << q)) fetch(tile + 1);
+    }
     if ((tile & a.zin_outer) == 0) {
       const float2 *pt = st + tile_base(a, tile) + gbase;
       float2 v[16];
       if (FOLD) {
-        float2 in[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          in[j] = make_float2(0.f, 0.f);
-          if (j < cols && thread_ok) in[j] = pt[ingo[j]];
-        }
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = cmul(tcol[c], in[0]);
         for (int j = 1; j < cols; ++j) {
@@ -1101,6 +1113,130 @@ __global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
 #pragma unroll
   for (int k = 0; k < 32; ++k)
     if (__popc((uint32_t)tid & m_thr[k]) & 1) A[k] = -A[k];
+  const int lane = tid & (kWave - 1), wv = tid / kWave, nw = (blockDim.x + kWave - 1) / kWave;
+  const float mine = wave_reduce_scatter<32>(A);
+  if (lane < 32) red[wv * 32 + lane] = mine;
+  __syncthreads();
+  float *po = reinterpret_cast<float *>(a.out) +
+              ((size_t)b * gridDim.x + blockIdx.x) * (QMLE_MAX_QUBITS + 1);
+  if (tid <= QMLE_MAX_QUBITS) {
+    float r = 0.f;
+    if (tid < a.n_obs)
+      for (int w = 0; w < nw; ++w) r += red[w * 32 + tid];
+    po[tid] = r;
+  }
+}
+
+// k_reg_measure when ALL FOUR register bits are known-zero on input: the work item reads one
+// amplitude x per tile and its 16 outputs are x * (U e_0), so every Walsh-Hadamard sum of the
+// tile is |x|^2 times a number that is the same for the whole workgroup (coef_k, from U e_0).
+// What is left per tile is |x|^2; the signs of the 32 tiles a workgroup walks (parity of the
+// tile index under the observable's outer bits) are applied by ONE more Walsh-Hadamard
+// transform, over the tile axis, held in registers: 32 independent 8-byte loads in flight per
+// work item, 2.5 adds per tile, and one signed cross-lane reduction per workgroup.
+typedef float v32f __attribute__((ext_vector_type(32)));
+
+__global__ void __launch_bounds__(1024) k_reg_measure_mono(const TileArgs a) {
+  constexpr int Q = 5;
+  extern __shared__ float4 smem4[];
+  OpSlot *slots = reinterpret_cast<OpSlot *>(smem4);
+  uint32_t *meta = reinterpret_cast<uint32_t *>(slots + a.n_ops);
+  uint32_t *m_thr = meta;        // [32] observable restricted to the work-item bits
+  uint32_t *m_reg = meta + 32;   // [32] ... to the 4 register bits
+  uint32_t *m_out = meta + 64;   // [32] ... to the outer (tile index) bits
+  float *red = reinterpret_cast<float *>(meta + 132);  // [16][32]
+  const int T = a.T, tid = threadIdx.x, b = blockIdx.y;
+  const int n_outer = a.n - T;
+  const OpGroup g = a.groups[0];
+  const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
+
+  tile_stage_slots(a, slots, b);
+  if (tid < 32) {
+    uint32_t mt = 0, mi = 0, mo = 0;
+    if (tid < a.n_obs) {
+      const uint32_t m = a.obs_mask[tid];
+      int tb = 0;
+      for (int j = 0; j < T; ++j) {
+        const uint32_t bitv = (m >> a.tile_bits[j]) & 1u;
+        if (j == b0) mi |= bitv;
+        else if (j == b1) mi |= bitv << 1;
+        else if (j == b2) mi |= bitv << 2;
+        else if (j == b3) mi |= bitv << 3;
+        else mt |= bitv << tb++;
+      }
+      for (int j = 0; j < n_outer; ++j) mo |= ((m >> a.outer_bits[j]) & 1u) << j;
+    }
+    m_thr[tid] = mt;
+    m_reg[tid] = mi;
+    m_out[tid] = mo;
+  }
+  __syncthreads();
+
+  // U e_0 and the Walsh-Hadamard sums of |U e_0|^2 (every work item, redundantly: wave-uniform)
+  v16f Wt;
+  {
+    float2 v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = make_float2(c == 0 ? 1.f : 0.f, 0.f);
+    reg_apply_group(v, g, slots, a.op_begin);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Wt[c] = norm2(v[c]);
+#pragma unroll
+    for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i & h) continue;
+        const float x = Wt[i], y = Wt[i | h];
+        Wt[i] = x + y;
+        Wt[i | h] = x - y;
+      }
+    }
+  }
+
+  const uint32_t lb = ins0(ins0(ins0(ins0((uint32_t)tid, b0), b1), b2), b3);
+  uint32_t gbase = 0;
+  for (int j = 0; j < T; ++j) gbase |= ((lb >> j) & 1u) << a.tile_bits[j];
+  const bool thread_ok = (lb & a.zin_local) == 0;
+  const uint32_t tile0 = blockIdx.x << Q;
+  const float2 *pt = a.states + ((size_t)b << a.n) + tile_base(a, tile0) + gbase;
+  uint32_t ostride[Q];  // element offsets of the 5 low tile-index bits
+#pragma unroll
+  for (int j = 0; j < Q; ++j) ostride[j] = 1u << a.outer_bits[j];
+
+  v32f P;
+#pragma unroll
+  for (int it = 0; it < (1 << Q); ++it) {
+    uint32_t off = 0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+      if ((it >> j) & 1) off |= ostride[j];
+    float2 x = make_float2(0.f, 0.f);
+    if (thread_ok && ((tile0 + (uint32_t)it) & a.zin_outer) == 0) x = pt[off];
+    P[it] = norm2(x);
+  }
+#pragma unroll
+  for (int h = 1; h < (1 << Q); h <<= 1) {
+#pragma unroll
+    for (int i = 0; i < (1 << Q); ++i) {
+      if (i & h) continue;
+      const float x = P[i], y = P[i | h];
+      P[i] = x + y;
+      P[i | h] = x - y;
+    }
+  }
+
+  float A[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    A[k] = 0.f;
+    if (k < a.n_obs) {
+      const uint32_t mo = __builtin_amdgcn_readfirstlane(m_out[k]);
+      const uint32_t mi = __builtin_amdgcn_readfirstlane(m_reg[k]);
+      float val = P[mo & ((1u << Q) - 1u)] * Wt[mi & 15u];  // wave-uniform register indices
+      const uint32_t par = (__popc(tile0 & mo) + __popc((uint32_t)tid & m_thr[k])) & 1u;
+      A[k] = par ? -val : val;
+    }
+  }
   const int lane = tid & (kWave - 1), wv = tid / kWave, nw = (blockDim.x + kWave - 1) / kWave;
   const float mine = wave_reduce_scatter<32>(A);
   if (lane < 32) red[wv * 32 + lane] = mine;
@@ -2586,7 +2722,11 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, float2 *state
   int live_bits = 0;
   const OpGroup &g = p->op_groups[st.grp_begin];
   for (int j = 0; j < 4; ++j) live_bits += !((a.zin_local >> g.bits[j]) & 1u);
-  if (live_bits <= 2 && g.n_ops > 0)
+  if (live_bits == 0 && n_outer >= 5) {
+    q = 5;
+    grid.x = 1u << (n_outer - q);
+    hipLaunchKernelGGL(k_reg_measure_mono, grid, dim3(1u << (st.T - 4)), lds, stream, a);
+  } else if (live_bits <= 2 && g.n_ops > 0)
     hipLaunchKernelGGL(k_reg_measure<true>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
   else
     hipLaunchKernelGGL(k_reg_measure<false>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
