@@ -139,6 +139,41 @@ def cpu_baseline(n, params_row, budget_s):
                       f"{el:.1f} s"}
 
 
+def dense_state_run(n, B, params_dev, n_gates, folded):
+    """The same step with known-zero tracking switched off (QMLE_PLAN_NO_SPARSE): every pass
+    reads / computes / stores all 2^n amplitudes, as a circuit without exploitable zeros would.
+    Reported beside `value` so that the gain from skipping known zeros is visible as such."""
+    import torch
+    from qml_essentials_amd import _native as N
+    from qml_essentials_amd import simulation
+    from qml_essentials_amd.model import Model
+
+    saved = simulation.PLAN_FLAGS
+    simulation.PLAN_FLAGS = saved | N.PLAN_NO_SPARSE
+    try:
+        model = Model(n, 1, "Hardware_Efficient", data_reupload=False)
+        tape, _ = model.record_tape(params=params_dev[:2].cpu().numpy())
+        plan = simulation.get_plan(simulation.LoweredTape(tape, n))
+        plan = plan.expval_child() or plan
+        st = plan.describe()["stages"]
+        moved = sum(s_["read_bytes_from_zero"] + (s_["write_bytes_from_zero"] if i + 1 < len(st) else 0.0)
+                    for i, s_ in enumerate(st))
+        model(params=params_dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(params=params_dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        simulation.PLAN_FLAGS = saved
+    return {"ms_per_step": round(dt * 1e3, 3), "gate_applies_per_s": round(n_gates * B / dt, 1),
+            "statevectors_per_s": round(B / dt, 2), "hbm_passes_per_state": len(st),
+            "hbm_bytes_moved_per_state": moved,
+            "moved_GBps": round(moved * B / dt / 1e9, 1),
+            "moved_frac_of_8TBps": round(moved * B / dt / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "QMLE_PLAN_NO_SPARSE: all 2^n amplitudes read / computed / stored in every pass"}
+
+
 def main():
     a = parse_args()
     from qml_essentials_amd import distributed
@@ -215,6 +250,8 @@ def main():
     fam = {}
     for i, st in enumerate(desc["stages"]):
         k = {"tile": "k_tile", "direct": "k_direct_1q", "diag_all": "k_diag_all"}[st["kind"]]
+        if i == len(desc["stages"]) - 1 and st["kind"] == "tile":
+            k = st["expval_kernel"].replace("_fold", "")  # <Z> out of the last pass: which kernel runs it
         f = fam.setdefault(k, {"ms": 0.0, "launches": 0, "algo": 0.0, "moved": 0.0})
         f["ms"] += stage_ms[i]
         f["launches"] += stage_cnt[i]
@@ -249,8 +286,11 @@ def main():
         "moved_frac": round(dom["moved"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if dom["ms"] > 0 else 0.0,
         "note": "algorithmic bytes = sum of the per-gate bytes (SURVEY 8-d) of the reference "
-                "gates one launch applies; a fused pass applies many gates per HBM round trip, "
-                "so achieved may exceed the HBM peak; moved_GBps is the real stream rate",
+                "gates one launch applies; a fused pass applies many gates per HBM round trip and "
+                "a run from |0..0> never reads or stores amplitudes that are still exactly zero, "
+                "so achieved exceeds the HBM peak; bytes_moved / moved_GBps is the real stream "
+                "(tiny here: the dominant kernel is bound by instruction issue, not HBM); "
+                "dense_state and k1_single_gate_28q are the HBM-streaming figures",
         "event_pool_overflow": overflow,
     }
     result = {
@@ -271,6 +311,8 @@ def main():
         "gate_applies_per_s_state_applied_only": round((n_gates - folded) * total_states / elapsed, 1),
         "roofline": roofline,
     }
+    if not a.skip_aux and size == 1 and not a.no_fusion:
+        result["dense_state"] = dense_state_run(n, B, params_dev, n_gates, folded)
     if not a.skip_aux and size == 1:
         result["cpu_baseline"] = cpu_baseline(n, params[:64], a.cpu_seconds)
         try:

@@ -158,6 +158,10 @@ void split_expval_tail(const std::vector<qmle_op> &ops, int n, std::vector<qmle_
 // Z on `wire` pulled back through the absorbed gates: bit w set <=> Z_w in the parity.
 uint32_t pull_back_z(const std::vector<qmle_op> &absorbed, int wire);
 std::string describe_plan(const qmle_plan *p);
+// Which kernel measures <Z> / Z parities out of stage `si` when it is the last one of a run
+// from |0..0>: 0 k_tile epilogue, 1 k_reg_measure<false>, 2 k_reg_measure<true> (gates folded
+// into columns), 3 k_reg_measure_mono.  `sparse`: known-zero tracking is on for the run.
+int expval_kernel_of(const qmle_plan *p, size_t si, bool sparse);
 double algo_bytes(const qmle_op &op, int n);
 constexpr int kLdsMaxQubits = 14;       // 2^14 * 8 B = 128 KiB <= 160 KiB LDS/CU
 constexpr int kDefaultTileBits = 13;    // 64 KiB tile -> 2 workgroups per CU

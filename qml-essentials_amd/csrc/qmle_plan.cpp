@@ -610,6 +610,19 @@ static double stage_write_bytes(const qmle_plan *p, size_t si) {
   return 8.0 * std::ldexp(1.0, p->n - __builtin_popcount(st.zero_in & outer));
 }
 
+int expval_kernel_of(const qmle_plan *p, size_t si, bool sparse) {
+  const Stage &st = p->stages[si];
+  if (st.kind != ST_TILE || si == 0 || (p->flags & QMLE_PLAN_PREFETCH)) return 0;
+  if (st.grp_end - st.grp_begin != 1 || p->op_groups[st.grp_begin].kind != GK_REG4) return 0;
+  if (st.T < 10 || st.T > 14 || st.T >= p->n || (st.op_end - st.op_begin) > 1000) return 0;
+  const OpGroup &g = p->op_groups[st.grp_begin];
+  int live_bits = 0;  // register bits that are not known-zero on input
+  for (int j = 0; j < 4; ++j)
+    live_bits += !(sparse && ((st.zero_in >> st.tile_bits[g.bits[j]]) & 1u));
+  if (live_bits == 0 && p->n - st.T >= 5) return 3;
+  return live_bits <= 2 && g.n_ops > 0 ? 2 : 1;
+}
+
 std::string describe_plan(const qmle_plan *p) {
   std::ostringstream os;
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
@@ -628,7 +641,10 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
        << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
-       << ",\"read_bytes_from_zero\":" << stage_read_bytes(p, s)
+       << ",\"expval_kernel\":\""
+       << (const char *[]){"k_tile", "k_reg_measure", "k_reg_measure_fold", "k_reg_measure_mono"}
+              [expval_kernel_of(p, s, !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)))]
+       << "\",\"read_bytes_from_zero\":" << stage_read_bytes(p, s)
        << ",\"write_bytes_from_zero\":" << stage_write_bytes(p, s)
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];

@@ -2697,18 +2697,17 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   return QMLE_OK;
 }
 
-// k_reg_measure takes the last pass of a <Z> run when all its gates share one register-tile group
-static bool reg_measure_ok(const qmle_plan *p, const Stage &st, int n_obs) {
+// k_reg_measure* takes the last pass of a <Z> run when all its gates share one register-tile
+// group (expval_kernel_of, qmle_plan.cpp)
+static int reg_measure_kind(const qmle_plan *p, size_t si, int n_obs) {
   static const bool off = std::getenv("QMLE_NO_REG_MEASURE") != nullptr;
-  if (off || (p->flags & QMLE_PLAN_PREFETCH) || st.grp_end - st.grp_begin != 1) return false;
-  if (p->op_groups[st.grp_begin].kind != GK_REG4) return false;
-  return st.T >= 10 && st.T <= 14 && st.T < p->n && n_obs >= 1 && n_obs <= 32 &&
-         (size_t)(st.op_end - st.op_begin) * sizeof(OpSlot) <= 48 * 1024;
+  if (off || n_obs < 1 || n_obs > 32) return 0;
+  return expval_kernel_of(p, si, plan_sparse(p));
 }
 
-static int launch_reg_measure(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
-                              const float *angles, int batch, void *out, const uint32_t *obs_masks,
-                              int n_obs, hipStream_t stream, int *q_out) {
+static int launch_reg_measure(const qmle_plan *p, const Stage &st, int kind, float2 *states,
+                              const float *mats, const float *angles, int batch, void *out,
+                              const uint32_t *obs_masks, int n_obs, hipStream_t stream, int *q_out) {
   TileArgs a = fill_tile_args(p, st, states, mats, angles, false, TM_EXPVAL_MASKS, out, obs_masks,
                               n_obs, plan_sparse(p));
   a.slots_in_lds = 1;
@@ -2716,17 +2715,12 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, float2 *state
   // ~4096 workgroups per launch when the batch allows, at most 64 tiles per workgroup
   int q = 0;
   while (q < 6 && q < n_outer && (((uint64_t)batch << n_outer) >> (q + 1)) >= 4096) ++q;
+  if (kind == 3) q = 5;
   const size_t lds = (size_t)a.n_ops * sizeof(OpSlot) + (132 + 16 * 32 + 128) * sizeof(uint32_t);
   dim3 grid(1u << (n_outer - q), (unsigned)batch);
-  // live register slots: the group bits that are not known-zero on input
-  int live_bits = 0;
-  const OpGroup &g = p->op_groups[st.grp_begin];
-  for (int j = 0; j < 4; ++j) live_bits += !((a.zin_local >> g.bits[j]) & 1u);
-  if (live_bits == 0 && n_outer >= 5) {
-    q = 5;
-    grid.x = 1u << (n_outer - q);
+  if (kind == 3)
     hipLaunchKernelGGL(k_reg_measure_mono, grid, dim3(1u << (st.T - 4)), lds, stream, a);
-  } else if (live_bits <= 2 && g.n_ops > 0)
+  else if (kind == 2)
     hipLaunchKernelGGL(k_reg_measure<true>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
   else
     hipLaunchKernelGGL(k_reg_measure<false>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
@@ -2945,12 +2939,14 @@ static size_t ws_mats_bytes(const qmle_plan *p, int batch) {
 static int default_states_in_flight(const qmle_plan *p, int batch) {
   // states per launch: the tile passes are LDS/VALU-bound, so big launches (fewer tails)
   // beat Infinity-Cache residency -- measured 3.4k -> 4.1k statevectors/s at n = 24 going
-  // from 1 to 32 states in flight (profiles/r01_in_flight_sweep.txt)
+  // from 1 to 32 states in flight, +1 % more at 128 (profiles/r01_in_flight_sweep.txt); runs
+  // that skip known zeros are launch-bound at 32 (11.5 M -> 14.3 M -> 15.2 M gate-applies/s at
+  // 32 / 128 / 512 states, K2).  32 GiB of state buffers = 256 states at n = 24.
   const size_t sb = (size_t)8 << p->n;
   static const size_t budget_mib = [] {
     const char *e = getenv("QMLE_IN_FLIGHT_MIB");  // tuning knob; default from measurements
     const long v = e ? atol(e) : 0;
-    return (size_t)(v > 0 ? v : 4096);
+    return (size_t)(v > 0 ? v : 32768);
   }();
   size_t s = (budget_mib << 20) / sb;
   if (s < 1) s = 1;
@@ -3189,9 +3185,10 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
         const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
         const int tm = !last_fused ? TM_STORE : single_bits ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
         reg_q = -1;
-        if (last_fused && initialised && reg_measure_ok(plan, st, n_obs)) {
-          rc = launch_reg_measure(plan, st, stc, mats, ang, bc, d_partial, obs_masks, n_obs,
-                                  stream, &reg_q);
+        const int reg_kind = last_fused && initialised ? reg_measure_kind(plan, si, n_obs) : 0;
+        if (reg_kind) {
+          rc = launch_reg_measure(plan, st, reg_kind, stc, mats, ang, bc, d_partial, obs_masks,
+                                  n_obs, stream, &reg_q);
         } else
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,

@@ -16,7 +16,7 @@ import numpy as np
 log = logging.getLogger(__name__)
 
 COMPLEX_BYTES, REAL_BYTES = 8, 4  # complex64 / float32
-IN_FLIGHT_TARGET_BYTES = 4096 << 20  # states per engine launch (mirrors libqmle_sv's default)
+IN_FLIGHT_TARGET_BYTES = 32768 << 20  # states per engine launch (mirrors libqmle_sv's default)
 
 
 def available_memory_bytes() -> int:
