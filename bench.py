@@ -41,8 +41,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-qubits", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1024, help="statevectors per GPU per step")
     ap.add_argument("--no-fusion", action="store_true", help="one HBM pass per reference gate")
