@@ -365,7 +365,8 @@ template <bool SLOTS>
 __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
                                                 const LoweredOp *__restrict__ ops,
                                                 const float *__restrict__ mrow,
-                                                const OpSlot *__restrict__ slots, int op_base) {
+                                                const OpSlot *__restrict__ slots, int op_base,
+                                                uint32_t zmask = 0) {
   const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
   // sw() is linear over XOR and base & off == 0, so slot(base | off[c]) = sw(base) ^ sw(off[c]):
   // 16 wave-uniform constants + ONE v_xor per gathered amplitude
@@ -376,7 +377,9 @@ __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, c
                 ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
   const uint32_t cnt = 1u << (T - 4);
   for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const uint32_t base = sw(ins0(ins0(ins0(ins0(i, b0), b1), b2), b3));
+    const uint32_t lbase = ins0(ins0(ins0(ins0(i, b0), b1), b2), b3);
+    if (lbase & zmask) continue;  // all 16 amplitudes are known zeros (TileArgs::zin_local)
+    const uint32_t base = sw(lbase);
     float2 a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = s[base ^ off[c]];
@@ -602,15 +605,21 @@ __device__ __forceinline__ void tile_compute(const TileArgs &a, float2 *s, const
   const int T = a.T;
   const float *mrow = a.mats + (size_t)b * a.mat_floats;
   const float *ang = a.angles + (size_t)b * a.n_slots;
+  // local bits still known-zero: work items holding only zeros rest (never set for k_tile_pf)
+  uint32_t z = RAW ? 0u : a.zin_local;
   for (int gi = 0; gi < a.n_groups; ++gi) {
     const OpGroup g = a.groups[gi];
     if (g.kind == GK_REG4) {
-      if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin);
-      else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin);
+      const uint32_t gm = (1u << g.bits[0]) | (1u << g.bits[1]) | (1u << g.bits[2]) | (1u << g.bits[3]);
+      if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
+      else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
+      z &= ~gm;
     } else if (DENSE4 && g.kind == GK_DENSE4) {
       lds_apply_dense4(s, T, g, a.consts + a.ops[g.op_begin].mat_off);
+      z = 0;
     } else {
       lds_apply(s, T, a.ops[g.op_begin], mrow, a.consts, ang);
+      z = 0;
     }
     tile_sync<RAW>();
   }
