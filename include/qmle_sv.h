@@ -127,6 +127,8 @@ typedef enum qmle_meas {
                                        folding them into the observables (A-B, tests)   */
 #define QMLE_PLAN_NO_SPARSE 128u    /* runs from |0..0>: read and store every amplitude, launch every tile,
                                        even where the state is known to be exactly zero (A-B, tests) */
+#define QMLE_PLAN_TAPE_ORDER (1u << 24) /* schedule commuting gates in tape order instead of low bit
+                                          positions first (A-B, tests)                       */
 /* bits 8..15: tile qubits T override (0 = auto); bits 16..23: low-bit count L override */
 #define QMLE_PLAN_TILE_BITS(t) (((unsigned)(t) & 0xffu) << 8)
 #define QMLE_PLAN_LOW_BITS(l) (((unsigned)(l) & 0xffu) << 16)

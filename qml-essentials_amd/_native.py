@@ -56,12 +56,14 @@ PLAN_PREFETCH = 16
 PLAN_NO_ABSORB = 32
 PLAN_NO_MERGE = 64
 PLAN_NO_SPARSE = 128
+PLAN_TAPE_ORDER = 1 << 24
 
 
 def plan_flags(no_fusion=False, force_global=False, force_tile=False, tile_bits=0, low_bits=0,
-               prefetch=False, no_absorb=False, no_sparse=False):
+               prefetch=False, no_absorb=False, no_sparse=False, tape_order=False):
     f = (PLAN_PREFETCH if prefetch else 0) | (PLAN_NO_ABSORB if no_absorb else 0)
     f |= PLAN_NO_SPARSE if no_sparse else 0
+    f |= PLAN_TAPE_ORDER if tape_order else 0
     if no_fusion:
         f |= PLAN_NO_FUSION
     if force_global:
