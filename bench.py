@@ -250,6 +250,8 @@ def main():
     fam = {}
     for i, st in enumerate(desc["stages"]):
         k = {"tile": "k_tile", "direct": "k_direct_1q", "diag_all": "k_diag_all"}[st["kind"]]
+        if st["kind"] == "tile" and st.get("product") and 0 < i < len(desc["stages"]) - 1:
+            k = "k_tile_product"  # (+ k_fold_columns, inside the same timed scope)
         if i == len(desc["stages"]) - 1 and st["kind"] == "tile":
             k = st["expval_kernel"].replace("_fold", "")  # <Z> out of the last pass: which kernel runs it
         f = fam.setdefault(k, {"ms": 0.0, "launches": 0, "algo": 0.0, "moved": 0.0})

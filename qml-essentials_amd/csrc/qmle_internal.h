@@ -93,6 +93,10 @@ struct Stage {
   // hold nothing else.
   uint32_t zero_in = 0, touched = 0;
   bool next_tile = false;
+  // Every gate group sits on 4 bit positions of its own that are all known-zero on input: the
+  // output tile is in[live bits] x prod_g (U_g e_0)[group bits] -- k_tile_product writes it
+  // from the groups' first columns without staging amplitudes or running gates per tile.
+  bool product_ok = false;
 };
 
 struct StageProfile {  // optional HIP-event timing of every stage launch (bench.py)
@@ -128,6 +132,7 @@ struct qmle_plan {
   std::vector<qmle::BuildGroup> groups;
   std::vector<qmle::Stage> stages;
   uint32_t mat_floats = 0;                // per-sample matrix row length
+  int fold_groups = 0;                    // most gate groups of any Stage::product_ok stage
   bool whole_state_lds = false;
   int tile_T = 0, tile_L = 0;
   double algo_bytes_per_state = 0;

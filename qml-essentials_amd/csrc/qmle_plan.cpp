@@ -609,7 +609,26 @@ int compile_plan(qmle_plan *p) {
       st.zero_in = Z;
       Z &= ~st.touched;
       st.next_tile = si + 1 < p->stages.size() && p->stages[si + 1].kind == ST_TILE;
+      st.product_ok = false;
+      if (st.kind == ST_TILE && si > 0 && st.grp_end > st.grp_begin && st.T >= 8) {
+        uint32_t seen = 0;
+        bool ok = true;
+        for (int g = st.grp_begin; g < st.grp_end && ok; ++g) {
+          const OpGroup &og = p->op_groups[g];
+          ok = og.kind == GK_REG4;
+          for (int j = 0; j < 4 && ok; ++j) {
+            const uint32_t lb = 1u << og.bits[j];
+            ok = !(seen & lb) && ((st.zero_in >> st.tile_bits[og.bits[j]]) & 1u);
+            seen |= lb;
+          }
+        }
+        st.product_ok = ok;
+      }
     }
+    p->fold_groups = 0;
+    for (const Stage &st : p->stages)
+      if (st.product_ok && st.grp_end - st.grp_begin > p->fold_groups)
+        p->fold_groups = st.grp_end - st.grp_begin;
 
   };
 
@@ -696,7 +715,7 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
        << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
-       << ",\"expval_kernel\":\""
+       << ",\"product\":" << (st.product_ok ? "true" : "false") << ",\"expval_kernel\":\""
        << (const char *[]){"k_tile", "k_reg_measure", "k_reg_measure_fold", "k_reg_measure_mono"}
               [expval_kernel_of(p, s, !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)))]
        << "\",\"read_bytes_from_zero\":" << stage_read_bytes(p, s)

@@ -1260,6 +1260,161 @@ __global__ void __launch_bounds__(1024) k_reg_measure_mono(const TileArgs a) {
   }
 }
 
+// ---- product pass (Stage::product_ok) -----------------------------------------------------
+// First columns U_g e_0 of the stage's gate groups, one work item per (group, sample).
+__global__ void __launch_bounds__(64)
+k_fold_columns(const LoweredOp *__restrict__ ops, const OpGroup *__restrict__ groups, int n_groups,
+               const float *__restrict__ mats, uint32_t mat_floats, float2 *__restrict__ cols,
+               int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_groups * batch) return;
+  const int b = i / n_groups, gi = i - b * n_groups;
+  const OpGroup g = groups[gi];
+  const float *mrow = mats + (size_t)b * mat_floats;
+  float2 v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = make_float2(c == 0 ? 1.f : 0.f, 0.f);
+  for (int k = 0; k < g.n_ops; ++k) {
+    const LoweredOp op = ops[g.op_begin + k];
+    const Mat2 m = load_mat2(mrow + op.mat_off);
+    const int cb = op.nc ? op.c0 : -1;
+    if (op.flags & LF_PERMX) reg_dispatch<2>(v, m, cb, op.t0);
+    else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
+    else reg_dispatch<0>(v, m, cb, op.t0);
+  }
+  float2 *o = cols + (size_t)i * 16;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) o[c] = v[c];
+}
+
+__device__ __forceinline__ uint32_t pext_mask(uint32_t x, uint32_t mask) {  // gather the bits of x under mask
+  uint32_t r = 0, k = 0;
+  while (mask) {
+    const uint32_t low = mask & (0u - mask);
+    if (x & low) r |= 1u << k;
+    ++k;
+    mask ^= low;
+  }
+  return r;
+}
+
+// out[e] = in[e with the group bits cleared] * prod_g col_g[bits of e under group g]: the live
+// inputs (2^(T - 4 G) per tile) are parked in LDS first, since the pass runs in place.
+__global__ void __launch_bounds__(1024)
+k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_wg, uint32_t n_tiles) {
+  extern __shared__ float4 smem4[];
+  const int T = a.T, L = a.L, G = a.n_groups;
+  float2 *tc = reinterpret_cast<float2 *>(smem4);          // [G <= 4][16]
+  float2 *lin = tc + 64;                                   // [2^(T - 4G)]
+  const int n_live = T - 4 * G;
+  uint32_t *lut = reinterpret_cast<uint32_t *>(lin + (1u << n_live));
+  const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.y;
+  tile_build_lut(a, lut);
+  const uint32_t lowmask = (1u << L) - 1u;
+  float2 *st = a.states + ((size_t)b << a.n);
+
+  uint32_t gm[4] = {0u, 0u, 0u, 0u}, gm_all = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (g < G) {
+      const OpGroup og = a.groups[g];
+      gm[g] = (1u << og.bits[0]) | (1u << og.bits[1]) | (1u << og.bits[2]) | (1u << og.bits[3]);
+      gm_all |= gm[g];
+    }
+  const uint32_t livemask = ((1u << T) - 1u) & ~gm_all;
+  for (int i = tid; i < G * 16; i += nt) tc[i] = cols[(size_t)b * (G * 16) + i];
+
+  // everything below but the tile base is the same for every tile: work-item indices into the
+  // live-input table and the column tables, split into the part the work item fixes (local bits
+  // 1 .. T-4) and the part the iteration fixes (the 3 top local bits)
+  const bool bit0_live = (livemask & 1u) != 0;
+  const uint32_t jt = 2u * (uint32_t)tid;
+  const uint32_t lc_t = pext_mask(jt, livemask);
+  uint32_t ig_t[4], odd[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    ig_t[g] = pext_mask(jt, gm[g]);
+    odd[g] = (gm[g] & 1u) ? 1u : 0u;  // bit 0 is the lowest bit of its group
+  }
+  uint32_t top_l[3], top_g[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t bitv = 1u << (T - 3 + k);
+    top_l[k] = pext_mask(bitv, livemask);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) top_g[g][k] = pext_mask(bitv, gm[g]);
+  }
+  // live-input slots this work item fills (<= 4: 2^n_live <= 4 * blockDim)
+  uint32_t in_e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t idx = (uint32_t)tid + (uint32_t)r * (uint32_t)nt;
+    uint32_t e = 0, rest = idx, m = livemask;  // deposit idx under livemask
+    while (rest && m) {
+      const uint32_t low = m & (0u - m);
+      if (rest & 1u) e |= low;
+      m ^= low;
+      rest >>= 1;
+    }
+    in_e[r] = e;
+  }
+  __syncthreads();  // lut, tc
+  uint32_t in_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) in_off[r] = lut[in_e[r] >> L] | (in_e[r] & lowmask);
+  uint32_t out_off[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint32_t j = jt | ((uint32_t)u << (T - 3));
+    out_off[u] = lut[j >> L] | (j & lowmask);
+  }
+
+  for (int tt = 0; tt < tiles_per_wg; ++tt) {
+    uint32_t tile = blockIdx.x * (uint32_t)tiles_per_wg + (uint32_t)tt;
+    if (tile >= n_tiles) break;
+    if (a.compact) {
+      uint32_t rest = tile, free_bits = a.tile_free;
+      tile = 0;
+      while (rest) {
+        const uint32_t low = free_bits & (0u - free_bits);
+        if (rest & 1u) tile |= low;
+        free_bits ^= low;
+        rest >>= 1;
+      }
+    }
+    float2 *pt = st + tile_base(a, tile);
+    if (tt) __syncthreads();  // the previous tile's reads of lin are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t idx = (uint32_t)tid + (uint32_t)r * (uint32_t)nt;
+      if (idx < (1u << n_live)) {
+        float2 x = make_float2(0.f, 0.f);
+        if ((in_e[r] & a.zin_local) == 0) x = pt[in_off[r]];
+        lin[idx] = x;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t lc = lc_t | ((u & 1) ? top_l[0] : 0u) | ((u & 2) ? top_l[1] : 0u) |
+                          ((u & 4) ? top_l[2] : 0u);
+      float2 f0 = make_float2(1.f, 0.f), f1 = make_float2(1.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (g < G) {
+          const uint32_t ig = ig_t[g] | ((u & 1) ? top_g[g][0] : 0u) | ((u & 2) ? top_g[g][1] : 0u) |
+                              ((u & 4) ? top_g[g][2] : 0u);
+          const float2 c0 = tc[g * 16 + ig], c1 = tc[g * 16 + (ig | odd[g])];
+          f0 = cmul(c0, f0);
+          f1 = cmul(c1, f1);
+        }
+      const float2 x0 = lin[lc], x1 = lin[bit0_live ? (lc | 1u) : lc];
+      const float2 o0 = cmul(f0, x0), o1 = cmul(f1, x1);
+      *reinterpret_cast<float4 *>(pt + out_off[u]) = make_float4(o0.x, o0.y, o1.x, o1.y);
+    }
+  }
+}
+
 // ---- whole-circuit adjoint in LDS (n <= 13) ----------------------------------------------
 // One workgroup per sample keeps psi AND lambda in LDS: forward circuit (fused gate groups),
 // lambda = (sum_k w_k Z_k) psi, then for every gate of the reversed, daggered tape the
@@ -2627,7 +2782,7 @@ static bool plan_sparse(const qmle_plan *p) {
 int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
                 const float *angles, int batch, bool init_zero, int meas, void *out,
                 const uint32_t *obs_masks, int n_obs, hipStream_t stream,
-                bool from_zero = false) {
+                bool from_zero = false, float2 *cols = nullptr) {
   from_zero = from_zero && plan_sparse(p);
   TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs,
                               from_zero);
@@ -2699,6 +2854,23 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       a.tile_free = all_outer & ~zo;
       grid.x = 1u << __builtin_popcount(a.tile_free);
     }
+  }
+  static const bool no_product = std::getenv("QMLE_NO_PRODUCT") != nullptr;
+  if (from_zero && cols && st.product_ok && !init_zero && meas == TM_STORE && !no_product &&
+      threads == (1 << (st.T - 4))) {
+    const int G = st.grp_end - st.grp_begin;
+    const int items = G * batch;
+    hipLaunchKernelGGL(k_fold_columns, dim3((items + 63) / 64), dim3(64), 0, stream, p->dev.d_ops,
+                       p->dev.d_op_groups + st.grp_begin, G, mats, p->mat_floats, cols, batch);
+    const size_t lds_p = 64 * sizeof(float2) + ((size_t)8 << (st.T - 4 * G)) +
+                         ((size_t)4 << (st.T - st.L)) + 64;
+    const uint32_t n_tiles = grid.x;
+    int tpw = 1;  // tiles per workgroup: the index tables are built once
+    while (tpw < 8 && (uint64_t)(n_tiles / (2 * tpw)) * batch >= 2048) tpw *= 2;
+    grid.x = (n_tiles + tpw - 1) / tpw;
+    hipLaunchKernelGGL(k_tile_product, grid, dim3(threads), lds_p, stream, a, cols, tpw, n_tiles);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
   }
   if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(threads), lds, stream, a);
   else hipLaunchKernelGGL(k_tile<false>, grid, dim3(threads), lds, stream, a);
@@ -2941,8 +3113,13 @@ int qmle_plan_stats(const qmle_plan *plan, int64_t stats[8]) {
 
 // workspace layout: [matrices: batch * mat_floats] [states: S * D (if needed)]
 //                   [expval partials]
-static size_t ws_mats_bytes(const qmle_plan *p, int batch) {
+static size_t ws_matrix_bytes(const qmle_plan *p, int batch) {
   return align_up((size_t)batch * (p->mat_floats ? p->mat_floats : 1) * sizeof(float), 256);
+}
+// per-sample gate matrices, then the product stages' group columns (k_fold_columns)
+static size_t ws_mats_bytes(const qmle_plan *p, int batch) {
+  return ws_matrix_bytes(p, batch) +
+         align_up((size_t)batch * (size_t)p->fold_groups * 16 * sizeof(float2), 256);
 }
 
 static int default_states_in_flight(const qmle_plan *p, int batch) {
@@ -3112,6 +3289,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
   const size_t mats_b = ws_mats_bytes(plan, batch);
   if (workspace_bytes < mats_b) return QMLE_ERR_WORKSPACE;
   float *d_mats = (float *)ws;
+  float2 *d_cols = plan->fold_groups ? (float2 *)(ws + ws_matrix_bytes(plan, batch)) : nullptr;
   ws += mats_b;
   workspace_bytes -= mats_b;
 
@@ -3201,7 +3379,8 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
         } else
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
-                         last_fused ? n_obs : 0, stream, /*from_zero=*/true);
+                         last_fused ? n_obs : 0, stream, /*from_zero=*/true,
+                         d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr);
         initialised = true;
       } else {
         if (!initialised) {

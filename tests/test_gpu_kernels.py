@@ -383,11 +383,11 @@ def _shallow_tapes(n, rng):
 
 
 @pytest.mark.parametrize("n,tile_bits,low_bits", [(14, 8, 2), (15, 7, 3), (16, 12, 4), (16, 9, 1), (18, 12, 4)])
-def test_known_zero_amplitudes_are_skipped_bit_exactly(n, tile_bits, low_bits):
+def test_known_zero_amplitudes_are_skipped(n, tile_bits, low_bits):
     """Runs from |0..0> do not read, compute or store amplitudes that are provably zero
-    (Stage::zero_in, compact grids): results are bit-identical to the dense run
-    (QMLE_PLAN_NO_SPARSE) for state / probs, equal to float32 rounding for <Z> / parities, and
-    match the oracle."""
+    (Stage::zero_in, compact grids, folded gates): results equal those of the dense run
+    (QMLE_PLAN_NO_SPARSE) to float32 rounding for state / probs / <Z> / parities, with the same
+    exact zeros, and match the oracle."""
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n * 100 + tile_bits)
@@ -410,12 +410,12 @@ def test_known_zero_amplitudes_are_skipped_bit_exactly(n, tile_bits, low_bits):
             if mode == "sparse" and name == "he":
                 st = plan.describe()["stages"]
                 assert len(st) >= 2 and st[0]["zero_in"] == (1 << n) - 1 and st[1]["zero_in"] != 0
-        for got, want in zip(res["sparse"][:2], res["dense"][:2]):
-            assert np.array_equal(got, want), name
-        # <Z> / parities: the measuring pass folds gates on known-zero inputs into per-workgroup
-        # columns (k_reg_measure<FOLD>) -- same numbers up to float32 rounding
-        for got, want in zip(res["sparse"][2:], res["dense"][2:]):
+        # gates acting on known zeros are folded (k_tile_product: first columns of the gate
+        # groups; k_reg_measure<FOLD> / _mono in the measuring pass): same numbers up to float32
+        # rounding -- and exactly the same zeros
+        for got, want in zip(res["sparse"], res["dense"]):
             assert np.abs(got - want).max() < 1e-6, name
+        assert np.array_equal(res["sparse"][0] == 0, res["dense"][0] == 0), name
         psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
         assert np.abs(res["sparse"][0][0] - psi).max() < 2e-6, name
 

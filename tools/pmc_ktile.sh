@@ -21,7 +21,7 @@ for f in sorted(glob.glob(out+"/**/*counter_collection.csv", recursive=True)):
     tag=f.split("/pmc_ktile/")[1].split("/")[0]
     per=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_tile" in r["Kernel_Name"] or "k_reg_measure" in r["Kernel_Name"]:
+        if ("k_tile" in r["Kernel_Name"] or "k_reg_measure" in r["Kernel_Name"]) and "k_fold" not in r["Kernel_Name"]:
             per[(int(r["Dispatch_Id"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     ids=sorted({k[0] for k in per})
     # last run's three passes
