@@ -1145,62 +1145,58 @@ __global__ void __launch_bounds__(1024) k_reg_measure(const TileArgs a, int q) {
 // work item, 2.5 adds per tile, and one signed cross-lane reduction per workgroup.
 typedef float v32f __attribute__((ext_vector_type(32)));
 
-__global__ void __launch_bounds__(1024) k_reg_measure_mono(const TileArgs a) {
+// Per observable: its wires split by where the measuring pass finds them (host-computed).
+struct MonoObs {
+  uint32_t thr[32];  // ... among the work-item bits (tile bits outside the gate group)
+  uint32_t out[32];  // ... among the outer (tile index) bits
+  uint8_t reg[32];   // ... among the 4 register bits
+};
+
+// coef[b][k] = Walsh-Hadamard sum `reg[k]` of |U e_0|^2 for sample b's gate group: one work
+// item per sample (the gate list runs once per state instead of once per workgroup).
+__global__ void __launch_bounds__(64)
+k_mono_coef(const LoweredOp *__restrict__ ops, const OpGroup *__restrict__ group,
+            const float *__restrict__ mats, uint32_t mat_floats, const MonoObs mo, int n_obs,
+            float *__restrict__ coef, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const OpGroup g = group[0];
+  const float *mrow = mats + (size_t)b * mat_floats;
+  float2 v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = make_float2(c == 0 ? 1.f : 0.f, 0.f);
+  for (int k = 0; k < g.n_ops; ++k) {
+    const LoweredOp op = ops[g.op_begin + k];
+    const Mat2 m = load_mat2(mrow + op.mat_off);
+    const int cb = op.nc ? op.c0 : -1;
+    if (op.flags & LF_PERMX) reg_dispatch<2>(v, m, cb, op.t0);
+    else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
+    else reg_dispatch<0>(v, m, cb, op.t0);
+  }
+  v16f W;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) W[c] = norm2(v[c]);
+#pragma unroll
+  for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i & h) continue;
+      const float x = W[i], y = W[i | h];
+      W[i] = x + y;
+      W[i | h] = x - y;
+    }
+  }
+  for (int k = 0; k < 32; ++k) coef[(size_t)b * 32 + k] = k < n_obs ? W[mo.reg[k] & 15u] : 0.f;
+}
+
+__global__ void __launch_bounds__(1024)
+k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__ coef) {
   constexpr int Q = 5;
   extern __shared__ float4 smem4[];
-  OpSlot *slots = reinterpret_cast<OpSlot *>(smem4);
-  uint32_t *meta = reinterpret_cast<uint32_t *>(slots + a.n_ops);
-  uint32_t *m_thr = meta;        // [32] observable restricted to the work-item bits
-  uint32_t *m_reg = meta + 32;   // [32] ... to the 4 register bits
-  uint32_t *m_out = meta + 64;   // [32] ... to the outer (tile index) bits
-  float *red = reinterpret_cast<float *>(meta + 132);  // [16][32]
+  float *red = reinterpret_cast<float *>(smem4);  // [16][32]
   const int T = a.T, tid = threadIdx.x, b = blockIdx.y;
-  const int n_outer = a.n - T;
   const OpGroup g = a.groups[0];
   const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
-
-  tile_stage_slots(a, slots, b);
-  if (tid < 32) {
-    uint32_t mt = 0, mi = 0, mo = 0;
-    if (tid < a.n_obs) {
-      const uint32_t m = a.obs_mask[tid];
-      int tb = 0;
-      for (int j = 0; j < T; ++j) {
-        const uint32_t bitv = (m >> a.tile_bits[j]) & 1u;
-        if (j == b0) mi |= bitv;
-        else if (j == b1) mi |= bitv << 1;
-        else if (j == b2) mi |= bitv << 2;
-        else if (j == b3) mi |= bitv << 3;
-        else mt |= bitv << tb++;
-      }
-      for (int j = 0; j < n_outer; ++j) mo |= ((m >> a.outer_bits[j]) & 1u) << j;
-    }
-    m_thr[tid] = mt;
-    m_reg[tid] = mi;
-    m_out[tid] = mo;
-  }
-  __syncthreads();
-
-  // U e_0 and the Walsh-Hadamard sums of |U e_0|^2 (every work item, redundantly: wave-uniform)
-  v16f Wt;
-  {
-    float2 v[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = make_float2(c == 0 ? 1.f : 0.f, 0.f);
-    reg_apply_group(v, g, slots, a.op_begin);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Wt[c] = norm2(v[c]);
-#pragma unroll
-    for (int h = 1; h < 16; h <<= 1) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i & h) continue;
-        const float x = Wt[i], y = Wt[i | h];
-        Wt[i] = x + y;
-        Wt[i | h] = x - y;
-      }
-    }
-  }
 
   const uint32_t lb = ins0(ins0(ins0(ins0((uint32_t)tid, b0), b1), b2), b3);
   uint32_t gbase = 0;
@@ -1234,15 +1230,15 @@ __global__ void __launch_bounds__(1024) k_reg_measure_mono(const TileArgs a) {
     }
   }
 
+  const float *cf = coef + (size_t)b * 32;
   float A[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     A[k] = 0.f;
     if (k < a.n_obs) {
-      const uint32_t mo = __builtin_amdgcn_readfirstlane(m_out[k]);
-      const uint32_t mi = __builtin_amdgcn_readfirstlane(m_reg[k]);
-      float val = P[mo & ((1u << Q) - 1u)] * Wt[mi & 15u];  // wave-uniform register indices
-      const uint32_t par = (__popc(tile0 & mo) + __popc((uint32_t)tid & m_thr[k])) & 1u;
+      const uint32_t mout = mo.out[k];
+      const float val = P[mout & ((1u << Q) - 1u)] * cf[k];  // wave-uniform register index
+      const uint32_t par = (__popc(tile0 & mout) + __popc((uint32_t)tid & mo.thr[k])) & 1u;
       A[k] = par ? -val : val;
     }
   }
@@ -2888,7 +2884,8 @@ static int reg_measure_kind(const qmle_plan *p, size_t si, int n_obs) {
 
 static int launch_reg_measure(const qmle_plan *p, const Stage &st, int kind, float2 *states,
                               const float *mats, const float *angles, int batch, void *out,
-                              const uint32_t *obs_masks, int n_obs, hipStream_t stream, int *q_out) {
+                              const uint32_t *obs_masks, int n_obs, hipStream_t stream, int *q_out,
+                              float *coef) {
   TileArgs a = fill_tile_args(p, st, states, mats, angles, false, TM_EXPVAL_MASKS, out, obs_masks,
                               n_obs, plan_sparse(p));
   a.slots_in_lds = 1;
@@ -2899,9 +2896,28 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, int kind, flo
   if (kind == 3) q = 5;
   const size_t lds = (size_t)a.n_ops * sizeof(OpSlot) + (132 + 16 * 32 + 128) * sizeof(uint32_t);
   dim3 grid(1u << (n_outer - q), (unsigned)batch);
-  if (kind == 3)
-    hipLaunchKernelGGL(k_reg_measure_mono, grid, dim3(1u << (st.T - 4)), lds, stream, a);
-  else if (kind == 2)
+  if (kind == 3) {
+    const OpGroup &g = p->op_groups[st.grp_begin];
+    MonoObs mo;
+    std::memset(&mo, 0, sizeof(mo));
+    for (int k = 0; k < n_obs; ++k) {
+      const uint32_t m = obs_masks[k];
+      int tb = 0;
+      for (int j = 0; j < st.T; ++j) {
+        const uint32_t bitv = (m >> st.tile_bits[j]) & 1u;
+        int gi = -1;
+        for (int i = 0; i < 4; ++i)
+          if (g.bits[i] == j) gi = i;
+        if (gi >= 0) mo.reg[k] |= (uint8_t)(bitv << gi);
+        else mo.thr[k] |= bitv << tb++;
+      }
+      for (int j = 0; j < n_outer; ++j) mo.out[k] |= ((m >> st.outer_bits[j]) & 1u) << j;
+    }
+    hipLaunchKernelGGL(k_mono_coef, dim3((batch + 63) / 64), dim3(64), 0, stream, p->dev.d_ops,
+                       p->dev.d_op_groups + st.grp_begin, mats, p->mat_floats, mo, n_obs, coef, batch);
+    hipLaunchKernelGGL(k_reg_measure_mono, grid, dim3(1u << (st.T - 4)), 16 * 32 * sizeof(float),
+                       stream, a, mo, coef);
+  } else if (kind == 2)
     hipLaunchKernelGGL(k_reg_measure<true>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
   else
     hipLaunchKernelGGL(k_reg_measure<false>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
@@ -3119,7 +3135,8 @@ static size_t ws_matrix_bytes(const qmle_plan *p, int batch) {
 // per-sample gate matrices, then the product stages' group columns (k_fold_columns)
 static size_t ws_mats_bytes(const qmle_plan *p, int batch) {
   return ws_matrix_bytes(p, batch) +
-         align_up((size_t)batch * (size_t)p->fold_groups * 16 * sizeof(float2), 256);
+         align_up((size_t)batch * (size_t)p->fold_groups * 16 * sizeof(float2), 256) +
+         align_up((size_t)batch * 32 * sizeof(float), 256);  // k_mono_coef
 }
 
 static int default_states_in_flight(const qmle_plan *p, int batch) {
@@ -3290,6 +3307,8 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
   if (workspace_bytes < mats_b) return QMLE_ERR_WORKSPACE;
   float *d_mats = (float *)ws;
   float2 *d_cols = plan->fold_groups ? (float2 *)(ws + ws_matrix_bytes(plan, batch)) : nullptr;
+  float *d_coef = (float *)(ws + ws_matrix_bytes(plan, batch) +
+                            align_up((size_t)batch * (size_t)plan->fold_groups * 16 * sizeof(float2), 256));
   ws += mats_b;
   workspace_bytes -= mats_b;
 
@@ -3375,7 +3394,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
         const int reg_kind = last_fused && initialised ? reg_measure_kind(plan, si, n_obs) : 0;
         if (reg_kind) {
           rc = launch_reg_measure(plan, st, reg_kind, stc, mats, ang, bc, d_partial, obs_masks,
-                                  n_obs, stream, &reg_q);
+                                  n_obs, stream, &reg_q, d_coef + (size_t)b0 * 32);
         } else
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
