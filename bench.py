@@ -290,9 +290,9 @@ def main():
         "note": "algorithmic bytes = sum of the per-gate bytes (SURVEY 8-d) of the reference "
                 "gates one launch applies; a fused pass applies many gates per HBM round trip and "
                 "a run from |0..0> never reads or stores amplitudes that are still exactly zero, "
-                "so achieved exceeds the HBM peak; bytes_moved / moved_GBps is the real stream "
-                "(tiny here: the dominant kernel is bound by instruction issue, not HBM); "
-                "dense_state and k1_single_gate_28q are the HBM-streaming figures",
+                "so achieved exceeds the HBM peak; bytes_moved_per_launch / moved_GBps / moved_frac "
+                "are the bytes the dominant kernel really streams (they match the PMC traffic); "
+                "dense_state is the same step with every amplitude read / computed / stored",
         "event_pool_overflow": overflow,
     }
     result = {
