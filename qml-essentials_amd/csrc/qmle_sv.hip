@@ -1379,6 +1379,14 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
       }
     }
     float2 *pt = st + tile_base(a, tile);
+    if ((tile & a.zin_outer) != 0) {
+      // (full grid only) nothing but known zeros in, nothing but zeros out -- and the input
+      // may never have been written: store the zeros without reading
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        *reinterpret_cast<float4 *>(pt + out_off[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
     if (tt) __syncthreads();  // the previous tile's reads of lin are done
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

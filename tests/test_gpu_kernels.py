@@ -379,10 +379,16 @@ def _shallow_tapes(n, rng):
     part += [("RY", [w], ang()) for w in half[: len(half) // 2]]
     diag = [("RZ", [q], ang()) for q in range(n)] + [("H", [n - 1], ()), ("CX", [n - 1, 0], ())]
     two = he + [(g, [q], ang()) for g in ("RX",) for q in range(n)]
-    return {"he": he, "partial": part, "diag_then_h": diag, "he_plus_layer": two, "empty": []}
+    # bits 0..9 first, then 4 fresh bits, the top bits never: a product pass (k_tile_product) that
+    # is the LAST stage has to store zeros for tiles its predecessor never wrote
+    low_mid = [("RX", [n - 1 - b], ang()) for b in range(min(10, n - 5))]
+    low_mid += [("RY", [n - 1 - b], ang()) for b in range(min(10, n - 5), min(14, n - 1))]
+    return {"he": he, "partial": part, "diag_then_h": diag, "he_plus_layer": two, "empty": [],
+            "low_then_mid": low_mid}
 
 
-@pytest.mark.parametrize("n,tile_bits,low_bits", [(14, 8, 2), (15, 7, 3), (16, 12, 4), (16, 9, 1), (18, 12, 4)])
+@pytest.mark.parametrize("n,tile_bits,low_bits", [(14, 8, 2), (15, 7, 3), (16, 12, 4), (16, 9, 1), (18, 12, 4),
+                                                  (18, 10, 2), (17, 11, 4)])
 def test_known_zero_amplitudes_are_skipped(n, tile_bits, low_bits):
     """Runs from |0..0> do not read, compute or store amplitudes that are provably zero
     (Stage::zero_in, compact grids, folded gates): results equal those of the dense run
@@ -391,6 +397,8 @@ def test_known_zero_amplitudes_are_skipped(n, tile_bits, low_bits):
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n * 100 + tile_bits)
+    junk = torch.full((3 << n,), 7.0, dtype=torch.complex64, device="cuda")  # recycled as state buffers
+    del junk
     for name, tape in _shallow_tapes(n, rng).items():
         ops, angles, consts = tape_to_native(tape, n)
         B = 3
