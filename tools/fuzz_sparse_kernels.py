@@ -18,8 +18,17 @@ for trial in range(int(os.environ.get("FUZZ_N", "200"))):
     sub = random_tape(k, int(rng.integers(3, 45)), rng, three_q=bool(rng.integers(2))) if k >= 3 else \
         [("RX", [0], (1.0,)), ("RY", [k - 1], (0.5,))]
     tape = [(nm, [wires[w] for w in ws], pr) for nm, ws, pr in sub]
+    layered = trial % 2 == 1
+    if layered:  # one layer of 1-qubit rotations (+ a foldable entangling tail): product / mono passes
+        tape = []
+        for w in wires:
+            for g_ in rng.choice(["RX", "RY", "RZ", "H"], size=int(rng.integers(1, 4))):
+                tape.append((str(g_), [w], (float(rng.uniform(0, 6.28)),) if g_ != "H" else ()))
+        for _ in range(int(rng.integers(0, 6))):
+            a_, b_ = (int(x) for x in rng.choice(n, size=2, replace=False))
+            tape.append((str(rng.choice(["CX", "CZ"])), [a_, b_], ()))
     ops, angles, consts = tape_to_native(tape, n)
-    T = int(rng.integers(6, 14)); T = min(T, n - 1)
+    T = int(rng.integers(10, 14)) if layered else int(rng.integers(6, 14)); T = min(T, n - 1)
     L = int(rng.integers(1, min(T, 8)))
     B = int(rng.integers(1, 4))
     table = rng.uniform(0, 6.28, size=(B, max(1, len(angles)))).astype(np.float32)[:, : len(angles)]
@@ -38,7 +47,7 @@ for trial in range(int(os.environ.get("FUZZ_N", "200"))):
     errs = [float(np.abs(a - b).max()) for a, b in zip(res["sparse"], res["dense"])]
     ok = max(errs) < 2e-6
     bad += not ok
-    print(trial, n, k, len(tape), T, L, kw["force_tile"], kw["no_absorb"], kw["tape_order"], errs,
+    print(trial, "layered" if layered else "random", n, k, len(tape), T, L, kw["force_tile"], kw["no_absorb"], kw["tape_order"], errs,
           "" if ok else "<<< MISMATCH", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
