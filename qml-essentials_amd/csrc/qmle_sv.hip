@@ -1419,6 +1419,63 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
   }
 }
 
+// The same product, laid out for the memory system: a work item keeps two neighbouring live
+// amplitudes in registers and walks ALL 2^(4G) values of the group bits, so every store
+// instruction of a workgroup covers one contiguous 4 KiB run (k_tile_product's tile geometry
+// gives 128-byte runs).  In place: the only input a work item overwrites (group bits = 0) is
+// the one it holds.  Needs the compact convention (known-zero outputs are not stored).
+struct ProductArgs {
+  float2 *states;
+  const float2 *cols;      // [batch][G][16]
+  uint32_t live_mask;      // bit positions an input can be non-zero on
+  uint32_t gpos[4][4];     // bit positions of group g's 4 bits (gather order)
+  int n, G;
+};
+
+__global__ void __launch_bounds__(256) k_product_stream(const ProductArgs a) {
+  __shared__ float2 tc[4][16];
+  __shared__ uint32_t goff[4][16];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid < 64) {
+    const int g = tid >> 4, c = tid & 15;
+    float2 v = make_float2(1.f, 0.f);
+    uint32_t off = 0;
+    if (g < a.G) {
+      v = a.cols[((size_t)b * a.G + g) * 16 + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((c >> i) & 1) off |= 1u << a.gpos[g][i];
+    }
+    tc[g][c] = v;
+    goff[g][c] = off;
+  }
+  // element offset of this work item's pair: deposit its compact live index under live_mask
+  uint32_t rest = ((uint32_t)blockIdx.x * 256u + (uint32_t)tid) * 2u, m = a.live_mask, e = 0;
+  while (rest) {
+    const uint32_t low = m & (0u - m);
+    if (rest & 1u) e |= low;
+    m ^= low;
+    rest >>= 1;
+  }
+  float2 *pt = a.states + ((size_t)b << a.n) + e;
+  const float4 x = *reinterpret_cast<const float4 *>(pt);
+  const float2 x0 = make_float2(x.x, x.y), x1 = make_float2(x.z, x.w);
+  __syncthreads();
+  const int n3 = a.G > 3 ? 16 : 1, n2 = a.G > 2 ? 16 : 1, n1 = a.G > 1 ? 16 : 1;
+  for (int i3 = 0; i3 < n3; ++i3)
+    for (int i2 = 0; i2 < n2; ++i2)
+      for (int i1 = 0; i1 < n1; ++i1) {
+        const float2 f123 = cmul(tc[3][i3], cmul(tc[2][i2], tc[1][i1]));
+        const uint32_t o123 = goff[3][i3] | goff[2][i2] | goff[1][i1];
+#pragma unroll 4
+        for (int i0 = 0; i0 < 16; ++i0) {
+          const float2 f = cmul(f123, tc[0][i0]);
+          const float2 o0 = cmul(f, x0), o1 = cmul(f, x1);
+          *reinterpret_cast<float4 *>(pt + (o123 | goff[0][i0])) = make_float4(o0.x, o0.y, o1.x, o1.y);
+        }
+      }
+}
+
 // ---- whole-circuit adjoint in LDS (n <= 13) ----------------------------------------------
 // One workgroup per sample keeps psi AND lambda in LDS: forward circuit (fused gate groups),
 // lambda = (sum_k w_k Z_k) psi, then for every gate of the reversed, daggered tape the
@@ -2866,6 +2923,33 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     const int items = G * batch;
     hipLaunchKernelGGL(k_fold_columns, dim3((items + 63) / 64), dim3(64), 0, stream, p->dev.d_ops,
                        p->dev.d_op_groups + st.grp_begin, G, mats, p->mat_floats, cols, batch);
+    // streaming layout when the pass may leave known-zero outputs unwritten, bit 0 is live and
+    // there are enough live amplitudes to fill the machine
+    uint32_t live = ~st.zero_in & (p->n >= 32 ? ~0u : ((1u << p->n) - 1u));
+    const int n_live = __builtin_popcount(live);
+    static const bool no_stream = std::getenv("QMLE_NO_PRODUCT_STREAM") != nullptr;
+    uint32_t gm_global = 0;
+    for (int g = 0; g < G; ++g)
+      for (int i = 0; i < 4; ++i)
+        gm_global |= 1u << st.tile_bits[p->op_groups[st.grp_begin + g].bits[i]];
+    const bool zeros_may_stay = st.next_tile || (st.zero_in & ~gm_global) == 0;
+    if (zeros_may_stay && (live & 1u) && n_live >= 9 && !no_stream &&
+        ((uint64_t)batch << (n_live - 9)) >= 512) {
+      ProductArgs pa;
+      std::memset(&pa, 0, sizeof(pa));
+      pa.states = states;
+      pa.cols = cols;
+      pa.live_mask = live;
+      pa.n = p->n;
+      pa.G = G;
+      for (int g = 0; g < G; ++g)
+        for (int i = 0; i < 4; ++i)
+          pa.gpos[g][i] = (uint32_t)st.tile_bits[p->op_groups[st.grp_begin + g].bits[i]];
+      hipLaunchKernelGGL(k_product_stream, dim3(1u << (n_live - 9), (unsigned)batch), dim3(256), 0,
+                         stream, pa);
+      HIPCHK(hipGetLastError());
+      return QMLE_OK;
+    }
     const size_t lds_p = 64 * sizeof(float2) + ((size_t)8 << (st.T - 4 * G)) +
                          ((size_t)4 << (st.T - st.L)) + 64;
     const uint32_t n_tiles = grid.x;
