@@ -251,7 +251,10 @@ def main():
     for i, st in enumerate(desc["stages"]):
         k = {"tile": "k_tile", "direct": "k_direct_1q", "diag_all": "k_diag_all"}[st["kind"]]
         if st["kind"] == "tile" and st.get("product") and 0 < i < len(desc["stages"]) - 1:
-            k = "k_tile_product"  # (+ k_fold_columns, inside the same timed scope)
+            # (+ k_fold_columns, inside the same timed scope); the streaming layout takes over
+            # when bit 0 is live and >= 512 live amplitudes x states are in flight (launch_tile)
+            live = bin(~st["zero_in"] & ((1 << n) - 1)).count("1")
+            k = "k_product_stream" if live >= 9 and not st["zero_in"] & 1 else "k_tile_product"
         if i == len(desc["stages"]) - 1 and st["kind"] == "tile":
             k = st["expval_kernel"].replace("_fold", "")  # <Z> out of the last pass: which kernel runs it
         f = fam.setdefault(k, {"ms": 0.0, "launches": 0, "algo": 0.0, "moved": 0.0})

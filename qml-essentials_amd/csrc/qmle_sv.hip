@@ -1189,35 +1189,47 @@ k_mono_coef(const LoweredOp *__restrict__ ops, const OpGroup *__restrict__ group
   for (int k = 0; k < 32; ++k) coef[(size_t)b * 32 + k] = k < n_obs ? W[mo.reg[k] & 15u] : 0.f;
 }
 
+// PAIR: a work item takes two neighbouring amplitudes (local bit 0) with one 16-byte load and
+// walks 2^4 tiles instead of 2^5 -- the same bytes in flight with half the load instructions.
+template <int Q, bool PAIR>
 __global__ void __launch_bounds__(1024)
 k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__ coef) {
-  constexpr int Q = 5;
   extern __shared__ float4 smem4[];
   float *red = reinterpret_cast<float *>(smem4);  // [16][32]
   const int T = a.T, tid = threadIdx.x, b = blockIdx.y;
   const OpGroup g = a.groups[0];
   const int b0 = g.bits[0], b1 = g.bits[1], b2 = g.bits[2], b3 = g.bits[3];
 
-  const uint32_t lb = ins0(ins0(ins0(ins0((uint32_t)tid, b0), b1), b2), b3);
+  const uint32_t vt = PAIR ? 2u * (uint32_t)tid : (uint32_t)tid;  // index among the work-item bits
+  const uint32_t lb = ins0(ins0(ins0(ins0(vt, b0), b1), b2), b3);
   uint32_t gbase = 0;
   for (int j = 0; j < T; ++j) gbase |= ((lb >> j) & 1u) << a.tile_bits[j];
   const bool thread_ok = (lb & a.zin_local) == 0;
   const uint32_t tile0 = blockIdx.x << Q;
   const float2 *pt = a.states + ((size_t)b << a.n) + tile_base(a, tile0) + gbase;
-  uint32_t ostride[Q];  // element offsets of the 5 low tile-index bits
+  uint32_t ostride[Q];  // element offsets of the Q low tile-index bits
 #pragma unroll
   for (int j = 0; j < Q; ++j) ostride[j] = 1u << a.outer_bits[j];
 
-  v32f P;
+  typedef float vqf __attribute__((ext_vector_type(1 << Q)));
+  vqf P, P1;
 #pragma unroll
   for (int it = 0; it < (1 << Q); ++it) {
     uint32_t off = 0;
 #pragma unroll
     for (int j = 0; j < Q; ++j)
       if ((it >> j) & 1) off |= ostride[j];
-    float2 x = make_float2(0.f, 0.f);
-    if (thread_ok && ((tile0 + (uint32_t)it) & a.zin_outer) == 0) x = pt[off];
-    P[it] = norm2(x);
+    const bool live = thread_ok && ((tile0 + (uint32_t)it) & a.zin_outer) == 0;
+    if (PAIR) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) x = *reinterpret_cast<const float4 *>(pt + off);
+      P[it] = x.x * x.x + x.y * x.y;
+      P1[it] = x.z * x.z + x.w * x.w;
+    } else {
+      float2 x = make_float2(0.f, 0.f);
+      if (live) x = pt[off];
+      P[it] = norm2(x);
+    }
   }
 #pragma unroll
   for (int h = 1; h < (1 << Q); h <<= 1) {
@@ -1227,6 +1239,11 @@ k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__
       const float x = P[i], y = P[i | h];
       P[i] = x + y;
       P[i | h] = x - y;
+      if (PAIR) {
+        const float x1 = P1[i], y1 = P1[i | h];
+        P1[i] = x1 + y1;
+        P1[i | h] = x1 - y1;
+      }
     }
   }
 
@@ -1236,9 +1253,12 @@ k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__
   for (int k = 0; k < 32; ++k) {
     A[k] = 0.f;
     if (k < a.n_obs) {
-      const uint32_t mout = mo.out[k];
-      const float val = P[mout & ((1u << Q) - 1u)] * cf[k];  // wave-uniform register index
-      const uint32_t par = (__popc(tile0 & mout) + __popc((uint32_t)tid & mo.thr[k])) & 1u;
+      const uint32_t mout = mo.out[k], mthr = mo.thr[k];
+      const uint32_t idx = mout & ((1u << Q) - 1u);  // wave-uniform register index
+      float val = P[idx];
+      if (PAIR) val += (mthr & 1u) ? -P1[idx] : P1[idx];  // the odd neighbour: local bit 0 set
+      val *= cf[k];
+      const uint32_t par = (__popc(tile0 & mout) + __popc(vt & mthr)) & 1u;
       A[k] = par ? -val : val;
     }
   }
@@ -3007,8 +3027,17 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, int kind, flo
     }
     hipLaunchKernelGGL(k_mono_coef, dim3((batch + 63) / 64), dim3(64), 0, stream, p->dev.d_ops,
                        p->dev.d_op_groups + st.grp_begin, mats, p->mat_floats, mo, n_obs, coef, batch);
-    hipLaunchKernelGGL(k_reg_measure_mono, grid, dim3(1u << (st.T - 4)), 16 * 32 * sizeof(float),
-                       stream, a, mo, coef);
+    static const bool no_pair = std::getenv("QMLE_NO_MONO_PAIR") != nullptr;
+    if (!no_pair && g.bits[0] != 0 && st.tile_bits[0] == 0 && !(a.zin_local & 1u) && st.T >= 11 &&
+        n_outer >= 4) {
+      q = 4;
+      grid.x = 1u << (n_outer - q);
+      hipLaunchKernelGGL((k_reg_measure_mono<4, true>), grid, dim3(1u << (st.T - 5)),
+                         16 * 32 * sizeof(float), stream, a, mo, coef);
+    } else {
+      hipLaunchKernelGGL((k_reg_measure_mono<5, false>), grid, dim3(1u << (st.T - 4)),
+                         16 * 32 * sizeof(float), stream, a, mo, coef);
+    }
   } else if (kind == 2)
     hipLaunchKernelGGL(k_reg_measure<true>, grid, dim3(1u << (st.T - 4)), lds, stream, a, q);
   else
