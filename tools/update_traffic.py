@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json entries (HBM bytes per launch, read by bench.py for roofline.traffic) from
+the per-kernel PMC averages that tools/parse_pmc.py wrote.  Usage: update_traffic.py pmc.json n states"""
+import json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pm = json.load(open(sys.argv[1])); n = int(sys.argv[2]); states = int(sys.argv[3])
+path = os.path.join(root, "profiles", "traffic.json")
+t = json.load(open(path))
+for fam, d in pm.items():
+    if "hbm_read_bytes_per_launch_x2_corrected" not in d or "hbm_write_bytes_per_launch" not in d:
+        continue
+    if not fam.startswith(("k_tile", "k_product", "k_reg_measure", "k_direct")):
+        continue
+    rd, wr = round(d["hbm_read_bytes_per_launch_x2_corrected"]), round(d["hbm_write_bytes_per_launch"])
+    t[f"{fam}:n{n}:fused"] = {"read": rd, "write": wr, "hbm_bytes_per_launch": rd + wr,
+                              "states_per_launch": states}
+json.dump(t, open(path, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in t.items() if k != "_how"}, indent=1))
