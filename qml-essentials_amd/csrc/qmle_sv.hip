@@ -1375,15 +1375,6 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
     in_e[r] = e;
   }
   __syncthreads();  // lut, tc
-  uint32_t in_off[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) in_off[r] = lut[in_e[r] >> L] | (in_e[r] & lowmask);
-  uint32_t out_off[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t j = jt | ((uint32_t)u << (T - 3));
-    out_off[u] = lut[j >> L] | (j & lowmask);
-  }
 
   for (int tt = 0; tt < tiles_per_wg; ++tt) {
     uint32_t tile = blockIdx.x * (uint32_t)tiles_per_wg + (uint32_t)tt;
@@ -1403,8 +1394,10 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
       // (full grid only) nothing but known zeros in, nothing but zeros out -- and the input
       // may never have been written: store the zeros without reading
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        *reinterpret_cast<float4 *>(pt + out_off[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t j = jt | ((uint32_t)u << (T - 3));
+        *reinterpret_cast<float4 *>(pt + (lut[j >> L] | (j & lowmask))) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       continue;
     }
     if (tt) __syncthreads();  // the previous tile's reads of lin are done
@@ -1413,7 +1406,7 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
       const uint32_t idx = (uint32_t)tid + (uint32_t)r * (uint32_t)nt;
       if (idx < (1u << n_live)) {
         float2 x = make_float2(0.f, 0.f);
-        if ((in_e[r] & a.zin_local) == 0) x = pt[in_off[r]];
+        if ((in_e[r] & a.zin_local) == 0) x = pt[lut[in_e[r] >> L] | (in_e[r] & lowmask)];
         lin[idx] = x;
       }
     }
@@ -1434,7 +1427,8 @@ k_tile_product(const TileArgs a, const float2 *__restrict__ cols, int tiles_per_
         }
       const float2 x0 = lin[lc], x1 = lin[bit0_live ? (lc | 1u) : lc];
       const float2 o0 = cmul(f0, x0), o1 = cmul(f1, x1);
-      *reinterpret_cast<float4 *>(pt + out_off[u]) = make_float4(o0.x, o0.y, o1.x, o1.y);
+      const uint32_t j = jt | ((uint32_t)u << (T - 3));
+      *reinterpret_cast<float4 *>(pt + (lut[j >> L] | (j & lowmask))) = make_float4(o0.x, o0.y, o1.x, o1.y);
     }
   }
 }

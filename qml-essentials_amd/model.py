@@ -719,21 +719,30 @@ class Model:
         # --- compiled call ------------------------------------------------------------------
         meas_type, obs = self._build_obs()
         leaf_ids = tuple(k for k, d in ((0, dev_params), (1, dev_inputs)) if d)
-        host_p = p[0].detach().cpu().numpy() if dev_params else np.asarray(p)
-        host_x = x[0].detach().cpu().numpy() if dev_inputs else np.asarray(x)
-        if not dev_params and host_p.ndim == 3 and host_p.shape[0] == 1:
+        # device leaves enter the cache key by shape only: their values are read back (a
+        # device -> host sync) just once, as probe values when the call is first compiled
+        host_p = None if dev_params else np.asarray(p)
+        host_x = None if dev_inputs else np.asarray(x)
+        if host_p is not None and host_p.ndim == 3 and host_p.shape[0] == 1:
             host_p = host_p[0]
-        if not dev_inputs and host_x.ndim == 2 and host_x.shape[0] == 1:
+        if host_x is not None and host_x.ndim == 2 and host_x.shape[0] == 1:
             host_x = host_x[0]
+        shape_p = tuple(p.shape[1:]) if dev_params else tuple(host_p.shape)
+        shape_x = tuple(x.shape[1:]) if dev_inputs else tuple(host_x.shape)
         h = hashlib.blake2b(digest_size=12)
-        for a in (np.asarray(enc, dtype=np.float64), self.data_reupload,
-                  None if dev_params else host_p, None if dev_inputs else host_x):
+        for a in (np.asarray(enc, dtype=np.float64), self.data_reupload, host_p, host_x):
             h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
         key = (meas_type, tuple((type(o).__name__, tuple(o.wires)) for o in obs), leaf_ids,
-               tuple(host_p.shape), tuple(host_x.shape), self._zero_inputs, B_I == 1,
+               shape_p, shape_x, self._zero_inputs, B_I == 1,
                self.remove_zero_encoding, h.hexdigest())
+
+        def probe_args():
+            hp = p[0].detach().cpu().numpy() if dev_params else host_p
+            hx = x[0].detach().cpu().numpy() if dev_inputs else host_x
+            return (hp, hx, None, None, enc)
+
         try:
-            cc = self.script.compiled(key, meas_type, obs, (host_p, host_x, None, None, enc),
+            cc = self.script.compiled(key, meas_type, obs, probe_args,
                                       leaf_ids, dict(noise_params=None, gate_mode="unitary"))
         except NotAffine:
             return NotImplemented

@@ -186,6 +186,8 @@ class Script:
         """Fetch / build the :class:`CompiledCall` for ``key`` (raises :class:`NotAffine`)."""
         cc = self._compiled.get(key)
         if cc is None:
+            if callable(args):  # probe values are only needed to build the call
+                args = args()
             cc = CompiledCall(self, type, obs, args, leaf_ids, kwargs or {})
             if len(self._compiled) > 64:
                 self._compiled.pop(next(iter(self._compiled)))
