@@ -453,12 +453,18 @@ class Model:
         if et in ("density", "state", "probs"):
             return et, []
         if et == "expval":
+            key = tuple(int(q) if isinstance(q, (int, np.integer)) else tuple(int(w) for w in q)
+                        for q in self.output_qubit)
+            cached = getattr(self, "_obs_cache", None)
+            if cached is not None and cached[0] == key:  # rebuilt only when output_qubit changes
+                return "expval", cached[1]
             obs = []
             for spec in self.output_qubit:
                 if isinstance(spec, (int, np.integer)):
                     obs.append(op.PauliZ(wires=int(spec), record=False))
                 else:
                     obs.append(js.build_parity_observable(list(spec)))
+            self._obs_cache = (key, obs)
             return "expval", obs
         raise ValueError(f"Invalid execution_type: {et}.")
 
