@@ -718,8 +718,8 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"product\":" << (st.product_ok ? "true" : "false") << ",\"expval_kernel\":\""
        << (const char *[]){"k_tile", "k_reg_measure", "k_reg_measure_fold", "k_reg_measure_mono"}
               [expval_kernel_of(p, s, !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)))]
-       << "\",\"read_bytes_from_zero\":" << stage_read_bytes(p, s)
-       << ",\"write_bytes_from_zero\":" << stage_write_bytes(p, s)
+       << "\",\"read_bytes_from_zero\":" << (unsigned long long)stage_read_bytes(p, s)
+       << ",\"write_bytes_from_zero\":" << (unsigned long long)stage_write_bytes(p, s)
        << ",\"bits\":[";
     for (int i = 0; i < st.T; ++i) os << (i ? "," : "") << (int)st.tile_bits[i];
     os << "],\"groups\":[";

@@ -136,3 +136,32 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
         assert r["Occupancy"] >= 4 and r["VGPRs"] <= 128, (name, r)
     direct = [v for k, v in res.items() if "k_direct_1q" in k]
     assert direct and all(r["Occupancy"] == 8 for r in direct)
+
+
+def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
+    """Plan compiler, host only: the K2 plan (one HE layer at n = 24, <Z> on every wire) after
+    observable folding -- ready gates are scheduled low bits first, every stage knows which bit
+    positions are still exactly zero when it starts, the middle pass qualifies for the product
+    kernels and the last one for the register-resident measuring kernel."""
+    ops, slots = he_layer_ops(24)
+    top = N.Plan(ops, 24, slots)
+    d = top.describe()
+    assert d["absorbed_ops"] == 24
+    st = d["expval_plan"]["stages"]
+    assert [s["kind"] for s in st] == ["tile"] * 3
+    assert st[0]["bits"] == list(range(12)) and st[0]["zero_in"] == (1 << 24) - 1
+    assert st[1]["zero_in"] == ((1 << 24) - 1) & ~((1 << 12) - 1)        # bits 0..11 rotated so far
+    assert st[2]["zero_in"] == 0xF << 20 and st[2]["bits"][-4:] == [20, 21, 22, 23]
+    assert st[0]["next_tile"] and st[1]["next_tile"] and not st[2]["next_tile"]
+    assert st[1]["product"] and st[1]["lds_round_trips"] == 2
+    assert st[2]["expval_kernel"] == "k_reg_measure_mono"
+    # HBM bytes per state: one 32 KiB tile, 2^12 -> 2^20 amplitudes, 2^20 amplitudes read
+    assert st[0]["read_bytes_from_zero"] == 0 and st[0]["write_bytes_from_zero"] == 8 * 2**12
+    assert st[1]["read_bytes_from_zero"] == 8 * 2**12 and st[1]["write_bytes_from_zero"] == 8 * 2**20
+    assert st[2]["read_bytes_from_zero"] == 8 * 2**20
+    # switched off: dense passes, the k_tile epilogue's register-resident sibling still measures
+    dense = N.Plan(ops, 24, slots, flags=N.plan_flags(no_sparse=True)).describe()["expval_plan"]["stages"]
+    assert dense[1]["read_bytes_from_zero"] == 8 * 2**24 and dense[2]["expval_kernel"] == "k_reg_measure"
+    # tape order keeps the old schedule (high wires first)
+    tape = N.Plan(ops, 24, slots, flags=N.plan_flags(tape_order=True)).describe()["expval_plan"]["stages"]
+    assert tape[0]["bits"] == [0, 1, 2, 3] + list(range(16, 24))
