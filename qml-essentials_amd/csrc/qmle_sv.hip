@@ -11,8 +11,19 @@
 //                      store / measure   (whole state in LDS when n <= 14)
 //   k_direct_1q        one (controlled) 2x2 gate streamed through HBM in place
 //   k_diag_all         full-register diagonal (Golomb encoding)
+//   k_reg_measure<FOLD>, k_reg_measure_mono (+ k_mono_coef)
+//                      measuring last pass in registers: <Z> / Z parities accumulated
+//                      across tiles per work item, gates on known zeros folded away
+//   k_product_stream, k_tile_product (+ k_fold_columns)
+//                      pass whose gate groups all act on known-zero bits:
+//                      out = in (x) prod_g U_g e_0, written without staging amplitudes
 //   k_expval_partial / k_expval_final   all-qubit <Z> in ONE read of the state
 //   k_probs, k_density, k_marginal, k_overlap_*, k_cross_*, k_histogram
+//   k_mw_tile*         Meyer-Wallach purities; k_adjoint_lds, k_tile_adj, k_adj_*: adjoint
+//   k_cdf, k_sample, k_probs_diag_expval: shot sampling; k_build_angles: device angle table
+//
+// Runs from |0..0> track the bit positions whose amplitudes are still exactly zero
+// (Stage::zero_in, qmle_plan.cpp): they are neither read nor computed nor stored.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
