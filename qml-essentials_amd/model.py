@@ -132,6 +132,12 @@ class Model:
                 )
                 value = [int(value)]
         self._output_qubit = value
+        # the reference derives the result shape in the execution_type setter only
+        # (model.py:343-365), so a later change of output_qubit leaves it stale there; refresh it
+        if getattr(self, "_execution_type", None) is not None:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.execution_type = self._execution_type
 
     @property
     def execution_type(self) -> str:

@@ -426,6 +426,12 @@ def test_known_zero_amplitudes_are_skipped(n, tile_bits, low_bits):
         assert np.array_equal(res["sparse"][0] == 0, res["dense"][0] == 0), name
         psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
         assert np.abs(res["sparse"][0][0] - psi).max() < 2e-6, name
+        # one state buffer recycled for every sample: regions a pass skipped hold the previous
+        # sample's amplitudes and must never be read
+        one = plan.run(ang, "expval", list(range(n)), states_in_flight=1).cpu().numpy()
+        assert np.abs(one - res["dense"][2]).max() < 1e-6, name
+        one = plan.run(ang, "probs", states_in_flight=1).cpu().numpy()
+        assert np.abs(one - res["dense"][1]).max() < 1e-6, name
 
 
 @pytest.mark.parametrize("n,tile_bits,low_bits,B", [(16, 12, 4, 5), (17, 11, 3, 3), (18, 13, 5, 2), (20, 12, 4, 70)])

@@ -534,3 +534,33 @@ def test_state_ignores_output_qubit():
     assert s.shape == (2, 8)
     assert np.abs(s - full(params=m.params, inputs=x, execution_type="state")).max() < 1e-6
     assert np.allclose(np.sum(np.abs(s) ** 2, axis=-1), 1.0, atol=1e-5)
+
+
+def test_output_qubit_change_between_calls_rebuilds_observables():
+    """The observable list is cached per ``output_qubit``: changing it between calls (int, list,
+    parity pairs) must change the measurement, on the host-array and the device-tensor path."""
+    from qml_essentials_amd.model import Model
+
+    m = Model(4, 2, "Hardware_Efficient")
+    x = np.array([[0.3], [0.9]], dtype=np.float32)
+    full = m(inputs=x)                                   # all wires
+    assert full.shape == (2, 4)
+    m.output_qubit = 1
+    one = m(inputs=x)
+    assert one.shape == (2,) and np.abs(one - full[:, 1]).max() < 1e-6
+    m.output_qubit = [0, 3]
+    two = m(inputs=torch.from_numpy(x).cuda()).cpu().numpy()
+    assert two.shape == (2, 2) and np.abs(two - full[:, [0, 3]]).max() < 1e-6
+    m.output_qubit = [[0, 1], [2, 3]]
+    par = m(inputs=x)
+    spec = OC.ModelSpec(4, 2, "Hardware_Efficient")
+    for i in range(2):
+        tape = OC.model_tape(spec, m.params[0] if m.params.ndim == 3 else m.params, x[i])
+        psi = OE.simulate_pure(tape, 4, np.complex128)
+        pr = np.abs(psi) ** 2
+        idx = np.arange(16)
+        for k, (a_, b_) in enumerate([(0, 1), (2, 3)]):
+            sign = 1.0 - 2.0 * (((idx >> (3 - a_)) ^ (idx >> (3 - b_))) & 1)
+            assert abs(par[i, k] - (pr * sign).sum()) < 1e-6
+    m.output_qubit = -1
+    assert np.abs(m(inputs=x) - full).max() < 1e-7
