@@ -634,11 +634,23 @@ int compile_plan(qmle_plan *p) {
 
   // pass-cost model (microseconds at n = 24, scaled by 2^(n-24); measured on MI355X,
   // profiles/): HBM round trip of a tile pass ~35, each LDS round trip ~14, direct ~33
+  // Known zeros scale both parts: a stage reads 2^-|zero_in| of the state, computes and (when
+  // the next stage is a tile stage) stores only the tiles whose outer bits are live.
+  const bool sparse_model = !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
   auto cost = [&]() {
     double c = 0;
-    for (const Stage &st : p->stages) {
-      if (st.kind == ST_TILE) c += 35.0 + 14.0 * (st.grp_end - st.grp_begin);
-      else c += 33.0;
+    for (size_t si = 0; si < p->stages.size(); ++si) {
+      const Stage &st = p->stages[si];
+      if (st.kind != ST_TILE) { c += 33.0; continue; }
+      double rd = si == 0 ? 0.0 : 1.0, wr = 1.0, tiles = 1.0;
+      if (sparse_model && st.zero_in) {
+        uint32_t outer = 0;
+        for (int i = 0; i < n - st.T; ++i) outer |= 1u << st.outer_bits[i];
+        tiles = std::ldexp(1.0, -__builtin_popcount(st.zero_in & outer));
+        if (si > 0) rd = std::ldexp(1.0, -__builtin_popcount(st.zero_in));
+        if (st.next_tile) wr = tiles;
+      }
+      c += 2.0 + 17.5 * (rd + wr) + 14.0 * (st.grp_end - st.grp_begin) * tiles;
     }
     return c;
   };
