@@ -282,6 +282,30 @@ class Plan:
     def workspace_bytes(self, batch: int, meas: str, n_obs: int = 0, states_in_flight: int = 0):
         return int(lib().qmle_workspace_bytes(self._h, batch, MEAS[meas], n_obs, states_in_flight))
 
+    def _workspace(self, B: int, meas: str, n_obs: int, states_in_flight: int, workspace, dev):
+        """Workspace tensor of the size the engine asks for.  The default asks for state buffers
+        for up to 32 GiB worth of states per launch; when the device cannot spare that, fall
+        back to fewer states in flight (the engine adapts to whatever it is handed)."""
+        torch = require_gpu()
+        need = self.workspace_bytes(B, meas, n_obs, states_in_flight)
+        if workspace is not None and workspace.numel() >= need:
+            return workspace
+        try:
+            return torch.empty(need, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError:
+            if states_in_flight == 1:
+                raise
+        s = states_in_flight if states_in_flight > 0 else B
+        while s > 1:
+            s = max(1, s // 4)
+            try:
+                return torch.empty(self.workspace_bytes(B, meas, n_obs, s), dtype=torch.uint8,
+                                   device=dev)
+            except torch.OutOfMemoryError:
+                if s == 1:
+                    raise
+        raise torch.OutOfMemoryError("qmle workspace")
+
     def run(self, angles, meas: str, obs_wires: Sequence[int] = (), out=None, workspace=None,
             states_in_flight: int = 0):
         """simulate_and_measure for a batch.  ``angles``: float32 cuda tensor [B, n_slots]."""
@@ -306,9 +330,7 @@ class Plan:
                 out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
             else:
                 out = torch.empty((B, D, D), dtype=torch.complex64, device=dev)
-        need = self.workspace_bytes(B, meas, n_obs, states_in_flight)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        workspace = self._workspace(B, meas, n_obs, states_in_flight, workspace, dev)
         rc = lib().qmle_run_batch(
             self._h, C.c_void_p(angles.data_ptr()), B, MEAS[meas], _i32(obs_wires), n_obs,
             C.c_void_p(out.data_ptr()), C.c_void_p(workspace.data_ptr()),
@@ -338,9 +360,7 @@ class Plan:
                 m |= 1 << int(w)
             masks[k] = m
         out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
-        need = self.workspace_bytes(B, "expval", n_obs, states_in_flight)
-        if workspace is None or workspace.numel() < need:
-            workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        workspace = self._workspace(B, "expval", n_obs, states_in_flight, workspace, dev)
         check(lib().qmle_run_batch_parity(
             self._h, C.c_void_p(angles.data_ptr()), B, masks, n_obs, C.c_void_p(out.data_ptr()),
             C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream_ptr()),

@@ -492,3 +492,33 @@ def test_register_measuring_last_pass(n, tile_bits, low_bits, B):
         if otape is not None:
             want = OE.simulate_and_measure(otape, n, "expval", [("PauliZ", [w]) for w in range(n)], np.complex128)
             assert np.abs(ez[0] - want).max() < 3e-6, name
+
+
+def test_workspace_falls_back_to_fewer_states_in_flight_when_memory_is_short():
+    """The engine asks for state buffers for up to 32 GiB of states per launch; with less free
+    HBM the Python wrapper hands it a smaller workspace and the engine runs more chunks."""
+    from qml_essentials_amd import _native as N
+
+    n, B = 22, 1536                      # 32 MiB per state: the default wants 32 GiB
+    ops, slots = _he_ops(n)
+    plan = N.Plan(ops, n, slots)
+    rng = np.random.default_rng(5)
+    ang = torch.from_numpy(rng.uniform(0, 6.28, (B, slots)).astype(np.float32)).cuda()
+    want = plan.run(ang[:8], "expval", list(range(n))).cpu().numpy()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (6 << 30)), dtype=torch.uint8, device="cuda")  # leave ~6 GiB
+    try:
+        assert plan.workspace_bytes(B, "expval", n) > (6 << 30)
+        got = plan.run(ang, "expval", list(range(n))).cpu().numpy()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert got.shape == (B, n) and np.abs(got[:8] - want).max() < 1e-6
+    assert np.isfinite(got).all() and np.abs(got).max() <= 1.0 + 1e-5
+
+
+def _he_ops(n):
+    from tests.test_abi_cpu import he_layer_ops
+
+    return he_layer_ops(n)
