@@ -10,8 +10,10 @@ wire, the two populations and one cross term: ``a^2 + d^2 + 2|c|^2``.
 ``bell_measurements`` (``entanglement.py:106-219``) and ``concentratable_entanglement``
 (``:471-576``) build 2n- / 3n-qubit circuits from shifted copies of the model circuit
 (``tape.copy_to_tape``) and read marginal probabilities -- same kernels at a larger
-register.  ``relative_entropy`` / ``entanglement_of_formation``
-need matrix logarithms / eigendecompositions of density matrices and stay out of scope.
+register.  ``relative_entropy`` (``:222-372``) and
+``entanglement_of_formation`` (``:375-468``) take their density matrices from the engine
+(``execution_type="density"``) and do what the reference does with them on the host: SciPy's
+matrix logarithm per matrix, ``eigh`` + Meyer-Wallach of the eigenvectors.
 """
 from __future__ import annotations
 
@@ -199,3 +201,118 @@ class Entanglement:
         log.debug("Variance of measure: %s", float(ent.var()) if ent.numel() > 1 else 0.0)
         return float(ent.mean())
 
+
+
+    # ------------------------------------------------------------------ density-matrix measures
+    @classmethod
+    def _compute_log_density(cls, model: Model, **kwargs):
+        """(rho, log2 rho) of the model's output state (``entanglement.py:307-327``); the matrix
+        logarithm is SciPy's, one matrix at a time, as ``math.logm_v`` (``math.py:7-28``)."""
+        kwargs.setdefault("inputs", None)
+        kwargs.pop("execution_type", None)
+        rho = np.asarray(js._host(model(execution_type="density", **kwargs)))
+        dim = 2**model.n_qubits
+        rho = rho.reshape(-1, dim, dim)
+        return rho, logm_v(rho) / np.log(2)
+
+    @classmethod
+    def _compute_rel_entropies(cls, rhos, log_rhos, log_sigmas):
+        """|Tr rho (log rho - log sigma)| for every (sigma, rho) pair (``entanglement.py:330-372``):
+        shape (n_rhos,) for a single sigma, (n_sigmas, n_rhos) for a batch of them."""
+        rhos, log_rhos, log_sigmas = (np.asarray(a) for a in (rhos, log_rhos, log_sigmas))
+        single = log_sigmas.ndim == 2
+        ls = log_sigmas[None] if single else log_sigmas
+        # Tr(A B) = sum_ij A_ij B_ji
+        out = np.abs(np.einsum("rij,srji->sr", rhos, log_rhos[None] - ls[:, None]))
+        return out[0] if single else out
+
+    @classmethod
+    def relative_entropy(cls, model: Model, n_samples: int, n_sigmas: int, random_key=None,
+                         scale: bool = False, **kwargs: Any) -> float:
+        """Relative entropy of entanglement against ``n_sigmas`` random separable states (an upper
+        bound: the nearest separable state is not searched for), normalised by the GHZ state's
+        (``entanglement.py:222-304``)."""
+        from .utils import safe_random_split
+
+        if scale:
+            n_samples = (2**model.n_qubits) * n_samples
+            n_sigmas = (2**model.n_qubits) * n_sigmas
+        if random_key is None:
+            random_key = model.random_key
+        log_sigmas = sample_random_separable_states(model.n_qubits, n_samples=int(n_sigmas),
+                                                    random_key=random_key, take_log=True)
+        random_key, _ = safe_random_split(random_key)
+        if n_samples is not None and n_samples > 0:
+            model.initialize_params(random_key, repeat=int(n_samples))
+        elif np.asarray(model.params).ndim <= 2:
+            model.params = np.asarray(model.params).reshape(1, *np.asarray(model.params).shape)
+        rhos, log_rhos = cls._compute_log_density(model, **kwargs)
+        rel = cls._compute_rel_entropies(rhos, log_rhos, log_sigmas)          # (n_sigmas, n_rhos)
+        ghz = Model(model.n_qubits, 1, "GHZ", data_reupload=False)
+        rho_g, log_rho_g = cls._compute_log_density(ghz, **kwargs)
+        rel_g = cls._compute_rel_entropies(rho_g, log_rho_g, log_sigmas)      # (n_sigmas, 1)
+        capability = (rel / rel_g).min(axis=0)                                 # nearest sampled sigma
+        log.debug("Variance of measure: %s", float(capability.var()))
+        return float(capability.mean())
+
+    @classmethod
+    def _compute_entanglement_of_formation(cls, rhos, n_qubits: int, always_decompose: bool):
+        """Eigen-decompose every density matrix and weight the Meyer-Wallach measure of the
+        eigenvectors by the eigenvalues (``entanglement.py:438-468``)."""
+        rhos = np.asarray(js._host(rhos)).astype(np.complex128)
+        evals, evecs = np.linalg.eigh(rhos)
+        if not always_decompose and np.isclose(evals, 1.0, atol=1e-5).any(axis=-1).all():
+            return np.asarray(cls._compute_meyer_wallach_meas(rhos, n_qubits))
+        dim = 2**n_qubits
+        states = np.swapaxes(evecs, -1, -2).reshape(-1, dim)                   # eigenvector k = row
+        measures = cls._compute_meyer_wallach_meas(states.astype(np.complex64), n_qubits)
+        measures = np.asarray(js._host(measures), dtype=np.float64).reshape(-1, dim)
+        return np.einsum("si,si->s", measures, np.clip(evals, 0.0, None))
+
+    @classmethod
+    def entanglement_of_formation(cls, model: Model, n_samples: int, random_key=None,
+                                  scale: bool = False, always_decompose: bool = False,
+                                  **kwargs: Any) -> float:
+        """Entanglement of formation of (possibly mixed) output states for the eigen-decomposition
+        into pure states; equals Meyer-Wallach for pure states (``entanglement.py:375-435``)."""
+        if scale:
+            n_samples = (2**model.n_qubits) * n_samples
+        if n_samples is not None and n_samples > 0:
+            model.initialize_params(random_key, repeat=int(n_samples))
+        elif np.asarray(model.params).ndim <= 2:
+            model.params = np.asarray(model.params).reshape(1, *np.asarray(model.params).shape)
+        kwargs.setdefault("inputs", None)
+        kwargs.pop("execution_type", None)
+        rhos = np.asarray(js._host(model(execution_type="density", **kwargs)))
+        dim = 2**model.n_qubits
+        ent = cls._compute_entanglement_of_formation(rhos.reshape(-1, dim, dim), model.n_qubits,
+                                                     always_decompose)
+        return float(np.mean(ent))
+
+
+def logm_v(A):
+    """Matrix logarithm of one matrix or of every matrix of a batch (``math.py:7-28``)."""
+    import warnings
+
+    from scipy.linalg import logm
+
+    A = np.asarray(A)
+    if A.ndim not in (2, 3):
+        raise NotImplementedError("Unsupported shape of input matrix")
+    with warnings.catch_warnings():
+        # pure states are singular: SciPy reports "logm result may be inaccurate" for every one
+        # of them (the reference leaves the same warnings unhandled, math.py:19)
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return logm(A) if A.ndim == 2 else np.stack([logm(a) for a in A])
+
+
+def sample_random_separable_states(n_qubits: int, n_samples: int, random_key, take_log: bool = False):
+    """Density matrices (n_samples, 2^n, 2^n) of random product states: one ``No_Entangling``
+    layer with random angles (``entanglement.py:687-715``)."""
+    model = Model(n_qubits, 1, "No_Entangling", data_reupload=False)
+    model.initialize_params(random_key, repeat=int(n_samples))
+    sigmas = np.asarray(js._host(model(execution_type="density", inputs=None)))
+    sigmas = sigmas.reshape(-1, 2**n_qubits, 2**n_qubits)
+    if take_log:
+        sigmas = logm_v(sigmas) / np.log(2.0)
+    return sigmas
