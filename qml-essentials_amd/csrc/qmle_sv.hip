@@ -76,6 +76,25 @@ __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {  // a*b +
   const v2f r = __builtin_elementwise_fma(ai, bs, __builtin_elementwise_fma(ar, bv, cv));
   return make_float2(r.x, r.y);
 }
+typedef float vf4 __attribute__((ext_vector_type(4)));
+// NT: non-temporal accesses for states far larger than the 256 MiB Infinity Cache
+// (measured on MI355X, tools/k1_tune.hip: +5..11 % at n = 28, harmful when cache-resident)
+template <bool NT> __device__ __forceinline__ float4 ld4(const float4 *p) {
+  if (NT) {
+    const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+template <bool NT> __device__ __forceinline__ void st4(float4 *p, float4 v) {
+  if (NT) {
+    const vf4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<vf4 *>(p));
+  } else {
+    *p = v;
+  }
+}
+
 __device__ __forceinline__ float norm2(float2 a) { return a.x * a.x + a.y * a.y; }
 
 struct Mat2 {
@@ -1202,7 +1221,7 @@ k_mono_coef(const LoweredOp *__restrict__ ops, const OpGroup *__restrict__ group
 
 // PAIR: a work item takes two neighbouring amplitudes (local bit 0) with one 16-byte load and
 // walks 2^4 tiles instead of 2^5 -- the same bytes in flight with half the load instructions.
-template <int Q, bool PAIR>
+template <int Q, bool PAIR, bool NT>
 __global__ void __launch_bounds__(1024)
 k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__ coef) {
   extern __shared__ float4 smem4[];
@@ -1233,7 +1252,15 @@ k_reg_measure_mono(const TileArgs a, const MonoObs mo, const float *__restrict__
     const bool live = thread_ok && ((tile0 + (uint32_t)it) & a.zin_outer) == 0;
     if (PAIR) {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) x = *reinterpret_cast<const float4 *>(pt + off);
+      if (live) {
+        if (NT) {  // read once, far more than the caches hold: keep it out of them
+          typedef float v4nt __attribute__((ext_vector_type(4)));
+          const v4nt v = __builtin_nontemporal_load(reinterpret_cast<const v4nt *>(pt + off));
+          x = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+          x = *reinterpret_cast<const float4 *>(pt + off);
+        }
+      }
       P[it] = x.x * x.x + x.y * x.y;
       P1[it] = x.z * x.z + x.w * x.w;
     } else {
@@ -1457,6 +1484,7 @@ struct ProductArgs {
   int n, G;
 };
 
+template <bool NT>
 __global__ void __launch_bounds__(256) k_product_stream(const ProductArgs a) {
   __shared__ float2 tc[4][16];
   __shared__ uint32_t goff[4][16];
@@ -1496,7 +1524,7 @@ __global__ void __launch_bounds__(256) k_product_stream(const ProductArgs a) {
         for (int i0 = 0; i0 < 16; ++i0) {
           const float2 f = cmul(f123, tc[0][i0]);
           const float2 o0 = cmul(f, x0), o1 = cmul(f, x1);
-          *reinterpret_cast<float4 *>(pt + (o123 | goff[0][i0])) = make_float4(o0.x, o0.y, o1.x, o1.y);
+          st4<NT>(reinterpret_cast<float4 *>(pt + (o123 | goff[0][i0])), make_float4(o0.x, o0.y, o1.x, o1.y));
         }
       }
 }
@@ -1852,24 +1880,6 @@ k_tile_pf(const TileArgs a, uint32_t n_tiles, uint32_t total, uint32_t chunk) {
 //   MODE 2: control >= 1, target >= 1        MODE 3: control >= 1, target bit 0
 //   MODE 4: control bit 0, target >= 1
 // ---------------------------------------------------------------------------
-typedef float vf4 __attribute__((ext_vector_type(4)));
-// NT: non-temporal accesses for states far larger than the 256 MiB Infinity Cache
-// (measured on MI355X, tools/k1_tune.hip: +5..11 % at n = 28, harmful when cache-resident)
-template <bool NT> __device__ __forceinline__ float4 ld4(const float4 *p) {
-  if (NT) {
-    const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
-  return *p;
-}
-template <bool NT> __device__ __forceinline__ void st4(float4 *p, float4 v) {
-  if (NT) {
-    const vf4 w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<vf4 *>(p));
-  } else {
-    *p = v;
-  }
-}
 
 // One work item per thread and an exact grid: a persistent grid-stride loop measured
 // 15-20 % slower for this in-place two-stream pattern (tools/k1_tune.hip).
@@ -2970,8 +2980,14 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       for (int g = 0; g < G; ++g)
         for (int i = 0; i < 4; ++i)
           pa.gpos[g][i] = (uint32_t)st.tile_bits[p->op_groups[st.grp_begin + g].bits[i]];
-      hipLaunchKernelGGL(k_product_stream, dim3(1u << (n_live - 9), (unsigned)batch), dim3(256), 0,
-                         stream, pa);
+      const dim3 pgrid(1u << (n_live - 9), (unsigned)batch);
+      const int n_out = n_live + 4 * G;  // amplitudes written per state = 2^n_out
+      // >= 1 GiB written per launch: non-temporal stores (the pass itself is no faster, the
+      // measuring pass that follows is: 3.13 -> 2.99 ms per K2 step)
+      if (((uint64_t)batch << (n_out + 3)) >= (1ull << 30))
+        hipLaunchKernelGGL(k_product_stream<true>, pgrid, dim3(256), 0, stream, pa);
+      else
+        hipLaunchKernelGGL(k_product_stream<false>, pgrid, dim3(256), 0, stream, pa);
       HIPCHK(hipGetLastError());
       return QMLE_OK;
     }
@@ -3037,10 +3053,18 @@ static int launch_reg_measure(const qmle_plan *p, const Stage &st, int kind, flo
         n_outer >= 4) {
       q = 4;
       grid.x = 1u << (n_outer - q);
-      hipLaunchKernelGGL((k_reg_measure_mono<4, true>), grid, dim3(1u << (st.T - 5)),
-                         16 * 32 * sizeof(float), stream, a, mo, coef);
+      // live amplitudes per launch >= 1 GiB: stream them past the caches (0.427 -> 0.38 ms per
+      // 256 states of K2; k_direct_1q's measurements say the opposite below the cache size)
+      const int n_live = p->n - __builtin_popcount(st.zero_in);
+      const bool nt = ((uint64_t)batch << (n_live + 3)) >= (1ull << 30);
+      if (nt)
+        hipLaunchKernelGGL((k_reg_measure_mono<4, true, true>), grid, dim3(1u << (st.T - 5)),
+                           16 * 32 * sizeof(float), stream, a, mo, coef);
+      else
+        hipLaunchKernelGGL((k_reg_measure_mono<4, true, false>), grid, dim3(1u << (st.T - 5)),
+                           16 * 32 * sizeof(float), stream, a, mo, coef);
     } else {
-      hipLaunchKernelGGL((k_reg_measure_mono<5, false>), grid, dim3(1u << (st.T - 4)),
+      hipLaunchKernelGGL((k_reg_measure_mono<5, false, false>), grid, dim3(1u << (st.T - 4)),
                          16 * 32 * sizeof(float), stream, a, mo, coef);
     }
   } else if (kind == 2)
