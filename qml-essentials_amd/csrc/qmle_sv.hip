@@ -485,6 +485,7 @@ struct TileArgs {
   // tile_free deposited); the others are neither computed nor stored -- the next stage knows.
   uint32_t zin_local, zin_outer, tile_free;
   int compact;
+  int nt;  // the launch streams >= 1 GiB of states: non-temporal tile loads / stores
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
@@ -675,7 +676,9 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const uint32_t j = (j0 + u * nt) * 2u;
-          *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = v[u];
+          float4 *dst = reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+          if (a.nt) st4<true>(dst, v[u]);
+          else st4<false>(dst, v[u]);
         }
       }
     } else {
@@ -920,7 +923,8 @@ __global__ void k_tile(const TileArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const uint32_t j = (j0 + u * nt) * 2u;
-          v[u] = *reinterpret_cast<const float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+          const float4 *src = reinterpret_cast<const float4 *>(st + (base | lut[j >> L] | (j & lowmask)));
+          v[u] = a.nt ? ld4<true>(src) : ld4<false>(src);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -2883,6 +2887,12 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs,
                               from_zero);
   a.slots_in_lds = tile_lds_bytes(st.T, st.L, a.n_ops) <= 160 * 1024 ? 1 : 0;
+  static const bool no_nt = std::getenv("QMLE_TILE_NO_NT") != nullptr;
+  // dense stages only (a stage that skips known zeros moves a fraction of the state, and what
+  // it writes is read back at once): K2 dense 122.6 -> 119.8 ms per step
+  a.nt = !no_nt && st.T < p->n && !(from_zero && st.zero_in) &&
+                 ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)
+             ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   static bool attr_set = false;
   if (!attr_set) {
