@@ -31,6 +31,8 @@ for trial in range(int(os.environ.get("FUZZ_N", "200"))):
     T = int(rng.integers(10, 14)) if layered else int(rng.integers(6, 14)); T = min(T, n - 1)
     L = int(rng.integers(1, min(T, 8)))
     B = int(rng.integers(1, 4))
+    if layered and rng.random() < 0.3:  # enough states per launch for the streaming product kernel
+        B = int(rng.integers(24, 72))
     table = rng.uniform(0, 6.28, size=(B, max(1, len(angles)))).astype(np.float32)[:, : len(angles)]
     ang = torch.from_numpy(np.ascontiguousarray(table)).cuda()
     if ang.shape[1] == 0:
