@@ -2969,7 +2969,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     hipLaunchKernelGGL(k_fold_columns, dim3((items + 63) / 64), dim3(64), 0, stream, p->dev.d_ops,
                        p->dev.d_op_groups + st.grp_begin, G, mats, p->mat_floats, cols, batch);
     // streaming layout when the pass may leave known-zero outputs unwritten, bit 0 is live and
-    // there are enough live amplitudes to fill the machine
+    // there are at least ~128 workgroups of 512 live amplitudes
     uint32_t live = ~st.zero_in & (p->n >= 32 ? ~0u : ((1u << p->n) - 1u));
     const int n_live = __builtin_popcount(live);
     static const bool no_stream = std::getenv("QMLE_NO_PRODUCT_STREAM") != nullptr;
@@ -2978,8 +2978,13 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       for (int i = 0; i < 4; ++i)
         gm_global |= 1u << st.tile_bits[p->op_groups[st.grp_begin + g].bits[i]];
     const bool zeros_may_stay = st.next_tile || (st.zero_in & ~gm_global) == 0;
+    static const uint64_t stream_min_wgs = [] {
+      const char *e = std::getenv("QMLE_STREAM_MIN_WGS");
+      const long v = e ? atol(e) : 0;
+      return (uint64_t)(v > 0 ? v : 128);  // K2, 32 states = 256 workgroups: 49 vs 73 us (tile layout)
+    }();
     if (zeros_may_stay && (live & 1u) && n_live >= 9 && !no_stream &&
-        ((uint64_t)batch << (n_live - 9)) >= 512) {
+        ((uint64_t)batch << (n_live - 9)) >= stream_min_wgs) {
       ProductArgs pa;
       std::memset(&pa, 0, sizeof(pa));
       pa.states = states;
