@@ -226,3 +226,30 @@ def test_tangent_tracking_of_gate_angles():
     prod = x[0] * x[1]                                    # product rule
     tt = {flat: coef for _, flat, coef in param_tangent(prod)}
     assert np.allclose(tt[0], [2.0, 4.0]) and np.allclose(tt[1], [1.0, 3.0])
+
+
+def test_entanglement_density_matrix_helpers_host_math():
+    """relative entropy / entanglement of formation: the host side (entanglement.py:307-372,
+    438-468) on density matrices with known answers -- no GPU involved."""
+    from qml_essentials_amd.entanglement import Entanglement, logm_v
+
+    p, q = np.array([0.5, 0.25, 0.125, 0.125]), np.array([0.25, 0.25, 0.25, 0.25])
+    rho, sigma = np.diag(p).astype(np.complex128), np.diag(q).astype(np.complex128)
+    log_rho, log_sigma = logm_v(rho[None]) / np.log(2), logm_v(sigma) / np.log(2)
+    assert log_rho.shape == (1, 4, 4) and np.allclose(np.diag(log_rho[0]).real, np.log2(p))
+    kl = float(np.sum(p * np.log2(p / q)))
+    one = Entanglement._compute_rel_entropies(rho[None], log_rho, log_sigma)
+    assert one.shape == (1,) and abs(one[0] - kl) < 1e-12
+    many = Entanglement._compute_rel_entropies(np.stack([rho, sigma]), np.stack([log_rho[0], log_sigma]),
+                                               np.stack([log_sigma, log_rho[0]]))
+    assert many.shape == (2, 2)                                   # (n_sigmas, n_rhos)
+    assert abs(many[0, 0] - kl) < 1e-12 and abs(many[0, 1]) < 1e-12 and abs(many[1, 0]) < 1e-12
+    assert abs(many[1, 1] - float(np.sum(q * np.log2(q / p)))) < 1e-12
+    with pytest.raises(NotImplementedError):
+        logm_v(np.zeros((2, 2, 2, 2)))
+    # entanglement of formation, pure-state shortcut: Bell state -> 1, product state -> 0
+    bell = np.zeros(4, dtype=np.complex128); bell[[0, 3]] = 2 ** -0.5
+    prod = np.zeros(4, dtype=np.complex128); prod[1] = 1.0
+    rhos = np.stack([np.outer(bell, bell.conj()), np.outer(prod, prod.conj())])
+    eof = Entanglement._compute_entanglement_of_formation(rhos, 2, always_decompose=False)
+    assert np.allclose(eof, [1.0, 0.0], atol=1e-12)
