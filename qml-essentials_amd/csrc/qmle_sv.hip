@@ -2588,6 +2588,8 @@ struct MwArgs {
   int8_t outer_bits[QMLE_MAX_QUBITS];
 };
 
+// LOW: also the sums of the 4 low bits, which every pass stages but only the first one reports
+template <bool LOW>
 __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t n_tiles) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -2628,7 +2630,7 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
     __syncthreads();
     const uint32_t tidv = (uint32_t)tid;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
+    for (int g = LOW ? 0 : 1; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
       const uint32_t bs =
           sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3));
       float2 r[16];
@@ -2649,7 +2651,7 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
         acc[3 * (4 * g + t) + 1] += ci;
         acc[3 * (4 * g + t) + 2] += z;
       }
-      if (g == 0) {
+      if (g == 1) {
         float tot = 0.f;
 #pragma unroll
         for (int c = 0; c < 16; ++c) tot += r[c].x * r[c].x + r[c].y * r[c].y;
@@ -2669,9 +2671,110 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
   }
 }
 
+// Passes after the first only report 8 high bits: no LDS staging for those.  A workgroup
+// takes a block of 2^14 amplitudes -- the 6 lowest bits (one wave = 512 contiguous bytes per
+// load instruction; the LDS tile kernel's 4 low bits give 128-byte runs) and the pass's 8
+// bits -- and walks it twice: the 16 amplitudes over the first 4 reported bits in registers,
+// then over the other 4 (second read out of L2).  The 25 sums are kept per work item across
+// the 2^q blocks a workgroup walks: one cross-lane reduction per workgroup.  Row layout as
+// k_mw_tile.
+struct MwDirectArgs {
+  const float2 *states;
+  float *partial;
+  int n;
+  int8_t hi[8];                        // reported bit positions, ascending
+  int8_t outer[QMLE_MAX_QUBITS];       // the other positions >= 6, ascending
+};
+
+// (156 VGPRs = 3 waves per SIMD; forcing 4 waves changes nothing: 1.96 vs 1.93 ms at n = 28)
+__global__ void __launch_bounds__(kMwThreads) k_mw_direct(const MwDirectArgs a, int q) {
+  __shared__ float red[(kMwThreads / kWave) * 37];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const float2 *st = a.states + ((size_t)b << a.n);
+  const uint32_t lane_off = (uint32_t)tid & 63u;  // bits 0..5
+  const uint32_t wv = (uint32_t)tid >> 6;          // 2 of the 4 bits a gather leaves to the work items
+  uint32_t hs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hs[i] = 1u << a.hi[i];
+  // per reported bit: (cr, ci) as one packed pair, z; explicit two-lane arithmetic (left to the
+  // SLP vectoriser the loop-carried sums get paired at random: 180 VGPRs)
+  v2f cri[8];
+  float zz[8], tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { cri[k] = (v2f){0.f, 0.f}; zz[k] = 0.f; }
+  const int n_outer = a.n - 14;
+  for (uint32_t it = 0; it < (1u << q); ++it) {
+    const uint32_t blk = (blockIdx.x << q) + it;
+    uint64_t base = 0;
+    for (int i = 0; i < n_outer; ++i) base |= (uint64_t)((blk >> i) & 1u) << a.outer[i];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll 1
+      for (uint32_t round = 0; round < 4; ++round) {
+        const uint32_t o = wv | (round << 2);  // the 4 bits of the OTHER gather
+        const uint32_t oo = ((o & 1u) ? hs[4 * (1 - g)] : 0u) | ((o & 2u) ? hs[4 * (1 - g) + 1] : 0u) |
+                            ((o & 4u) ? hs[4 * (1 - g) + 2] : 0u) | ((o & 8u) ? hs[4 * (1 - g) + 3] : 0u);
+        const float2 *pu = st + base + oo;
+        v2f r[16];
+        float pr[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const uint32_t go = ((c & 1) ? hs[4 * g] : 0u) | ((c & 2) ? hs[4 * g + 1] : 0u) |
+                              ((c & 4) ? hs[4 * g + 2] : 0u) | ((c & 8) ? hs[4 * g + 3] : 0u);
+          const float2 x = (pu + go)[lane_off];
+          r[c] = (v2f){x.x, x.y};
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) pr[c] = r[c].x * r[c].x + r[c].y * r[c].y;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v2f sum = {0.f, 0.f};
+          float zt = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (c & (1 << t)) continue;
+            const v2f x = r[c], y = r[c | (1 << t)];
+            // conj(x) * y = (x.x y.x + x.y y.y,  x.x y.y - x.y y.x);  ci below is its negative,
+            // as in k_mw_tile -- only |c|^2 is used
+            sum = __builtin_elementwise_fma(x, y.xx, sum);
+            sum = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, sum);
+            zt += pr[c] - pr[c | (1 << t)];
+          }
+          cri[4 * g + t] += sum;
+          zz[4 * g + t] += zt;
+        }
+        if (g == 0) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) tot += pr[c];
+        }
+      }
+    }
+  }
+  float full[37];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) full[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    full[12 + 3 * k] = cri[k].x;
+    full[12 + 3 * k + 1] = cri[k].y;
+    full[12 + 3 * k + 2] = zz[k];
+  }
+  full[36] = tot;
+  const int lane = tid & (kWave - 1), w = tid / kWave;
+  const float mine = wave_reduce_scatter<37>(full);
+  if (lane < 37) red[w * 37 + lane] = mine;
+  __syncthreads();
+  if (tid < 37) {
+    float v = 0.f;
+    for (int i = 0; i < kMwThreads / kWave; ++i) v += red[i * 37 + tid];
+    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = v;
+  }
+}
+
 // purity of one wire from the per-tile rows: one block per (state, bit)
 __global__ void __launch_bounds__(1024)
 k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_passes, int batch,
+                 int rows_later /* rows per state of the passes after the first */,
                  float *__restrict__ pur_out /* [batch][n] by bit position */) {
   __shared__ double red[16];
   const int b = blockIdx.x, p = blockIdx.y;
@@ -2683,9 +2786,10 @@ k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_pa
     local = kMwL + (p - kMwL) % (kMwT - kMwL);
     if (pass == n_passes - 1 && n > kMwT) local = kMwL + (p - (n - (kMwT - kMwL)));
   }
-  const float *pp = partial + pass * pass_stride + (size_t)b * n_tiles * kMwRow;
+  const int rows = pass == 0 ? n_tiles : rows_later;
+  const float *pp = partial + pass * pass_stride + (size_t)b * rows * kMwRow;
   double cr = 0, ci = 0, z = 0, tot = 0;
-  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
     const float *row = pp + (size_t)i * kMwRow;
     cr += row[3 * local]; ci += row[3 * local + 1]; z += row[3 * local + 2]; tot += row[36];
   }
@@ -4271,6 +4375,14 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
     const uint32_t n_tiles = 1u << (n - kMwT);
     const int tiles = (int)n_tiles;
     const size_t lds = ((size_t)8 << kMwT) + ((size_t)4 << (kMwT - kMwL)) + 160 * sizeof(float);
+    // later passes: register-direct kernel, 2^mw_q tiles per workgroup (>= 2048 workgroups)
+    static const bool no_direct = std::getenv("QMLE_MW_NO_DIRECT") != nullptr;
+    int mw_q = -1;           // blocks of 2^14 amplitudes per workgroup = 2^mw_q; rows = blocks >> mw_q
+    const int blocks = n >= 14 ? 1 << (n - 14) : 0;
+    if (!no_direct && n >= 18) {
+      mw_q = 0;
+      while (mw_q < 3 && (((uint64_t)batch * blocks) >> (mw_q + 1)) >= 2048) ++mw_q;
+    }
     for (int p = 0; p < passes; ++p) {
       MwArgs a;
       std::memset(&a, 0, sizeof(a));
@@ -4287,11 +4399,31 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
         if (mask & (1u << bit)) a.tile_bits[nt++] = (int8_t)bit;
         else a.outer_bits[no++] = (int8_t)bit;
       }
-      hipLaunchKernelGGL(k_mw_tile, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
+      if (p == 0)
+        hipLaunchKernelGGL(k_mw_tile<true>, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
+      else if (mw_q >= 0) {
+        MwDirectArgs da;
+        std::memset(&da, 0, sizeof(da));
+        da.states = a.states;
+        da.partial = a.partial;
+        da.n = n;
+        uint32_t used = 63u;
+        for (int i = 0; i < 8; ++i) {
+          da.hi[i] = a.tile_bits[kMwL + i];
+          used |= 1u << da.hi[i];
+        }
+        int no2 = 0;
+        for (int bit = 6; bit < n; ++bit)
+          if (!(used & (1u << bit))) da.outer[no2++] = (int8_t)bit;
+        hipLaunchKernelGGL(k_mw_direct, dim3(blocks >> mw_q, batch), dim3(kMwThreads), 0, stream, da, mw_q);
+      }
+      else
+        hipLaunchKernelGGL(k_mw_tile<false>, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
     }
     float *d_pur = (float *)d_workspace + (size_t)passes * batch * tiles * kMwRow;
     hipLaunchKernelGGL(k_mw_tile_purity, dim3(batch, n), dim3(tiles >= 1024 ? 1024 : 64), 0,
-                       stream, (const float *)d_workspace, n, tiles, passes, batch, d_pur);
+                       stream, (const float *)d_workspace, n, tiles, passes, batch,
+                       mw_q >= 0 ? blocks >> mw_q : tiles, d_pur);
     hipLaunchKernelGGL(k_mw_tile_q, dim3((batch + 63) / 64), dim3(64), 0, stream,
                        (const float *)d_pur, n, batch, d_out, d_purities);
     HIPCHK(hipGetLastError());
