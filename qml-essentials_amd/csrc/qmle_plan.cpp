@@ -632,8 +632,10 @@ int compile_plan(qmle_plan *p) {
 
   };
 
-  // pass-cost model (microseconds at n = 24, scaled by 2^(n-24); measured on MI355X,
-  // profiles/): HBM round trip of a tile pass ~35, each LDS round trip ~14, direct ~33
+  // pass-cost model (microseconds per state at n = 24; measured on MI355X, dense passes of 1-
+  // and 3-layer HE circuits, tools/stage_profile.py): a tile pass costs ~11 for its HBM round
+  // trip and ~25 per register-tile group (the gate arithmetic is what a pass is made of: 62 us
+  // with 2 groups, 125 with 5, 192 with 7); a direct single-gate pass ~33
   // Known zeros scale both parts: a stage reads 2^-|zero_in| of the state, computes and (when
   // the next stage is a tile stage) stores only the tiles whose outer bits are live.
   const bool sparse_model = !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
@@ -650,7 +652,10 @@ int compile_plan(qmle_plan *p) {
         if (si > 0) rd = std::ldexp(1.0, -__builtin_popcount(st.zero_in));
         if (st.next_tile) wr = tiles;
       }
-      c += 2.0 + 17.5 * (rd + wr) + 14.0 * (st.grp_end - st.grp_begin) * tiles;
+      // + a part that does not shrink with the state (launch, first / last wave): at n = 20 a
+      // pass costs ~1.2 us per state before its first group, a group ~1.35 us
+      c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 6.0 * (rd + wr) +
+           25.0 * (st.grp_end - st.grp_begin) * tiles;
     }
     return c;
   };
