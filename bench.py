@@ -181,7 +181,9 @@ def main():
 
     rank, size = distributed.init_from_env()
     if rank == 0:
-        entry.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):  # stdout carries the ONE JSON line only
+            entry.build()
     distributed.barrier()
     from qml_essentials_amd import _native as N
     from qml_essentials_amd import simulation
