@@ -30,6 +30,8 @@ for trial in range(int(os.environ.get("FUZZ_N", "200"))):
     ops, angles, consts = tape_to_native(tape, n)
     T = int(rng.integers(10, 14)) if layered else int(rng.integers(6, 14)); T = min(T, n - 1)
     L = int(rng.integers(1, min(T, 8)))
+    if rng.random() < 0.25:  # the plan compiler's own choice of tile geometry
+        T = L = 0
     B = int(rng.integers(1, 4))
     if layered and rng.random() < 0.3:  # enough states per launch for the streaming product kernel
         B = int(rng.integers(24, 72))
