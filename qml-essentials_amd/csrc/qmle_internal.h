@@ -73,6 +73,35 @@ struct BuildGroup {
   uint32_t dim;  // 2 or 4
 };
 
+// ---- fast tile path (k_tile2) ---------------------------------------------------------------
+// A register-tile group whose LDS addressing is a host-built table: thread t gathers its 16
+// amplitudes from byte addresses tbl[t] ^ off[c] (XOR-swizzle and the x8 already folded in).
+// Basis permutations (X, CX: GF(2)-affine index maps) between groups never move data: they
+// change the logical -> physical layout map the tables are built from.  `relayout` groups
+// scatter to the identity layout (tbl2 / off2) behind an extra barrier: the last group of a
+// stage does, so that the store / measure epilogue indexes the tile plainly.
+// Ops of a group carry group-local bits (t0, c0 in 0..3) and a dispatch code in `pad`.
+enum FastCode : uint8_t {
+  FC_DENSE = 0,     // + tb                      dense 2x2 on bit tb
+  FC_CDENSE = 4,    // + 3 * cb + (tb - (tb>cb)) controlled dense 2x2
+  FC_DIAG = 16,     // + tb
+  FC_CDIAG = 20,    // + 3 * cb + ..
+  FC_X = 32,        // + tb                      in-register Pauli-X (pairs swapped)
+  FC_CX = 36,       // + 3 * cb + ..             in-register CX
+  FC_COUNT = 48
+};
+struct Group2 {
+  uint32_t op_begin;   // first op in qmle_plan::ops2
+  uint16_t n_ops;
+  uint8_t relayout;
+  uint8_t pad;
+  uint32_t tbl;        // index into qmle_plan::tbl2 (one uint32 per thread of the workgroup)
+  uint32_t tbl_out;    // relayout: scatter table
+  uint32_t off[16];
+  uint32_t off_out[16];
+};
+static_assert(sizeof(Group2) == 144, "Group2 layout");
+
 enum StageKind : int { ST_DIRECT = 0, ST_TILE = 1, ST_DIAG_ALL = 2 };
 
 struct Stage {
@@ -97,6 +126,9 @@ struct Stage {
   // output tile is in[live bits] x prod_g (U_g e_0)[group bits] -- k_tile_product writes it
   // from the groups' first columns without staging amplitudes or running gates per tile.
   bool product_ok = false;
+  // fast tile path: every gate is a (<= 1 control) 2x2 and T is in k_tile2's range
+  bool fast_ok = false;
+  int fast_begin = 0, fast_end = 0;  // range in qmle_plan::groups2
 };
 
 struct StageProfile {  // optional HIP-event timing of every stage launch (bench.py)
@@ -114,6 +146,9 @@ struct DevicePlan {  // lazily created by the first run on a device
   BuildOp *d_build = nullptr;
   BuildGroup *d_groups = nullptr;
   float *d_consts = nullptr;
+  LoweredOp *d_ops2 = nullptr;   // fast tile path
+  Group2 *d_groups2 = nullptr;
+  uint32_t *d_tbl2 = nullptr;
 };
 
 }  // namespace qmle
@@ -128,6 +163,9 @@ struct qmle_plan {
   std::vector<qmle::LoweredOp> dev_ops;   // per stage, stage-local positions
   std::vector<int> dev_src;               // source op of every dev_op (-1 if merged from several)
   std::vector<qmle::OpGroup> op_groups;   // register-tile groups of the tile stages
+  std::vector<qmle::LoweredOp> ops2;      // fast tile path: ops of the Group2 groups
+  std::vector<qmle::Group2> groups2;
+  std::vector<uint32_t> tbl2;             // per-thread LDS byte addresses of the Group2 groups
   std::vector<qmle::BuildOp> build_ops;
   std::vector<qmle::BuildGroup> groups;
   std::vector<qmle::Stage> stages;
@@ -168,6 +206,7 @@ std::string describe_plan(const qmle_plan *p);
 // into columns), 3 k_reg_measure_mono.  `sparse`: known-zero tracking is on for the run.
 int expval_kernel_of(const qmle_plan *p, size_t si, bool sparse);
 double algo_bytes(const qmle_op &op, int n);
+constexpr int kFastMinT = 10, kFastMaxT = 13;  // k_tile2: 2^(T-4) threads, 8 float4 per thread
 constexpr int kLdsMaxQubits = 14;       // 2^14 * 8 B = 128 KiB <= 160 KiB LDS/CU
 constexpr int kDefaultTileBits = 13;    // 64 KiB tile -> 2 workgroups per CU
 constexpr int kDefaultLowBits = 7;      // 128 amplitudes = 1 KiB contiguous per wave load

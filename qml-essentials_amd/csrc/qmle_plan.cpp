@@ -205,6 +205,210 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
   st.grp_end = (int)p->op_groups.size();
 }
 
+// ---- fast tile path: perm-fused register-tile groups (Group2) --------------------------------
+// `src`: the stage's ops in a valid execution order, TILE-local bit positions.  Greedy like
+// group_stage_ops, except that X / CX never cost a group of their own:
+//   * one that touches no bit of the group being formed (and no blocked bit) is applied to the
+//     layout map at once -- the group's gather table already sees it;
+//   * one at the END of a group's op list is peeled off and applied to the layout map after the
+//     group (its scatter stays in place);
+//   * only an X / CX sandwiched between the group's dense gates runs in registers (8 moves).
+// Layout map: logical tile index e lives at physical slot L(e) = XOR_{j in e} Lcol[j] ^ Lconst.
+static inline uint32_t swz(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }  // = sw() in qmle_sv.hip
+
+static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<LoweredOp> &src) {
+  st.fast_ok = false;
+  st.fast_begin = st.fast_end = (int)p->groups2.size();
+  const int T = st.T;
+  if (T < kFastMinT || T > kFastMaxT || (p->flags & QMLE_PLAN_NO_REGTILE)) return;
+  for (const LoweredOp &o : src)
+    if (o.kind != LK_1Q || o.nc > 1) return;
+  const int nops = (int)src.size();
+  const uint32_t nt = 1u << (T - 4);
+  const size_t ops2_mark = p->ops2.size(), tbl_mark = p->tbl2.size();
+  uint32_t Lcol[16], Lconst = 0;
+  for (int j = 0; j < T; ++j) Lcol[j] = 1u << j;
+  auto L_of = [&](uint32_t e) {
+    uint32_t v = Lconst;
+    for (int j = 0; j < T; ++j)
+      if (e & (1u << j)) v ^= Lcol[j];
+    return v;
+  };
+  auto L_is_identity = [&]() {
+    if (Lconst) return false;
+    for (int j = 0; j < T; ++j)
+      if (Lcol[j] != (1u << j)) return false;
+    return true;
+  };
+  // M: logical index in the frame of the last emitted group -> logical index now
+  uint32_t Mcol[16], Mconst = 0;
+  auto M_reset = [&]() { for (int j = 0; j < T; ++j) Mcol[j] = 1u << j; Mconst = 0; };
+  M_reset();
+  auto is_perm = [](const LoweredOp &o) { return (o.flags & LF_PERMX) != 0; };
+  auto apply_perm = [&](const LoweredOp &o) {
+    const int t = o.t0;
+    if (o.nc == 0) {
+      Lconst ^= Lcol[t];
+      Mconst ^= 1u << t;
+    } else {
+      const int c = o.c0;
+      Lcol[c] ^= Lcol[t];
+      for (int j = 0; j < T; ++j) Mcol[j] ^= ((Mcol[j] >> c) & 1u) << t;
+      Mconst ^= ((Mconst >> c) & 1u) << t;
+    }
+  };
+  auto mask_of = [](const LoweredOp &o) {
+    uint32_t m = 1u << o.t0;
+    if (o.c0 >= 0) m |= 1u << o.c0;
+    return m;
+  };
+  auto deposit = [&](uint32_t t, uint32_t G) {  // bits of t into the positions outside G
+    uint32_t e = 0;
+    int k = 0;
+    for (int j = 0; j < T; ++j)
+      if (!(G & (1u << j))) e |= ((t >> k++) & 1u) << j;
+    return e;
+  };
+  auto emit_tables = [&](Group2 &g, uint32_t G) {
+    int gb[4], k = 0;
+    for (int j = 0; j < T; ++j)
+      if (G & (1u << j)) gb[k++] = j;
+    g.tbl = (uint32_t)p->tbl2.size();
+    for (uint32_t t = 0; t < nt; ++t) p->tbl2.push_back(swz(L_of(deposit(t, G))) << 3);
+    for (int c = 0; c < 16; ++c) {
+      uint32_t v = 0;
+      for (int j = 0; j < 4; ++j)
+        if (c & (1 << j)) v ^= Lcol[gb[j]];
+      g.off[c] = swz(v) << 3;
+    }
+  };
+  std::vector<char> done(nops, 0);
+  int n_done = 0;
+  int last_group = -1;
+  uint32_t last_G = 0;
+  while (n_done < nops) {
+    uint32_t G = 0, touched = 0, blocked = 0;
+    std::vector<int> mem, after;  // `after`: X / CX applied to the layout behind the group
+    for (int i = 0; i < nops; ++i) {
+      if (done[i]) continue;
+      const uint32_t m = mask_of(src[i]);
+      if (m & blocked) { blocked |= m; continue; }
+      if (is_perm(src[i])) {
+        if (!(m & touched)) {  // independent of the group: layout only, before the group
+          apply_perm(src[i]);
+          done[i] = 1;
+          ++n_done;
+        } else if ((m & ~G) == 0 && mem.size() < 4000) {
+          mem.push_back(i);  // inside the group's bits: stays in registers unless peeled below
+        } else {             // would cost the group a bit position: behind the group instead
+          after.push_back(i);
+          blocked |= m;
+        }
+        continue;
+      }
+      if (__builtin_popcount(G | m) <= 4 && mem.size() < 4000) {
+        G |= m;
+        touched |= m;
+        mem.push_back(i);
+      } else {
+        blocked |= m;
+      }
+    }
+    if (mem.empty()) continue;  // only layout changes were left (`after` needs a member: empty too)
+    {  // an X / CX that commutes with every later member of the group leaves it for the layout
+      uint32_t later = 0;
+      std::vector<int> keep;
+      for (size_t k = mem.size(); k-- > 0;) {
+        const int i = mem[k];
+        const uint32_t m = mask_of(src[i]);
+        if (is_perm(src[i]) && !(m & later)) {
+          after.push_back(i);
+        } else {
+          later |= m;
+          keep.insert(keep.begin(), i);
+        }
+      }
+      mem.swap(keep);
+      std::sort(after.begin(), after.end());
+    }
+    const std::vector<int> &trailing = after;
+    G = 0;
+    for (int i : mem) G |= mask_of(src[i]);
+    for (int b = 5; b < T && __builtin_popcount(G) < 4; ++b) G |= 1u << b;
+    for (int b = 0; b < T && __builtin_popcount(G) < 4; ++b) G |= 1u << b;
+    int8_t local_of[16];
+    {
+      int k = 0;
+      for (int b = 0; b < T; ++b) local_of[b] = (G & (1u << b)) ? (int8_t)k++ : (int8_t)-1;
+    }
+    Group2 g;
+    std::memset(&g, 0, sizeof(g));
+    g.op_begin = (uint32_t)p->ops2.size();
+    g.n_ops = (uint16_t)mem.size();
+    emit_tables(g, G);
+    for (int i : mem) {
+      LoweredOp o = src[i];
+      o.t0 = local_of[(int)o.t0];
+      if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
+      const int base = is_perm(o) ? (o.nc ? FC_CX : FC_X)
+                       : (o.flags & LF_DIAG) ? (o.nc ? FC_CDIAG : FC_DIAG)
+                                             : (o.nc ? FC_CDENSE : FC_DENSE);
+      o.pad = (uint8_t)(base + (o.nc ? 3 * o.c0 + (o.t0 - (o.t0 > o.c0 ? 1 : 0)) : o.t0));
+      p->ops2.push_back(o);
+      done[i] = 1;
+      ++n_done;
+    }
+    M_reset();
+    for (int i : trailing) {
+      apply_perm(src[i]);
+      done[i] = 1;
+      ++n_done;
+    }
+    last_group = (int)p->groups2.size();
+    last_G = G;
+    p->groups2.push_back(g);
+  }
+  // the epilogue (store / measure) reads the tile in the identity layout
+  if (!L_is_identity() || last_group < 0) {
+    uint32_t G = last_G;
+    if (last_group < 0) {  // nothing but layout changes (or no gate at all): an empty group moves the data
+      Group2 g;
+      std::memset(&g, 0, sizeof(g));
+      g.op_begin = (uint32_t)p->ops2.size();
+      G = 0xFu << (T >= 9 ? 5 : 0);
+      emit_tables(g, G);
+      M_reset();
+      last_group = (int)p->groups2.size();
+      p->groups2.push_back(g);
+    }
+    Group2 &g = p->groups2[last_group];
+    if (!L_is_identity()) {
+      // a thread holds logical index e of the group's frame; its final logical index is M(e)
+      int gb[4], k = 0;
+      for (int j = 0; j < T; ++j)
+        if (G & (1u << j)) gb[k++] = j;
+      auto M_lin = [&](uint32_t e) {
+        uint32_t v = 0;
+        for (int j = 0; j < T; ++j)
+          if (e & (1u << j)) v ^= Mcol[j];
+        return v;
+      };
+      g.relayout = 1;
+      g.tbl_out = (uint32_t)p->tbl2.size();
+      for (uint32_t t = 0; t < nt; ++t) p->tbl2.push_back(swz(M_lin(deposit(t, G)) ^ Mconst) << 3);
+      for (int c = 0; c < 16; ++c) {
+        uint32_t e = 0;
+        for (int j = 0; j < 4; ++j)
+          if (c & (1 << j)) e |= 1u << gb[j];
+        g.off_out[c] = swz(M_lin(e)) << 3;
+      }
+    }
+  }
+  (void)ops2_mark; (void)tbl_mark;
+  st.fast_end = (int)p->groups2.size();
+  st.fast_ok = true;
+}
+
 // ---- observable absorption ---------------------------------------------------------------
 // Going backwards through the tape, a gate is absorbed iff it is a basis permutation with a
 // LINEAR index map (CX, SWAP), a diagonal gate (phases drop out of |amplitude|^2) or the
@@ -476,6 +680,9 @@ int compile_plan(qmle_plan *p) {
     p->dev_ops.clear();
     p->dev_src.clear();
     p->op_groups.clear();
+    p->ops2.clear();
+    p->groups2.clear();
+    p->tbl2.clear();
     p->consts.resize(n_user_consts);  // drop permuted-matrix copies of a previous candidate
     const size_t nl = p->lowered.size();
     std::vector<char> done(nl, 0);
@@ -575,7 +782,12 @@ int compile_plan(qmle_plan *p) {
       }
       st.op_end = (int)p->dev_ops.size();
       st.n_tile_ops = st.op_end - st.op_begin;
-      if (st.kind == ST_TILE) group_stage_ops(p, st);
+      if (st.kind == ST_TILE) {
+        const std::vector<LoweredOp> tile_local(p->dev_ops.begin() + st.op_begin,
+                                                p->dev_ops.begin() + st.op_end);
+        build_fast_groups(p, st, tile_local);
+        group_stage_ops(p, st);
+      }
       for (int mi : members) {
         done[mi] = 1;
         ++n_done;
@@ -746,6 +958,10 @@ std::string describe_plan(const qmle_plan *p) {
          << (int)og.n_ops << ",\"bits\":[" << (int)og.bits[0] << "," << (int)og.bits[1] << ","
          << (int)og.bits[2] << "," << (int)og.bits[3] << "]}";
     }
+    os << "],\"fast\":" << (st.fast_ok ? "true" : "false") << ",\"fast_groups\":[";
+    for (int g = st.fast_begin; g < st.fast_end; ++g)
+      os << (g > st.fast_begin ? "," : "") << "{\"n_ops\":" << p->groups2[g].n_ops
+         << ",\"relayout\":" << (int)p->groups2[g].relayout << "}";
     os << "],\"src_ops\":[";
     for (size_t i = 0; i < st.src_ops.size(); ++i) os << (i ? "," : "") << st.src_ops[i];
     os << "]}";

@@ -944,6 +944,289 @@ __global__ void k_tile(const TileArgs a) {
   tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
 }
 
+// ---- fast tile kernel (k_tile2) --------------------------------------------------------------
+// Dense tile pass for stages whose gates are all (<= 1 control) 2x2 (Stage::fast_ok):
+//   * the groups' LDS addresses come from host-built tables (Group2): X / CX between groups are
+//     GF(2)-affine index maps folded into those tables and cost nothing (qmle_plan.cpp);
+//   * gate matrices are read into SGPRs with scalar loads straight from the per-sample matrix
+//     row (no LDS staging, no v_readfirstlane), and a gate on 16 amplitudes is 64 packed-fp32
+//     instructions written in asm: 4 independent dependency chains interleaved, so the packed
+//     pipe never waits on its own result (hipcc serialises each chain behind s_nop);
+//   * no lookup table in LDS: the 8 float4 of a lane differ in wave-uniform high bits only, so
+//     a tile of 2^12 amplitudes needs exactly 32 KiB -> 5 workgroups per CU.
+typedef unsigned long long u64;
+
+// (b0, b1) = M (a0, a1) for two amplitude pairs under the same 2x2 matrix; complex products as
+// 2 packed instructions each: (m.x, m.x) * (a.x, a.y), then (-m.y, m.y) * (a.y, a.x) + ...
+#define QMLE_PAIR2(a0, a1, a2, a3)                                                               \
+  asm volatile(                                                                                  \
+      "v_pk_mul_f32 %4, %8, %0 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_mul_f32 %5, %10, %0 op_sel_hi:[0,1]\n\t"                                             \
+      "v_pk_mul_f32 %6, %8, %2 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_mul_f32 %7, %10, %2 op_sel_hi:[0,1]\n\t"                                             \
+      "v_pk_fma_f32 %4, %8, %0, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %5, %10, %0, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %6, %8, %2, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %7, %10, %2, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %4, %9, %1, %4 op_sel_hi:[0,1,1]\n\t"                                        \
+      "v_pk_fma_f32 %5, %11, %1, %5 op_sel_hi:[0,1,1]\n\t"                                       \
+      "v_pk_fma_f32 %6, %9, %3, %6 op_sel_hi:[0,1,1]\n\t"                                        \
+      "v_pk_fma_f32 %7, %11, %3, %7 op_sel_hi:[0,1,1]\n\t"                                       \
+      "v_pk_fma_f32 %0, %9, %1, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %1, %11, %1, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %2, %9, %3, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %3, %11, %3, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)       \
+      : "s"(m00), "s"(m01), "s"(m10), "s"(m11))
+// four amplitudes times the same complex number
+#define QMLE_CMUL4(a0, a1, a2, a3, m)                                                            \
+  asm volatile(                                                                                  \
+      "v_pk_mul_f32 %4, %8, %0 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_mul_f32 %5, %8, %1 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_mul_f32 %6, %8, %2 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_mul_f32 %7, %8, %3 op_sel_hi:[0,1]\n\t"                                              \
+      "v_pk_fma_f32 %0, %8, %0, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %1, %8, %1, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %2, %8, %2, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      "v_pk_fma_f32 %3, %8, %3, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"          \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)       \
+      : "s"(m))
+
+struct Mat2S {  // a 2x2 complex matrix as four (re, im) SGPR pairs
+  u64 m00, m01, m10, m11;
+};
+
+template <int TB>
+__device__ __forceinline__ void f_dense(u64 (&a)[16], const Mat2S &M) {
+  const u64 m00 = M.m00, m01 = M.m01, m10 = M.m10, m11 = M.m11;
+  u64 t0, t1, t2, t3;
+  constexpr int S = 1 << TB;
+  constexpr int lo = S - 1;
+  // pair q (0..7): c = q with a zero inserted at bit TB
+#define QMLE_IDX(q) ((((q) & ~lo) << 1) | ((q) & lo))
+  QMLE_PAIR2(a[QMLE_IDX(0)], a[QMLE_IDX(0) | S], a[QMLE_IDX(1)], a[QMLE_IDX(1) | S]);
+  QMLE_PAIR2(a[QMLE_IDX(2)], a[QMLE_IDX(2) | S], a[QMLE_IDX(3)], a[QMLE_IDX(3) | S]);
+  QMLE_PAIR2(a[QMLE_IDX(4)], a[QMLE_IDX(4) | S], a[QMLE_IDX(5)], a[QMLE_IDX(5) | S]);
+  QMLE_PAIR2(a[QMLE_IDX(6)], a[QMLE_IDX(6) | S], a[QMLE_IDX(7)], a[QMLE_IDX(7) | S]);
+#undef QMLE_IDX
+}
+// index r (0..3) deposited into the two bits that are neither CB nor TB, control bit set
+template <int CB, int TB>
+__device__ __forceinline__ constexpr int ctl_idx(int r) {
+  int c = 0, k = 0;
+  for (int j = 0; j < 4; ++j) {
+    if (j == CB) c |= 1 << j;
+    else if (j != TB) c |= ((r >> k++) & 1) << j;
+  }
+  return c;
+}
+template <int CB, int TB>
+__device__ __forceinline__ void f_cdense(u64 (&a)[16], const Mat2S &M) {
+  const u64 m00 = M.m00, m01 = M.m01, m10 = M.m10, m11 = M.m11;
+  u64 t0, t1, t2, t3;
+  constexpr int S = 1 << TB;
+  constexpr int i0 = ctl_idx<CB, TB>(0), i1 = ctl_idx<CB, TB>(1), i2 = ctl_idx<CB, TB>(2),
+                i3 = ctl_idx<CB, TB>(3);
+  QMLE_PAIR2(a[i0], a[i0 | S], a[i1], a[i1 | S]);
+  QMLE_PAIR2(a[i2], a[i2 | S], a[i3], a[i3 | S]);
+}
+template <int TB>
+__device__ __forceinline__ void f_diag(u64 (&a)[16], const Mat2S &M) {
+  const u64 m00 = M.m00, m11 = M.m11;
+  u64 t0, t1, t2, t3;
+  constexpr int S = 1 << TB;
+  constexpr int lo = S - 1;
+#define QMLE_IDX(q) ((((q) & ~lo) << 1) | ((q) & lo))
+  QMLE_CMUL4(a[QMLE_IDX(0)], a[QMLE_IDX(1)], a[QMLE_IDX(2)], a[QMLE_IDX(3)], m00);
+  QMLE_CMUL4(a[QMLE_IDX(4)], a[QMLE_IDX(5)], a[QMLE_IDX(6)], a[QMLE_IDX(7)], m00);
+  QMLE_CMUL4(a[QMLE_IDX(0) | S], a[QMLE_IDX(1) | S], a[QMLE_IDX(2) | S], a[QMLE_IDX(3) | S], m11);
+  QMLE_CMUL4(a[QMLE_IDX(4) | S], a[QMLE_IDX(5) | S], a[QMLE_IDX(6) | S], a[QMLE_IDX(7) | S], m11);
+#undef QMLE_IDX
+}
+template <int CB, int TB>
+__device__ __forceinline__ void f_cdiag(u64 (&a)[16], const Mat2S &M) {
+  const u64 m00 = M.m00, m11 = M.m11;
+  u64 t0, t1, t2, t3;
+  constexpr int S = 1 << TB;
+  constexpr int i0 = ctl_idx<CB, TB>(0), i1 = ctl_idx<CB, TB>(1), i2 = ctl_idx<CB, TB>(2),
+                i3 = ctl_idx<CB, TB>(3);
+  QMLE_CMUL4(a[i0], a[i1], a[i2], a[i3], m00);
+  QMLE_CMUL4(a[i0 | S], a[i1 | S], a[i2 | S], a[i3 | S], m11);
+}
+template <int TB>
+__device__ __forceinline__ void f_x(u64 (&a)[16]) {
+  constexpr int S = 1 << TB;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (!(c & S)) { const u64 t = a[c]; a[c] = a[c | S]; a[c | S] = t; }
+}
+template <int CB, int TB>
+__device__ __forceinline__ void f_cx(u64 (&a)[16]) {
+  constexpr int S = 1 << TB;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = ctl_idx<CB, TB>(r);
+    const u64 t = a[c]; a[c] = a[c | S]; a[c | S] = t;
+  }
+}
+
+// one op of a Group2 on the 16 amplitudes a thread holds; `code` is wave-uniform (FastCode)
+__device__ __forceinline__ void fast_dispatch(u64 (&a)[16], int code, const Mat2S &M) {
+#define QMLE_C12(F, base, ...)                                                                   \
+  case base + 0: F<0, 1>(__VA_ARGS__); break; case base + 1: F<0, 2>(__VA_ARGS__); break;        \
+  case base + 2: F<0, 3>(__VA_ARGS__); break; case base + 3: F<1, 0>(__VA_ARGS__); break;        \
+  case base + 4: F<1, 2>(__VA_ARGS__); break; case base + 5: F<1, 3>(__VA_ARGS__); break;        \
+  case base + 6: F<2, 0>(__VA_ARGS__); break; case base + 7: F<2, 1>(__VA_ARGS__); break;        \
+  case base + 8: F<2, 3>(__VA_ARGS__); break; case base + 9: F<3, 0>(__VA_ARGS__); break;        \
+  case base + 10: F<3, 1>(__VA_ARGS__); break; case base + 11: F<3, 2>(__VA_ARGS__); break;
+  switch (code) {
+    case FC_DENSE + 0: f_dense<0>(a, M); break;
+    case FC_DENSE + 1: f_dense<1>(a, M); break;
+    case FC_DENSE + 2: f_dense<2>(a, M); break;
+    case FC_DENSE + 3: f_dense<3>(a, M); break;
+    QMLE_C12(f_cdense, FC_CDENSE, a, M)
+    case FC_DIAG + 0: f_diag<0>(a, M); break;
+    case FC_DIAG + 1: f_diag<1>(a, M); break;
+    case FC_DIAG + 2: f_diag<2>(a, M); break;
+    case FC_DIAG + 3: f_diag<3>(a, M); break;
+    QMLE_C12(f_cdiag, FC_CDIAG, a, M)
+    case FC_X + 0: f_x<0>(a); break;
+    case FC_X + 1: f_x<1>(a); break;
+    case FC_X + 2: f_x<2>(a); break;
+    case FC_X + 3: f_x<3>(a); break;
+    QMLE_C12(f_cx, FC_CX, a)
+    default: break;
+  }
+#undef QMLE_C12
+}
+
+// Plan data and per-sample matrices are written before the launch and never during it: reading
+// them through the constant address space lets wave-uniform accesses compile to scalar loads
+// (s_load_dwordx4/x8/x16 into SGPRs) instead of vector loads + v_readfirstlane.
+#define QMLE_CONSTANT __attribute__((address_space(4)))
+template <class X>
+__device__ __forceinline__ const X QMLE_CONSTANT *as_constant(const X *p) {
+  return (const X QMLE_CONSTANT *)(uintptr_t)p;
+}
+
+struct Tile2Args {
+  const Group2 *groups;     // this stage's Group2 range
+  const LoweredOp *ops;     // qmle_plan::ops2 on the device
+  const uint32_t *tbl;      // qmle_plan::tbl2 on the device
+  int n_groups;
+};
+
+template <bool NT>
+__global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
+  extern __shared__ float4 smem4[];
+  float2 *s = reinterpret_cast<float2 *>(smem4);
+  char *sb = reinterpret_cast<char *>(smem4);
+  const int T = a.T;
+  float *red = reinterpret_cast<float *>(s + (1u << T));
+  const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
+  const int b = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
+  const size_t D = (size_t)1 << a.n;
+  const uint64_t base = tile_base(a, tile);
+  float2 *st = a.states + (size_t)b * D + base;
+  // a lane's 8 float4: local index j = 2 (tid + u nt): bit 0 rides in the access, bits 1..T-4
+  // come from tid, the top three from u (wave-uniform)
+  const uint32_t jl = 2u * tid;
+  uint32_t goff = jl & ((1u << a.L) - 1u);
+  for (int p = a.L; p <= T - 4; ++p) goff |= ((jl >> p) & 1u) << a.tile_bits[p];
+  uint32_t uoff[8], soff[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    uoff[u] = ((u & 1u) << a.tile_bits[T - 3]) | (((u >> 1) & 1u) << a.tile_bits[T - 2]) |
+              (((u >> 2) & 1u) << a.tile_bits[T - 1]);
+    soff[u] = sw((uint32_t)u << (T - 3)) >> 1;  // float4 index; sw() is linear over XOR
+  }
+  const uint32_t sl = sw(jl) >> 1;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.init_zero && base != 0) {
+    // |0..0> lives in tile 0 alone and gates are linear: every other tile stays exactly zero
+    if (a.meas == TM_STORE) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + (goff | uoff[u])), z4);
+    } else if (a.meas == TM_PROBS) {
+      float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D + base;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<float2 *>(po + (goff | uoff[u])) = make_float2(0.f, 0.f);
+    } else {
+      float *po = reinterpret_cast<float *>(a.out) +
+                  ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
+      if (tid <= QMLE_MAX_QUBITS) po[tid] = 0.f;
+    }
+    return;
+  }
+  const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
+  uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
+  if (a.init_zero) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = z4;
+    __syncthreads();
+    if (tid == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+  } else {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + (goff | uoff[u])));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = v[u];
+  }
+  __syncthreads();
+
+  const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
+  for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
+    u64 r[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+    // scalar loads are dword-wide: header fields are unpacked from whole words
+    const uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
+    const int n_ops = (int)(hdr & 0xffffu);
+    const bool relayout = ((hdr >> 16) & 0xffu) != 0;
+    uint32_t addr_next = 0;
+    if (relayout) addr_next = f.tbl[grp->tbl_out + tid];
+    else if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
+    for (int k = 0; k < n_ops; ++k) {
+      const v4u w = op[k];  // LoweredOp: .y >> 24 = dispatch code, .z = matrix offset (floats)
+      const u64 QMLE_CONSTANT *m = mrow + (w.z >> 1);
+      const Mat2S M = {m[0], m[1], m[2], m[3]};
+      fast_dispatch(r, (int)(w.y >> 24), M);
+    }
+    if (relayout) {
+      __syncthreads();  // every gather of the group is done: slots may change owners
+#pragma unroll
+      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr_next ^ grp->off_out[c])) = r[c];
+      if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ grp->off[c])) = r[c];
+    }
+    addr = addr_next;
+    __syncthreads();
+  }
+
+  if (a.meas == TM_STORE) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + (goff | uoff[u])), v[u]);
+  } else if (a.meas == TM_PROBS) {
+    float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D + base;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 v = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
+      *reinterpret_cast<float2 *>(po + (goff | uoff[u])) =
+          make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+    }
+  } else {
+    tile_epilogue<false>(a, s, nullptr, red, tile, gridDim.x, b, base);
+  }
+}
+
 // ---- measuring pass in registers -----------------------------------------------------------
 // Last pass of a <Z> / Z-parity run whose gates all sit on <= 4 bit positions (ONE register-tile
 // group): nothing is staged through LDS.  Every work item loads its 16 amplitudes straight from
@@ -2900,7 +3183,10 @@ int ensure_device_plan(qmle_plan *p) {
   const size_t b_groups = align_up(p->groups.size() * sizeof(BuildGroup) + 16, 256);
   const size_t b_consts = align_up(p->consts.size() * sizeof(float) + 16, 256);
   const size_t b_opg = align_up(p->op_groups.size() * sizeof(OpGroup) + 16, 256);
-  const size_t total = b_ops + b_build + b_groups + b_consts + b_opg;
+  const size_t b_ops2 = align_up(p->ops2.size() * sizeof(LoweredOp) + 16, 256);
+  const size_t b_grp2 = align_up(p->groups2.size() * sizeof(Group2) + 16, 256);
+  const size_t b_tbl2 = align_up(p->tbl2.size() * sizeof(uint32_t) + 16, 256);
+  const size_t total = b_ops + b_build + b_groups + b_consts + b_opg + b_ops2 + b_grp2 + b_tbl2;
   char *blob = nullptr;
   HIPCHK(hipMalloc((void **)&blob, total));
   p->dev.blob = blob;
@@ -2910,6 +3196,19 @@ int ensure_device_plan(qmle_plan *p) {
   p->dev.d_groups = (BuildGroup *)(blob + b_ops + b_build);
   p->dev.d_consts = (float *)(blob + b_ops + b_build + b_groups);
   p->dev.d_op_groups = (OpGroup *)(blob + b_ops + b_build + b_groups + b_consts);
+  char *fast = blob + b_ops + b_build + b_groups + b_consts + b_opg;
+  p->dev.d_ops2 = (LoweredOp *)fast;
+  p->dev.d_groups2 = (Group2 *)(fast + b_ops2);
+  p->dev.d_tbl2 = (uint32_t *)(fast + b_ops2 + b_grp2);
+  if (!p->ops2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_ops2, p->ops2.data(), p->ops2.size() * sizeof(LoweredOp),
+                     hipMemcpyHostToDevice));
+  if (!p->groups2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_groups2, p->groups2.data(), p->groups2.size() * sizeof(Group2),
+                     hipMemcpyHostToDevice));
+  if (!p->tbl2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_tbl2, p->tbl2.data(), p->tbl2.size() * sizeof(uint32_t),
+                     hipMemcpyHostToDevice));
   if (!p->op_groups.empty())
     HIPCHK(hipMemcpy(p->dev.d_op_groups, p->op_groups.data(),
                      p->op_groups.size() * sizeof(OpGroup), hipMemcpyHostToDevice));
@@ -3117,6 +3416,31 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     while (tpw < 8 && (uint64_t)(n_tiles / (2 * tpw)) * batch >= 2048) tpw *= 2;
     grid.x = (n_tiles + tpw - 1) / tpw;
     hipLaunchKernelGGL(k_tile_product, grid, dim3(threads), lds_p, stream, a, cols, tpw, n_tiles);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
+  // fast path: all-live stage of (controlled) 2x2 gates -- table-addressed groups, CX folded
+  // into the LDS layout, SGPR matrices (k_tile2)
+  static const bool no_fast = std::getenv("QMLE_NO_FAST_TILE") != nullptr;
+  if (!no_fast && st.fast_ok && !a.compact && !a.zin_local && !a.zin_outer && st.T < p->n &&
+      threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
+    static bool attr2 = false;
+    if (!attr2) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr2 = true;
+    }
+    Tile2Args f;
+    f.groups = p->dev.d_groups2 + st.fast_begin;
+    f.ops = p->dev.d_ops2;
+    f.tbl = p->dev.d_tbl2;
+    f.n_groups = st.fast_end - st.fast_begin;
+    const size_t lds2 = ((size_t)8 << st.T) +
+                        (meas == TM_STORE || meas == TM_PROBS ? 0 : 288 * sizeof(float));
+    if (a.nt) hipLaunchKernelGGL(k_tile2<true>, grid, dim3(threads), lds2, stream, a, f);
+    else hipLaunchKernelGGL(k_tile2<false>, grid, dim3(threads), lds2, stream, a, f);
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }

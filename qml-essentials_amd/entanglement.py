@@ -49,10 +49,7 @@ class Entanglement:
         kwargs.pop("execution_type", None)
         params = np.asarray(model.params)
         total = params.shape[0]
-        lo, hi = 0, total
-        sharded = distributed.enabled() and total >= distributed.world()[1]
-        if sharded:
-            lo, hi = distributed.shard_bounds(total)
+        lo, hi, sharded = distributed.my_block(total)
         with distributed.local_only():
             states = model._forward(params=params[lo:hi], execution_type="state",
                                     as_tensor=True, **kwargs)

@@ -31,10 +31,7 @@ class Expressibility:
         n_samples = int(n_samples)
         model.initialize_params(random_key, repeat=n_samples * 2)
         params = np.asarray(model.params)
-        lo, hi = 0, n_samples
-        sharded = distributed.enabled() and n_samples >= distributed.world()[1]
-        if sharded:
-            lo, hi = distributed.shard_bounds(n_samples)
+        lo, hi, sharded = distributed.my_block(n_samples)
         local = np.concatenate([params[lo:hi], params[n_samples + lo: n_samples + hi]])
         kwargs.pop("execution_type", None)
         with distributed.local_only():
