@@ -38,8 +38,12 @@ void svc_set_threads(int n) {
 }
 
 void svc_init_zero(c64 *psi, int n) {
+  /* first touch in parallel with the same static partition the gate loops use, so that on a
+     multi-socket host every thread's share of the state lands on its own NUMA node (a
+     single-threaded memset put all pages on one node: ~31 GB/s on a 128-thread box) */
   const size_t D = (size_t)1 << n;
-  memset(psi, 0, D * sizeof(c64));
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < D; ++i) psi[i] = 0.0f;
   psi[0] = 1.0f;
 }
 
