@@ -866,6 +866,13 @@ int compile_plan(qmle_plan *p) {
       }
       // + a part that does not shrink with the state (launch, first / last wave): at n = 20 a
       // pass costs ~1.2 us per state before its first group, a group ~1.35 us
+      if (st.fast_ok && !(sparse_model && st.zero_in)) {
+        // all-live stage on the fast kernel (k_tile2; MI355X, round 2): ~47 us for the HBM round
+        // trip with one group hidden behind it, ~9 per further group (51 with 2, 106 with 9)
+        c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 18.0 * (rd + wr) +
+             9.0 * ((st.fast_end - st.fast_begin) - 0.5);
+        continue;
+      }
       c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 6.0 * (rd + wr) +
            25.0 * (st.grp_end - st.grp_begin) * tiles;
     }

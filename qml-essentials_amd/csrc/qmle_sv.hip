@@ -120,6 +120,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
   return v;
 }
+// Wave sum on the DPP data path (no LDS crossbar): quad swaps, half-row / row mirrors, then the
+// row broadcasts; the total lands in lane 63.  One v_add_f32_dpp per step -- six per value, and
+// independent values interleave freely.
+__device__ __forceinline__ float wave_sum_dpp63(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+  return v;
+}
 // Sum over the block; result valid in thread 0.  `red` holds >= 16 floats.
 __device__ __forceinline__ float block_sum(float v, float *red) {
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
@@ -702,32 +714,47 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
                 ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
     const uint32_t cnt = 1u << T;
     if (cnt == 16u * nt) {
-      float tot = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+      // |amplitude|^2 of the 16 elements a lane owns, then a pruned Walsh-Hadamard butterfly over
+      // the 4 iteration bits: the total and the four single-bit signed sums in 41 additions
+      float pr[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const float pr = norm2(s[sw(tid + it * nt)]);
-        tot += pr;
-        h0 += (it & 1) ? -pr : pr;
-        h1 += (it & 2) ? -pr : pr;
-        h2 += (it & 4) ? -pr : pr;
-        h3 += (it & 8) ? -pr : pr;
-      }
-      // nt = 2^tb threads: tb thread-bit sums (unused ones are harmless), 4 iteration-bit
-      // sums, the total.  One multi-value block reduction = 2 barriers, then ONE coalesced
-      // store of the 33-float row (no global store may sit in front of a barrier).
-      float v[15];
+      for (int it = 0; it < 16; ++it) pr[it] = norm2(s[sw(tid + it * nt)]);
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3, tot;
+      float s1[8], s2[4], s3[2];
 #pragma unroll
-      for (int j = 0; j < 10; ++j) v[j] = ((tid >> j) & 1) ? -tot : tot;
-      v[10] = h0; v[11] = h1; v[12] = h2; v[13] = h3; v[14] = tot;
+      for (int i = 0; i < 8; ++i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; }
+      tot = s3[0] + s3[1];
+      h3 = s3[0] - s3[1];
+      // per wave: the total, the six lane-bit signed totals and h0..h3 through DPP wave sums
+      // (66 v_add_f32_dpp, nothing on the LDS crossbar); wave-index bits are signed afterwards
       const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
-      const float mine = wave_reduce_scatter<15>(v);  // lane k: this wave's total of v[k]
-      if (lane < 15) red[w * 15 + lane] = mine;
+      float v[11];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) v[j] = ((lane >> j) & 1) ? -tot : tot;
+      v[6] = h0; v[7] = h1; v[8] = h2; v[9] = h3; v[10] = tot;
+#pragma unroll
+      for (int j = 0; j < 11; ++j) v[j] = wave_sum_dpp63(v[j]);
+      tile_sync<RAW>();  // k_tile2 keeps `red` INSIDE the tile buffer (32 KiB per workgroup = 5
+                         // workgroups per CU): every amplitude must have been read by now
+      if (lane == kWave - 1) {
+#pragma unroll
+        for (int j = 0; j < 11; ++j) red[w * 11 + j] = v[j];
+      }
       tile_sync<RAW>();
       float *row = red + 240;  // 33 floats
+      const int tb = T - 4;    // thread bits: 0..5 lane, 6..tb-1 wave index
       if (tid < 15) {
         float r = 0.f;
-        for (int i = 0; i < nw; ++i) r += red[i * 15 + tid];
-        const int tb = T - 4;
+        if (tid < 6 || tid >= 10) {  // lane bits, h0..h3, total: plain sums over the waves
+          const int k = tid < 6 ? tid : tid - 4;
+          for (int i = 0; i < nw; ++i) r += red[i * 11 + k];
+        } else {                     // wave-index bit (tid - 6)
+          for (int i = 0; i < nw; ++i) r += ((i >> (tid - 6)) & 1) ? -red[i * 11 + 10] : red[i * 11 + 10];
+        }
         if (tid < 10) { if (tid < tb) row[a.tile_bits[tid]] = r; }
         else if (tid < 14) row[a.tile_bits[tb + tid - 10]] = r;
         else {
@@ -1114,21 +1141,24 @@ struct Tile2Args {
   const LoweredOp *ops;     // qmle_plan::ops2 on the device
   const uint32_t *tbl;      // qmle_plan::tbl2 on the device
   int n_groups;
+  int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue
 };
 
-template <bool NT>
+template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own
+                                  // instantiation: the storing kernel keeps a small register budget)
 __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
   char *sb = reinterpret_cast<char *>(smem4);
   const int T = a.T;
-  float *red = reinterpret_cast<float *>(s + (1u << T));
+  float *red = reinterpret_cast<float *>(s);  // measuring epilogues: scratch aliases the tile
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
   const int b = blockIdx.y;
   const uint32_t tile = blockIdx.x;
   const size_t D = (size_t)1 << a.n;
   const uint64_t base = tile_base(a, tile);
-  float2 *st = a.states + (size_t)b * D + base;
+  // global addresses: wave-uniform 64-bit base (SGPRs) + one 32-bit byte offset per lane
+  char *st = reinterpret_cast<char *>(a.states + (size_t)b * D + base);
   // a lane's 8 float4: local index j = 2 (tid + u nt): bit 0 rides in the access, bits 1..T-4
   // come from tid, the top three from u (wave-uniform)
   const uint32_t jl = 2u * tid;
@@ -1137,27 +1167,34 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   uint32_t uoff[8], soff[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    uoff[u] = ((u & 1u) << a.tile_bits[T - 3]) | (((u >> 1) & 1u) << a.tile_bits[T - 2]) |
-              (((u >> 2) & 1u) << a.tile_bits[T - 1]);
+    uoff[u] = (((u & 1u) << a.tile_bits[T - 3]) | (((u >> 1) & 1u) << a.tile_bits[T - 2]) |
+               (((u >> 2) & 1u) << a.tile_bits[T - 1])) << 3;  // bytes
     soff[u] = sw((uint32_t)u << (T - 3)) >> 1;  // float4 index; sw() is linear over XOR
   }
   const uint32_t sl = sw(jl) >> 1;
+  const uint32_t goff8 = goff << 3;  // < 2^31 for n <= 28
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.init_zero && base != 0) {
     // |0..0> lives in tile 0 alone and gates are linear: every other tile stays exactly zero
-    if (a.meas == TM_STORE) {
+    if (!MEASURE && a.meas == TM_STORE) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + (goff | uoff[u])), z4);
-    } else if (a.meas == TM_PROBS) {
-      float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D + base;
+      for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), z4);
+    } else if (!MEASURE) {
+      char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) *reinterpret_cast<float2 *>(po + (goff | uoff[u])) = make_float2(0.f, 0.f);
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) = make_float2(0.f, 0.f);
     } else {
       float *po = reinterpret_cast<float *>(a.out) +
                   ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
       if (tid <= QMLE_MAX_QUBITS) po[tid] = 0.f;
     }
     return;
+  }
+  if (f.dbg & 4) {  // experiment: static pseudo-random wave priority per workgroup
+    const uint32_t hsh = ((blockIdx.x + 977u * blockIdx.y) * 2654435761u) >> 30;
+    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
+    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
+    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
   }
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
   uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
@@ -1169,7 +1206,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   } else {
     float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + (goff | uoff[u])));
+    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
 #pragma unroll
     for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = v[u];
   }
@@ -1180,6 +1217,9 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     u64 r[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+    // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
+    // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
+    asm volatile("" : "+v"(addr));
     // scalar loads are dword-wide: header fields are unpacked from whole words
     const uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
     const int n_ops = (int)(hdr & 0xffffu);
@@ -1189,11 +1229,26 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     else if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
-    for (int k = 0; k < n_ops; ++k) {
-      const v4u w = op[k];  // LoweredOp: .y >> 24 = dispatch code, .z = matrix offset (floats)
-      const u64 QMLE_CONSTANT *m = mrow + (w.z >> 1);
-      const Mat2S M = {m[0], m[1], m[2], m[3]};
-      fast_dispatch(r, (int)(w.y >> 24), M);
+    // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats).  Scalar loads run
+    // two descriptors and one matrix ahead of the gate being applied, so neither latency (the
+    // matrix address depends on the descriptor) is ever waited for inside the gate loop.
+    if (n_ops > 0) {
+      v4u w0 = op[0];
+      v4u w1 = op[n_ops > 1 ? 1 : 0];
+      const u64 QMLE_CONSTANT *m = mrow + (w0.z >> 1);
+      Mat2S M0 = {m[0], m[1], m[2], m[3]};
+      for (int k = 0; k < n_ops; ++k) {
+        // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
+        // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
+        asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
+        const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
+        const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
+        const v4u w2 = op[k + 2 < n_ops ? k + 2 : n_ops - 1];
+        fast_dispatch(r, (int)(w0.y >> 24), M0);
+        w0 = w1;
+        w1 = w2;
+        M0 = Mn;
+      }
     }
     if (relayout) {
       __syncthreads();  // every gather of the group is done: slots may change owners
@@ -1208,22 +1263,23 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     __syncthreads();
   }
 
-  if (a.meas == TM_STORE) {
+  if (MEASURE) {
+    if (f.dbg & 2) return;
+    tile_epilogue<false>(a, s, nullptr, red, tile, gridDim.x, b, base);
+  } else if (a.meas == TM_STORE) {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + (goff | uoff[u])), v[u]);
-  } else if (a.meas == TM_PROBS) {
-    float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D + base;
+    for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), v[u]);
+  } else {
+    char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float4 v = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
-      *reinterpret_cast<float2 *>(po + (goff | uoff[u])) =
+      *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) =
           make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
     }
-  } else {
-    tile_epilogue<false>(a, s, nullptr, red, tile, gridDim.x, b, base);
   }
 }
 
@@ -3426,9 +3482,13 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
     static bool attr2 = false;
     if (!attr2) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false>,
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true>,
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr2 = true;
     }
@@ -3437,10 +3497,18 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     f.ops = p->dev.d_ops2;
     f.tbl = p->dev.d_tbl2;
     f.n_groups = st.fast_end - st.fast_begin;
-    const size_t lds2 = ((size_t)8 << st.T) +
-                        (meas == TM_STORE || meas == TM_PROBS ? 0 : 288 * sizeof(float));
-    if (a.nt) hipLaunchKernelGGL(k_tile2<true>, grid, dim3(threads), lds2, stream, a, f);
-    else hipLaunchKernelGGL(k_tile2<false>, grid, dim3(threads), lds2, stream, a, f);
+    static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
+    f.dbg = dbg;
+    if (dbg & 1) f.n_groups = 0;
+    const size_t lds2 = (size_t)8 << st.T;  // T >= 10: the epilogues' scratch fits inside
+    const bool measure = !(meas == TM_STORE || meas == TM_PROBS);
+    if (measure) {
+      if (a.nt) hipLaunchKernelGGL((k_tile2<true, true>), grid, dim3(threads), lds2, stream, a, f);
+      else hipLaunchKernelGGL((k_tile2<false, true>), grid, dim3(threads), lds2, stream, a, f);
+    } else {
+      if (a.nt) hipLaunchKernelGGL((k_tile2<true, false>), grid, dim3(threads), lds2, stream, a, f);
+      else hipLaunchKernelGGL((k_tile2<false, false>), grid, dim3(threads), lds2, stream, a, f);
+    }
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }

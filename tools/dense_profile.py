@@ -45,7 +45,8 @@ def run(n, B, layers, flags, label, reps=3, absorb=True):
     print(f"{label}: n={n} B={B} layers={layers} total {tot*1e3:.1f} us/state; "
           f"(kind,T,L,gates,groups,us/state-ish per launch/B): {passes} launches {cnt}", flush=True)
     for s in d["stages"]:
-        print("    groups:", [(g["n_ops"], g["bits"]) for g in s["groups"]], flush=True)
+        print("    groups:", [(g["n_ops"], g["bits"]) for g in s["groups"]], "fast:",
+              [(g["n_ops"], g["relayout"]) for g in s["fast_groups"]] if s["fast"] else None, flush=True)
 
 
 if __name__ == "__main__":
@@ -54,7 +55,7 @@ if __name__ == "__main__":
     NS = N.PLAN_NO_SPARSE
     run(24, B, 1, NS, "K2 dense (folded CX)")
     run(24, B, 1, NS | N.PLAN_NO_ABSORB, "K2 dense, all 96 gates applied")
-    for T, L in ((12, 4), (12, 5), (13, 5), (13, 7)):
+    for T, L in ((12, 4), (12, 5), (13, 4), (13, 5), (13, 6)):
         run(24, B, 1, NS | N.PLAN_NO_ABSORB | F(tile_bits=T, low_bits=L), f"  T{T} L{L}")
     for layers in (2, 4):
         run(24, B, layers, NS | N.PLAN_NO_ABSORB, f"HE {layers} layers dense")

@@ -58,6 +58,7 @@ __device__ __forceinline__ void gate16(u64 (&a)[16], u64 m00, u64 m01, u64 m10, 
 struct Args {
   float2 *states;
   const float *mats;  // [B][G][4][8]
+  const float *amat;  // [B][G][16][64]: A-operand fragments of the merged 32x32 real matrix
   int n, T, L, G;
   int tile_bits[16];   // global positions of the local bits
   int outer_bits[32];
@@ -106,16 +107,57 @@ __global__ void __launch_bounds__(256) k_t2(const Args a) {
                   ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
     const uint32_t bs = sw(ins0(ins0(ins0(ins0(tid, b0), b1), b2), b3));
     const u64 *m = reinterpret_cast<const u64 *>(mrow + g * 32);
-    if (ASM) {
+    if (ASM && (a.use_asm == 3 || a.use_asm == 14)) {
+      // matrix-core group: the 4 gates merged into one 16x16 complex operator = 32x32 real
+      // matrix R; out[32 reals x 32 items] = R . in via 16 x v_mfma_f32_32x32x2_f32 per block of
+      // 32 work items (two blocks per wave)
+      typedef float f16v __attribute__((ext_vector_type(16)));
+      const int lane = tid & 63, hh = lane >> 5;
+      const float *A = a.amat + ((size_t)(b * a.G + g) * 16) * 64 + lane;
+      float af[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) af[k] = A[k * 64];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const uint32_t item = (tid & ~63u) + 32u * blk + (lane & 31);
+        const uint32_t bsi = sw(ins0(ins0(ins0(ins0(item, b0), b1), b2), b3));
+        float bf[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bf[k] = reinterpret_cast<const float *>(s)[2 * (bsi ^ off[k]) + hh];
+        f16v acc = {0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], bf[k], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+          const int a0 = 4 * (v >> 2) + ((v & 3) >> 1);  // lane half 0; half 1 holds amplitude a0 + 2
+          s[bsi ^ (hh ? off[a0 + 2] : off[a0])] = make_float2(acc[v], acc[v + 1]);
+        }
+      }
+    } else if (ASM) {
       u64 v[16];
+      const bool lds_on = a.use_asm != 13 || g == 0, gates_on = a.use_asm != 12;
+      if (lds_on) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = reinterpret_cast<const u64 *>(s)[bs ^ off[c]];
-      gate16<0>(v, m[0], m[1], m[2], m[3]);
-      gate16<1>(v, m[4], m[5], m[6], m[7]);
-      gate16<2>(v, m[8], m[9], m[10], m[11]);
-      gate16<3>(v, m[12], m[13], m[14], m[15]);
+        for (int c = 0; c < 16; ++c) v[c] = reinterpret_cast<const u64 *>(s)[bs ^ off[c]];
+      } else {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) reinterpret_cast<u64 *>(s)[bs ^ off[c]] = v[c];
+        for (int c = 0; c < 16; ++c) v[c] = 0x3c0000003c000000ull + c + tid;
+      }
+      if (gates_on) {
+        gate16<0>(v, m[0], m[1], m[2], m[3]);
+        gate16<1>(v, m[4], m[5], m[6], m[7]);
+        gate16<2>(v, m[8], m[9], m[10], m[11]);
+        gate16<3>(v, m[12], m[13], m[14], m[15]);
+      }
+      if (lds_on || g + 1 == a.G) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) reinterpret_cast<u64 *>(s)[bs ^ off[c]] = v[c];
+      } else {
+        u64 x = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x ^= v[c];
+        if (x == 0x1234567ull) reinterpret_cast<u64 *>(s)[bs] = x;
+      }
     } else {
       float2 v[16];
 #pragma unroll
@@ -245,7 +287,7 @@ int main(int argc, char **argv) {
   CHK(hipFuncSetAttribute((const void *)k_t2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   const int wgs = argc > 3 ? atoi(argv[3]) : 1280;
   CHK(hipFuncSetAttribute((const void *)k_t2p, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  const int modes[] = {11, 1, 2};
+  const int modes[] = {3, 14, 1, 11};
   for (int use_asm : modes)
     for (int G = 0; G <= 4; ++G) {
       Args a{};
@@ -269,6 +311,33 @@ int main(int argc, char **argv) {
             o[0] = m00.real(); o[1] = m00.imag(); o[2] = m01.real(); o[3] = m01.imag();
             o[4] = m10.real(); o[5] = m10.imag(); o[6] = m11.real(); o[7] = m11.imag();
           }
+      std::vector<float> ha((size_t)B * (G ? G : 1) * 16 * 64);
+      for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g) {
+          std::complex<double> U[16][16];
+          for (int r = 0; r < 16; ++r)
+            for (int c = 0; c < 16; ++c) {
+              std::complex<double> x = 1.0;
+              for (int t = 0; t < 4; ++t) {
+                const float *o = &hm[((size_t)(b * G + g) * 4 + t) * 8];
+                const int rb = (r >> t) & 1, cb = (c >> t) & 1;
+                x *= std::complex<double>(o[(rb * 2 + cb) * 2], o[(rb * 2 + cb) * 2 + 1]);
+              }
+              U[r][c] = x;
+            }
+          for (int k = 0; k < 16; ++k)
+            for (int l = 0; l < 64; ++l) {
+              const int i = l & 31, col = 2 * k + (l >> 5);
+              const int ar = i >> 1, cr = i & 1, ac = col >> 1, cc = col & 1;
+              const std::complex<double> u = U[ar][ac];
+              const double val = cr == 0 ? (cc == 0 ? u.real() : -u.imag()) : (cc == 0 ? u.imag() : u.real());
+              ha[(((size_t)(b * G + g) * 16) + k) * 64 + l] = (float)val;
+            }
+        }
+      float *da;
+      CHK(hipMalloc(&da, ha.size() * sizeof(float)));
+      CHK(hipMemcpy(da, ha.data(), ha.size() * sizeof(float), hipMemcpyHostToDevice));
+      a.amat = da;
       float *dm;
       CHK(hipMalloc(&dm, hm.size() * sizeof(float)));
       CHK(hipMemcpy(dm, hm.data(), hm.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -322,6 +391,7 @@ int main(int argc, char **argv) {
              use_asm, L, G, 4 * G, us, 2.0 * D * 8 / us / 1e6, err, nrm);
       fflush(stdout);
       CHK(hipFree(dm));
+      CHK(hipFree(da));
     }
   return 0;
 }
