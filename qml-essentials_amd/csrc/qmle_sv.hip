@@ -3010,6 +3010,120 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
   }
 }
 
+// Round-2 Meyer-Wallach tile kernel: same rows as k_mw_tile, built like k_tile2 -- no lookup
+// table (a lane's 8 float4 differ in wave-uniform high bits), cross terms as packed fp32 (2
+// instructions per amplitude pair), the populations of a gather's 4 bits through a pruned
+// Walsh-Hadamard butterfly (41 additions instead of 64), the 37 per-wave sums on the DPP data
+// path instead of 63 LDS-crossbar exchanges, and 2^q tiles per workgroup with the next tile in
+// flight in registers (one reduction and one 37-float row per 16 tiles at n = 28).
+// Measured (MI355X, n = 28, three reads of 2 GiB): 1.93 ms (k_mw_tile + 2 x k_mw_direct) ->
+// 2.01 ms one tile per workgroup -> 1.80 ms at q = 4; hipcc gives the loop form 180-204 VGPRs
+// (2 waves per SIMD), and capping it at 128 spills (5 ms).  See DESIGN.md section 5 for why two
+// reads are out of reach with 160 KiB of LDS.
+template <bool LOW, bool NT>
+__global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) {
+  extern __shared__ float4 smem4[];
+  float2 *s = reinterpret_cast<float2 *>(smem4);
+  float *red = reinterpret_cast<float *>(smem4);  // reduction scratch aliases the tile
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const uint32_t jl = 2u * tid;  // local bits 1..8 from tid (bits 0..3 contiguous), 9..11 from u
+  uint32_t goff = jl & ((1u << kMwL) - 1u);
+  for (int p = kMwL; p <= kMwT - 4; ++p) goff |= ((jl >> p) & 1u) << a.tile_bits[p];
+  const uint32_t goff8 = goff << 3;
+  uint32_t uo[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    uo[u] = (((u & 1u) << a.tile_bits[kMwT - 3]) | (((u >> 1) & 1u) << a.tile_bits[kMwT - 2]) |
+             (((u >> 2) & 1u) << a.tile_bits[kMwT - 1])) << 3;
+  const uint32_t sl = sw(jl) >> 1;
+  const uint32_t tidv = (uint32_t)tid;
+  // a workgroup walks 2^q tiles: the next tile's 8 float4 per lane are in flight (registers)
+  // while the gathers run on the current one, and the 37 sums stay per work item until the end
+  auto tile_ptr = [&](uint32_t tile) {
+    uint64_t base = 0;
+    for (int i = 0; i < a.n - kMwT; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
+    return reinterpret_cast<const char *>(a.states + ((size_t)b << a.n) + base);
+  };
+  const uint32_t tile0 = blockIdx.x << q, n_it = 1u << q;
+  float4 v[8];
+  {
+    const char *st = tile_ptr(tile0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8));
+  }
+  float acc[37];
+#pragma unroll
+  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
+  for (uint32_t it = 0; it < n_it; ++it) {
+    if (it) __syncthreads();  // the previous tile's gathers are done
+#pragma unroll
+    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ (sw((uint32_t)u << (kMwT - 3)) >> 1)] = v[u];
+    __syncthreads();
+    if (it + 1 < n_it) {
+      const char *st = tile_ptr(tile0 + it + 1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8));
+    }
+#pragma unroll
+    for (int g = LOW ? 0 : 1; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
+      const uint32_t bs = sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3));
+      v2f r[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float2 x = s[bs ^ sw((uint32_t)c << (4 * g))];
+        r[c] = (v2f){x.x, x.y};
+      }
+      float pr[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const v2f qq = r[c] * r[c];
+        pr[c] = qq.x + qq.y;
+      }
+      // populations: signed sums over each of the 4 bits + the total, pruned butterfly
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f, s1[8], s2[4], s3[2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; }
+      acc[3 * (4 * g + 0) + 2] += h0;
+      acc[3 * (4 * g + 1) + 2] += h1;
+      acc[3 * (4 * g + 2) + 2] += h2;
+      acc[3 * (4 * g + 3) + 2] += s3[0] - s3[1];
+      if (g == 1) acc[36] += s3[0] + s3[1];
+      // cross terms x conj(y) over the 8 pairs of each bit: two packed fmas per pair
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v2f sum = {acc[3 * (4 * g + t)], acc[3 * (4 * g + t) + 1]};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c & (1 << t)) continue;
+          const v2f x = r[c], y = r[c | (1 << t)];
+          sum = __builtin_elementwise_fma(x, y.xx, sum);
+          sum = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, sum);
+        }
+        acc[3 * (4 * g + t)] = sum.x;
+        acc[3 * (4 * g + t) + 1] = sum.y;
+      }
+    }
+  }
+  const int lane = tid & (kWave - 1), w = tid / kWave;
+#pragma unroll
+  for (int k = LOW ? 0 : 12; k < 37; ++k) acc[k] = wave_sum_dpp63(acc[k]);
+  __syncthreads();  // every gather has been read: the tile becomes scratch
+  if (lane == kWave - 1) {
+#pragma unroll
+    for (int k = 0; k < 37; ++k) red[w * 37 + k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 37) {
+    float vv = 0.f;
+    for (int i = 0; i < kMwThreads / kWave; ++i) vv += red[i * 37 + tid];
+    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = vv;
+  }
+}
+
 // Passes after the first only report 8 high bits: no LDS staging for those.  A workgroup
 // takes a block of 2^14 amplitudes -- the 6 lowest bits (one wave = 512 contiguous bytes per
 // load instruction; the LDS tile kernel's 4 low bits give 128-byte runs) and the pass's 8
@@ -3114,6 +3228,7 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_direct(const MwDirectArgs a, 
 __global__ void __launch_bounds__(1024)
 k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_passes, int batch,
                  int rows_later /* rows per state of the passes after the first */,
+                 int rows_first /* rows per state of the first pass */,
                  float *__restrict__ pur_out /* [batch][n] by bit position */) {
   __shared__ double red[16];
   const int b = blockIdx.x, p = blockIdx.y;
@@ -3125,7 +3240,7 @@ k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_pa
     local = kMwL + (p - kMwL) % (kMwT - kMwL);
     if (pass == n_passes - 1 && n > kMwT) local = kMwL + (p - (n - (kMwT - kMwL)));
   }
-  const int rows = pass == 0 ? n_tiles : rows_later;
+  const int rows = pass == 0 ? rows_first : rows_later;
   const float *pp = partial + pass * pass_stride + (size_t)b * rows * kMwRow;
   double cr = 0, ci = 0, z = 0, tot = 0;
   for (int i = threadIdx.x; i < rows; i += blockDim.x) {
@@ -4769,6 +4884,7 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
     const size_t lds = ((size_t)8 << kMwT) + ((size_t)4 << (kMwT - kMwL)) + 160 * sizeof(float);
     // later passes: register-direct kernel, 2^mw_q tiles per workgroup (>= 2048 workgroups)
     static const bool no_direct = std::getenv("QMLE_MW_NO_DIRECT") != nullptr;
+    int mw_rows = -1;        // k_mw_tile2: rows per pass (tiles >> q2)
     int mw_q = -1;           // blocks of 2^14 amplitudes per workgroup = 2^mw_q; rows = blocks >> mw_q
     const int blocks = n >= 14 ? 1 << (n - 14) : 0;
     if (!no_direct && n >= 18) {
@@ -4790,6 +4906,28 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
       for (int bit = 0; bit < n; ++bit) {
         if (mask & (1u << bit)) a.tile_bits[nt++] = (int8_t)bit;
         else a.outer_bits[no++] = (int8_t)bit;
+      }
+      static const bool mw_old = std::getenv("QMLE_MW_OLD") != nullptr;
+      if (!mw_old) {
+        // >= 1 GiB per launch: stream past the caches
+        const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
+        const size_t lds2 = (size_t)8 << kMwT;
+        // 2^q2 tiles per workgroup: >= ~4 workgroups per CU-slot left (at n = 28: 16 tiles each)
+        int q2 = 0;
+        while (q2 < 4 && (((uint64_t)batch * tiles) >> (q2 + 1)) >= 4096) ++q2;
+        static const int q_env = std::getenv("QMLE_MW_Q") ? atoi(std::getenv("QMLE_MW_Q")) : -1;
+        if (q_env >= 0 && (tiles >> q_env) >= 1) q2 = q_env;
+        mw_q = -1;
+        mw_rows = tiles >> q2;
+        const dim3 grid2(tiles >> q2, batch);
+        if (p == 0) {
+          if (nt) hipLaunchKernelGGL((k_mw_tile2<true, true>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
+          else hipLaunchKernelGGL((k_mw_tile2<true, false>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
+        } else {
+          if (nt) hipLaunchKernelGGL((k_mw_tile2<false, true>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
+          else hipLaunchKernelGGL((k_mw_tile2<false, false>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
+        }
+        continue;
       }
       if (p == 0)
         hipLaunchKernelGGL(k_mw_tile<true>, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
@@ -4815,7 +4953,8 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
     float *d_pur = (float *)d_workspace + (size_t)passes * batch * tiles * kMwRow;
     hipLaunchKernelGGL(k_mw_tile_purity, dim3(batch, n), dim3(tiles >= 1024 ? 1024 : 64), 0,
                        stream, (const float *)d_workspace, n, tiles, passes, batch,
-                       mw_q >= 0 ? blocks >> mw_q : tiles, d_pur);
+                       mw_rows >= 0 ? mw_rows : mw_q >= 0 ? blocks >> mw_q : tiles,
+                       mw_rows >= 0 ? mw_rows : tiles, d_pur);
     hipLaunchKernelGGL(k_mw_tile_q, dim3((batch + 63) / 64), dim3(64), 0, stream,
                        (const float *)d_pur, n, batch, d_out, d_purities);
     HIPCHK(hipGetLastError());

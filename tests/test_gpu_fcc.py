@@ -57,12 +57,22 @@ def test_fcc_matches_oracle_on_same_parameters(circuit_type):
     assert np.isclose(fcc, np.abs(want[low]).mean(), atol=5e-4), (fcc, np.abs(want[low]).mean())
 
 
-@pytest.mark.parametrize("circuit_type,expected", [("Circuit_20", 0.004), ("Circuit_19", 0.010)])
+_FP64_NOISE = ("the published value is dominated by correlations between float64 rounding-noise "
+               "columns (analytically vanishing top-frequency coefficients; the double-precision "
+               "oracle reproduces 0.084 for Circuit_17), which a complex64 engine cannot share: "
+               "0.03 / 0.05 here; with the reference's numerical_cap both agree to 5e-4 "
+               "(test_fcc_matches_oracle_on_same_parameters), DESIGN.md section 8")
+
+
+@pytest.mark.parametrize("circuit_type,expected", [
+    ("Circuit_20", 0.004), ("Circuit_19", 0.010),
+    # the reference's other two published values (tests/test_coefficients.py:958-961): kept as
+    # known gaps instead of being dropped
+    pytest.param("Circuit_17", 0.078, marks=pytest.mark.xfail(strict=True, reason=_FP64_NOISE)),
+    pytest.param("Hardware_Efficient", 0.080, marks=pytest.mark.xfail(strict=False, reason=_FP64_NOISE)),
+])
 def test_fcc_paper_values(circuit_type, expected):
-    """test_coefficients.py:954-983.  (Circuit_17 / Hardware_Efficient have analytically
-    vanishing high-frequency coefficients; their published 0.078 / 0.080 are dominated by
-    correlations of float64 rounding noise -- reproduced by the double-precision oracle,
-    0.084 for Circuit_17 -- which a float32 engine cannot share; see DESIGN.md.)"""
+    """test_coefficients.py:954-983, all four published values."""
     model = Model(n_qubits=6, n_layers=1, circuit_type=circuit_type, output_qubit=-1,
                   encoding=["RY"])
     fcc = FCC.get_fcc(model=model, n_samples=500, scale=True)
