@@ -2235,7 +2235,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
   const uint64_t chunks = (uint64_t)1 << (n - 1);
   float4 *st = states + (size_t)b * chunks;
   const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (k >= items) return;
+  if (MODE < 5 && k >= items) return;  // modes 5 / 6: exact grids, whole waves
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
   if constexpr (MODE == 0) {
     if constexpr (DIAG) {  // items = all chunks
@@ -2293,6 +2293,52 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
       apply2(m, a0, a1);
     }
     st4<NT>(st + c, make_float4(a0.x, a0.y, a1.x, a1.y));
+  } else if constexpr (MODE == 5) {
+    // uncontrolled dense gate on bit 1..6: the partner chunk sits in lane ^ 2^(pt-1) of the same
+    // wave.  Every lane loads and stores contiguous float4s (coalesced like the diagonal gate)
+    // and fetches the partner's through the cross-lane path; it computes its own half of the
+    // pair only.  items = chunks / 2, two rows per lane.  (tools/k1_tune.hip: 0.76 -> 0.70 ms)
+    const uint64_t c0 = (uint64_t)blockIdx.x * 512u + threadIdx.x, c1 = c0 + 256u;
+    const bool up = (threadIdx.x >> (pt - 1)) & 1u;
+    const float2 ms = up ? m.m11 : m.m00, mo = up ? m.m10 : m.m01;
+    float4 v[2] = {ld4<NT>(st + c0), ld4<NT>(st + c1)};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float4 o;
+      o.x = __shfl_xor(v[u].x, 1 << (pt - 1), kWave); o.y = __shfl_xor(v[u].y, 1 << (pt - 1), kWave);
+      o.z = __shfl_xor(v[u].z, 1 << (pt - 1), kWave); o.w = __shfl_xor(v[u].w, 1 << (pt - 1), kWave);
+      const float2 x = cfma(mo, make_float2(o.x, o.y), cmul(ms, make_float2(v[u].x, v[u].y)));
+      const float2 y = cfma(mo, make_float2(o.z, o.w), cmul(ms, make_float2(v[u].z, v[u].w)));
+      v[u] = make_float4(x.x, x.y, y.x, y.y);
+    }
+    st4<NT>(st + c0, v[0]);
+    st4<NT>(st + c1, v[1]);
+  } else if constexpr (MODE == 6) {
+    // uncontrolled dense gate on a high bit (>= 21): a wave takes 4 ADJACENT rows of each of the
+    // two streams (4 KiB contiguous per stream), all loads of one stream first: the DRAM banks
+    // see fewer alternations between the two rows 2^pt amplitudes apart.  items = pairs / 4.
+    // (tools/k1_tune.hip: 0.75-0.79 -> 0.70 ms for bits 21..27)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t row0 = ((uint64_t)blockIdx.x * 4u + wave) * 4u;
+    float4 v0[4], v1[4];
+    uint64_t c0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c0[u] = ins0_64((row0 + u) * 64u + lane, pt - 1); v0[u] = ld4<NT>(st + c0[u]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v1[u] = ld4<NT>(st + (c0[u] | (1ull << (pt - 1))));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float2 a0 = make_float2(v0[u].x, v0[u].y), a1 = make_float2(v1[u].x, v1[u].y);
+      float2 b0 = make_float2(v0[u].z, v0[u].w), b1 = make_float2(v1[u].z, v1[u].w);
+      apply2(m, a0, a1);
+      apply2(m, b0, b1);
+      v0[u] = make_float4(a0.x, a0.y, b0.x, b0.y);
+      v1[u] = make_float4(a1.x, a1.y, b1.x, b1.y);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4<NT>(st + c0[u], v0[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4<NT>(st + (c0[u] | (1ull << (pt - 1))), v1[u]);
   } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
     if constexpr (DIAG) {  // items = all chunks
       float4 v = ld4<NT>(st + k);
@@ -3722,9 +3768,17 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
   const int pt = op.t0, pc = op.c0;
   int mode;
   uint64_t items;
+  static const bool k1_plain = std::getenv("QMLE_K1_PLAIN") != nullptr;
   if (op.nc == 0) {
-    if (pt >= 1) { mode = 0; items = diag ? chunks : chunks >> 1; }
-    else { mode = 1; items = chunks; }
+    if (pt >= 1) {
+      mode = 0;
+      items = diag ? chunks : chunks >> 1;
+      // dense gate, state >= 2^12 chunks: lane exchange for bits 1..6, 4-row bursts for bits >= 21
+      if (!diag && !k1_plain && n >= 14) {
+        if (pt <= 6) { mode = 5; items = chunks >> 1; }
+        else if (pt >= 21) { mode = 6; items = chunks >> 3; }
+      }
+    } else { mode = 1; items = chunks; }
   } else {
     if (pc >= 1 && pt >= 1) { mode = 2; items = diag ? chunks >> 1 : chunks >> 2; }
     else if (pt == 0) { mode = 3; items = chunks >> 1; }
@@ -3740,6 +3794,8 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     case 1: launch_direct_mode<1>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     case 2: launch_direct_mode<2>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     case 3: launch_direct_mode<3>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 5: launch_direct_mode<5>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
   }
   HIPCHK(hipGetLastError());
