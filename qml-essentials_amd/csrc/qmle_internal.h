@@ -139,6 +139,7 @@ struct StageProfile {  // optional HIP-event timing of every stage launch (bench
 };
 
 struct DevicePlan {  // lazily created by the first run on a device
+  int device = -1;     // HIP device the image lives on; runs on another device are refused
   void *blob = nullptr;
   size_t blob_bytes = 0;
   LoweredOp *d_ops = nullptr;

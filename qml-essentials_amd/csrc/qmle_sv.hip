@@ -3393,8 +3393,30 @@ inline unsigned grid_for(uint64_t items, unsigned block, unsigned cap = 1u << 30
   return (unsigned)g;
 }
 
+// hipFuncSetAttribute (160 KiB dynamic LDS) and the CU count are per DEVICE: a process that
+// drives several GPUs (one process per GPU is the supported layout, but nothing stops a caller)
+// must set them on each.  `slot` = a distinct small integer per call site.
+constexpr int kMaxDevices = 64;
+static inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+static inline bool first_use_on_device(int slot) {
+  static bool done[8][kMaxDevices] = {};
+  bool &d = done[slot][current_device()];
+  const bool first = !d;
+  d = true;
+  return first;
+}
+
 int ensure_device_plan(qmle_plan *p) {
-  if (p->dev.blob) return QMLE_OK;
+  if (p->dev.blob) {
+    // the plan's device image lives on the device of its first run: refuse another one rather
+    // than hand kernels a pointer they cannot read
+    return p->dev.device == current_device() ? QMLE_OK : QMLE_ERR_UNSUPPORTED;
+  }
+  p->dev.device = current_device();
   const size_t b_ops = align_up(p->dev_ops.size() * sizeof(LoweredOp) + 16, 256);
   const size_t b_build = align_up(p->build_ops.size() * sizeof(BuildOp) + 16, 256);
   const size_t b_groups = align_up(p->groups.size() * sizeof(BuildGroup) + 16, 256);
@@ -3514,13 +3536,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                  ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)
              ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (first_use_on_device(0)) {
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   bool has_dense4 = false;  // 16x16 Kraus superoperators: separate instantiation, so that the
                             // common kernel keeps its register budget
@@ -3531,11 +3551,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   const uint64_t total = (uint64_t)tiles * (uint64_t)batch;
   const int threads = tile_threads(st.T);
   const size_t lds_pf = lds + ((size_t)8 << st.T);
-  static int n_cu = 0;
+  static int n_cu_of[kMaxDevices] = {};
+  int &n_cu = n_cu_of[current_device()];
   if (!n_cu) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, current_device()) == hipSuccess && v > 0)
       n_cu = v;
     else
       n_cu = 256;
@@ -3550,13 +3570,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                      wg_per_cu >= 1 && total < (1ull << 31) &&
                      total >= 4ull * n_cu * wg_per_cu;
   if (pf_ok) {
-    static bool pf_attr = false;
-    if (!pf_attr) {
+    if (first_use_on_device(1)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      pf_attr = true;
     }
     const unsigned wgs = (unsigned)n_cu * wg_per_cu;
     const uint32_t chunk = (uint32_t)((total + wgs - 1) / wgs);
@@ -3641,8 +3659,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   static const bool no_fast = std::getenv("QMLE_NO_FAST_TILE") != nullptr;
   if (!no_fast && st.fast_ok && !a.compact && !a.zin_local && !a.zin_outer && st.T < p->n &&
       threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
-    static bool attr2 = false;
-    if (!attr2) {
+    if (first_use_on_device(2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, false>,
@@ -3651,7 +3668,6 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr2 = true;
     }
     Tile2Args f;
     f.groups = p->dev.d_groups2 + st.fast_begin;
@@ -4484,13 +4500,11 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     for (int k = 0; k < n_obs; ++k) a.zmask[k] = wires_to_pos(obs_wire_masks[k], n);
     a.grad = d_grad;
     a.n_grad_slots = n_grad_slots;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_device(3)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
     }
     bool has_dense4 = false;
     for (int g = fst.grp_begin; g < fst.grp_end; ++g) has_dense4 |= fwd->op_groups[g].kind == GK_DENSE4;
@@ -4598,11 +4612,9 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     d_gtype = (const int32_t *)((char *)rev->adjf_blob + o1);
     d_slot_of = (const int32_t *)((char *)rev->adjf_blob + o2);
     d_coef_of = (const float *)((char *)rev->adjf_blob + o3);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_device(4)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_adj,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
     }
   }
   float *tile_partial = (float *)(ws + L.tile_partial);

@@ -4,15 +4,19 @@ the per-kernel PMC averages that tools/parse_pmc.py wrote.  Usage: update_traffi
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pm = json.load(open(sys.argv[1])); n = int(sys.argv[2]); states = int(sys.argv[3])
+tag = sys.argv[4] if len(sys.argv) > 4 else "fused"   # "dense": the all-amplitudes-live plan
+source = sys.argv[5] if len(sys.argv) > 5 else None
 path = os.path.join(root, "profiles", "traffic.json")
 t = json.load(open(path))
 for fam, d in pm.items():
     if "hbm_read_bytes_per_launch_x2_corrected" not in d or "hbm_write_bytes_per_launch" not in d:
         continue
-    if not fam.startswith(("k_tile", "k_product", "k_reg_measure", "k_direct")):
+    if not fam.startswith(("k_tile", "k_product", "k_reg_measure", "k_direct", "k_mw")):
         continue
     rd, wr = round(d["hbm_read_bytes_per_launch_x2_corrected"]), round(d["hbm_write_bytes_per_launch"])
-    t[f"{fam}:n{n}:fused"] = {"read": rd, "write": wr, "hbm_bytes_per_launch": rd + wr,
-                              "states_per_launch": states}
+    t[f"{fam}:n{n}:{tag}"] = {"read": rd, "write": wr, "hbm_bytes_per_launch": rd + wr,
+                              "states_per_launch": states, "launches_averaged": d.get("launches")}
+    if source:
+        t[f"{fam}:n{n}:{tag}"]["source"] = source
 json.dump(t, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in t.items() if k != "_how"}, indent=1))
