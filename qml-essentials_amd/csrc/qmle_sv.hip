@@ -1190,12 +1190,6 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     }
     return;
   }
-  if (f.dbg & 4) {  // experiment: static pseudo-random wave priority per workgroup
-    const uint32_t hsh = ((blockIdx.x + 977u * blockIdx.y) * 2654435761u) >> 30;
-    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
-    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
-    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
-  }
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
   uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
   if (a.init_zero) {
