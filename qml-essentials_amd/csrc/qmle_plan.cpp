@@ -216,7 +216,8 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
 // Layout map: logical tile index e lives at physical slot L(e) = XOR_{j in e} Lcol[j] ^ Lconst.
 static inline uint32_t swz(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }  // = sw() in qmle_sv.hip
 
-static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<LoweredOp> &src) {
+static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<LoweredOp> &src,
+                              uint32_t zin_local) {
   st.fast_ok = false;
   st.fast_begin = st.fast_end = (int)p->groups2.size();
   const int T = st.T;
@@ -245,7 +246,13 @@ static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<Lowered
   auto M_reset = [&]() { for (int j = 0; j < T; ++j) Mcol[j] = 1u << j; Mconst = 0; };
   M_reset();
   auto is_perm = [](const LoweredOp &o) { return (o.flags & LF_PERMX) != 0; };
+  // known-zero tile-local bits along the stage's execution (runs from |0..0>, Stage::zero_in):
+  // a gate that is not diagonal takes its target out of the set, controls stay.  A work item
+  // whose base index meets the set outside its group's bits holds 16 exact zeros: bit 0 of its
+  // table entry says so (the kernel honours it only in runs that track known zeros).
+  uint32_t Z = zin_local;
   auto apply_perm = [&](const LoweredOp &o) {
+    Z &= ~(1u << o.t0);
     const int t = o.t0;
     if (o.nc == 0) {
       Lconst ^= Lcol[t];
@@ -274,7 +281,10 @@ static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<Lowered
     for (int j = 0; j < T; ++j)
       if (G & (1u << j)) gb[k++] = j;
     g.tbl = (uint32_t)p->tbl2.size();
-    for (uint32_t t = 0; t < nt; ++t) p->tbl2.push_back(swz(L_of(deposit(t, G))) << 3);
+    for (uint32_t t = 0; t < nt; ++t) {
+      const uint32_t e = deposit(t, G);
+      p->tbl2.push_back((swz(L_of(e)) << 3) | ((e & Z & ~G) ? 1u : 0u));
+    }
     for (int c = 0; c < 16; ++c) {
       uint32_t v = 0;
       for (int j = 0; j < 4; ++j)
@@ -346,6 +356,8 @@ static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<Lowered
     g.op_begin = (uint32_t)p->ops2.size();
     g.n_ops = (uint16_t)mem.size();
     emit_tables(g, G);
+    for (int i : mem)
+      if (!(src[i].flags & LF_DIAG)) Z &= ~(1u << src[i].t0);
     for (int i : mem) {
       LoweredOp o = src[i];
       o.t0 = local_of[(int)o.t0];
@@ -690,6 +702,7 @@ int compile_plan(qmle_plan *p) {
     const bool no_fusion = (p->flags & QMLE_PLAN_NO_FUSION) != 0;
     const bool force_tile = (p->flags & QMLE_PLAN_FORCE_TILE) != 0;
     const uint64_t all_mask = n >= 64 ? ~0ull : bit(n) - 1;
+    uint32_t Zrun = n >= 32 ? ~0u : ((1u << n) - 1u);  // known-zero positions so far (|0..0> start)
 
     auto popc = [](uint64_t x) { return __builtin_popcountll(x); };
 
@@ -785,7 +798,10 @@ int compile_plan(qmle_plan *p) {
       if (st.kind == ST_TILE) {
         const std::vector<LoweredOp> tile_local(p->dev_ops.begin() + st.op_begin,
                                                 p->dev_ops.begin() + st.op_end);
-        build_fast_groups(p, st, tile_local);
+        uint32_t zin_local = 0;  // known-zero bits when this stage starts, tile-local
+        for (int j = 0; j < st.T; ++j)
+          if (Zrun & (1u << st.tile_bits[j])) zin_local |= 1u << j;
+        build_fast_groups(p, st, tile_local, zin_local);
         group_stage_ops(p, st);
       }
       for (int mi : members) {
@@ -803,6 +819,7 @@ int compile_plan(qmle_plan *p) {
           st.algo_bytes_per_state += algo_bytes(p->ops[s], n);
         }
       }
+      Zrun &= ~st.touched;
       p->stages.push_back(st);
     }
     if (p->whole_state_lds && p->stages.empty()) {
@@ -866,11 +883,12 @@ int compile_plan(qmle_plan *p) {
       }
       // + a part that does not shrink with the state (launch, first / last wave): at n = 20 a
       // pass costs ~1.2 us per state before its first group, a group ~1.35 us
-      if (st.fast_ok && !(sparse_model && st.zero_in)) {
-        // all-live stage on the fast kernel (k_tile2; MI355X, round 2): ~47 us for the HBM round
-        // trip with one group hidden behind it, ~9 per further group (51 with 2, 106 with 9)
+      if (st.fast_ok) {
+        // fast kernel (k_tile2; MI355X, round 2): ~47 us for the HBM round trip of an all-live
+        // stage with one group hidden behind it, ~9 per further group (51 with 2, 106 with 9);
+        // known zeros scale the traffic and the share of tiles that run their groups
         c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 18.0 * (rd + wr) +
-             9.0 * ((st.fast_end - st.fast_begin) - 0.5);
+             9.0 * ((st.fast_end - st.fast_begin) - 0.5) * tiles;
         continue;
       }
       c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 6.0 * (rd + wr) +

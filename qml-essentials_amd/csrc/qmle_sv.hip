@@ -1154,7 +1154,17 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   float *red = reinterpret_cast<float *>(s);  // measuring epilogues: scratch aliases the tile
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
   const int b = blockIdx.y;
-  const uint32_t tile = blockIdx.x;
+  uint32_t tile = blockIdx.x;
+  if (a.compact) {  // blockIdx.x enumerates the tiles that can be non-zero (launch_tile)
+    uint32_t rest = tile, free_bits = a.tile_free;
+    tile = 0;
+    while (rest) {
+      const uint32_t low = free_bits & (0u - free_bits);
+      if (rest & 1u) tile |= low;
+      free_bits ^= low;
+      rest >>= 1;
+    }
+  }
   const size_t D = (size_t)1 << a.n;
   const uint64_t base = tile_base(a, tile);
   // global addresses: wave-uniform 64-bit base (SGPRs) + one 32-bit byte offset per lane
@@ -1174,8 +1184,9 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   const uint32_t sl = sw(jl) >> 1;
   const uint32_t goff8 = goff << 3;  // < 2^31 for n <= 28
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.init_zero && base != 0) {
-    // |0..0> lives in tile 0 alone and gates are linear: every other tile stays exactly zero
+  if (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0) {
+    // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
+    // (Stage::zero_in) stays exactly zero -- write the zeros, skip the gates
     if (!MEASURE && a.meas == TM_STORE) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), z4);
@@ -1197,6 +1208,21 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = z4;
     __syncthreads();
     if (tid == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+  } else if (a.zin_local) {
+    // only the amplitudes that can be non-zero are read; the rest of the tile is zero-filled
+    const uint32_t zl = a.zin_local & ~1u;
+    const bool z0 = (a.zin_local & 1u) != 0;
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = z4;
+      if (((jl | ((uint32_t)u << (T - 3))) & zl) == 0) {
+        v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+        if (z0) v[u].z = v[u].w = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = v[u];
   } else {
     float4 v[8];
 #pragma unroll
@@ -1207,10 +1233,19 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   __syncthreads();
 
   const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
+  const bool use_skip = a.zin_local != 0;  // runs that track known zeros (Stage::zero_in)
   for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
+    // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point
+    const bool idle = use_skip && (addr & 1u);
+    addr &= ~7u;
     u64 r[16];
+    if (!idle) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = 0ull;
+    }
     // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
     // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
     asm volatile("" : "+v"(addr));
@@ -1226,6 +1261,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats).  Scalar loads run
     // two descriptors and one matrix ahead of the gate being applied, so neither latency (the
     // matrix address depends on the descriptor) is ever waited for inside the gate loop.
+    // (idle work items skip the arithmetic; the branch is per lane, the loads are per wave)
     if (n_ops > 0) {
       v4u w0 = op[0];
       v4u w1 = op[n_ops > 1 ? 1 : 0];
@@ -1238,7 +1274,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
         const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
         const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
         const v4u w2 = op[k + 2 < n_ops ? k + 2 : n_ops - 1];
-        fast_dispatch(r, (int)(w0.y >> 24), M0);
+        if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
         w0 = w1;
         w1 = w2;
         M0 = Mn;
@@ -1246,10 +1282,12 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     }
     if (relayout) {
       __syncthreads();  // every gather of the group is done: slots may change owners
+      // (an idle work item still owns 16 slots of the new layout: it stores its zeros)
+      addr_next &= ~7u;
 #pragma unroll
       for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr_next ^ grp->off_out[c])) = r[c];
       if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
-    } else {
+    } else if (!idle) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ grp->off[c])) = r[c];
     }
@@ -3651,8 +3689,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   // fast path: all-live stage of (controlled) 2x2 gates -- table-addressed groups, CX folded
   // into the LDS layout, SGPR matrices (k_tile2)
   static const bool no_fast = std::getenv("QMLE_NO_FAST_TILE") != nullptr;
-  if (!no_fast && st.fast_ok && !a.compact && !a.zin_local && !a.zin_outer && st.T < p->n &&
-      threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
+  if (!no_fast && st.fast_ok && st.T < p->n && threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
     if (first_use_on_device(2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
