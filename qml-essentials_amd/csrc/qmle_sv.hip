@@ -1144,6 +1144,74 @@ struct Tile2Args {
   int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue
 };
 
+// All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this
+// work item's table entry of the first group, already loaded.  Ends with a barrier.
+__device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile2Args &f,
+                                             const u64 QMLE_CONSTANT *mrow, int tid, bool use_skip) {
+  const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
+  for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
+    // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point
+    const bool idle = use_skip && (addr & 1u);
+    addr &= ~7u;
+    u64 r[16];
+    if (!idle) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = 0ull;
+    }
+    // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
+    // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
+    asm volatile("" : "+v"(addr));
+    // scalar loads are dword-wide: header fields are unpacked from whole words
+    const uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
+    const int n_ops = (int)(hdr & 0xffffu);
+    const bool relayout = ((hdr >> 16) & 0xffu) != 0;
+    uint32_t addr_next = 0;
+    if (relayout) addr_next = f.tbl[grp->tbl_out + tid];
+    else if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
+    // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats).  Scalar loads run
+    // two descriptors and one matrix ahead of the gate being applied, so neither latency (the
+    // matrix address depends on the descriptor) is ever waited for inside the gate loop.
+    // (idle work items skip the arithmetic; the branch is per lane, the loads are per wave)
+    if (n_ops > 0) {
+      v4u w0 = op[0];
+      v4u w1 = op[n_ops > 1 ? 1 : 0];
+      const u64 QMLE_CONSTANT *m = mrow + (w0.z >> 1);
+      Mat2S M0 = {m[0], m[1], m[2], m[3]};
+      for (int k = 0; k < n_ops; ++k) {
+        // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
+        // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
+        asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
+        const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
+        const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
+        const v4u w2 = op[k + 2 < n_ops ? k + 2 : n_ops - 1];
+        if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
+        w0 = w1;
+        w1 = w2;
+        M0 = Mn;
+      }
+    }
+    if (relayout) {
+      __syncthreads();  // every gather of the group is done: slots may change owners
+      // (an idle work item still owns 16 slots of the new layout: it stores its zeros)
+      addr_next &= ~7u;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr_next ^ grp->off_out[c])) = r[c];
+      if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
+    } else if (!idle) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ grp->off[c])) = r[c];
+    }
+    addr = addr_next;
+    __syncthreads();
+  }
+
+}
+
 template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own
                                   // instantiation: the storing kernel keeps a small register budget)
 __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
@@ -1233,67 +1301,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   __syncthreads();
 
   const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
-  const bool use_skip = a.zin_local != 0;  // runs that track known zeros (Stage::zero_in)
-  for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
-    // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point
-    const bool idle = use_skip && (addr & 1u);
-    addr &= ~7u;
-    u64 r[16];
-    if (!idle) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = 0ull;
-    }
-    // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
-    // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
-    asm volatile("" : "+v"(addr));
-    // scalar loads are dword-wide: header fields are unpacked from whole words
-    const uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
-    const int n_ops = (int)(hdr & 0xffffu);
-    const bool relayout = ((hdr >> 16) & 0xffu) != 0;
-    uint32_t addr_next = 0;
-    if (relayout) addr_next = f.tbl[grp->tbl_out + tid];
-    else if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
-    // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats).  Scalar loads run
-    // two descriptors and one matrix ahead of the gate being applied, so neither latency (the
-    // matrix address depends on the descriptor) is ever waited for inside the gate loop.
-    // (idle work items skip the arithmetic; the branch is per lane, the loads are per wave)
-    if (n_ops > 0) {
-      v4u w0 = op[0];
-      v4u w1 = op[n_ops > 1 ? 1 : 0];
-      const u64 QMLE_CONSTANT *m = mrow + (w0.z >> 1);
-      Mat2S M0 = {m[0], m[1], m[2], m[3]};
-      for (int k = 0; k < n_ops; ++k) {
-        // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
-        // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
-        asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
-        const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
-        const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
-        const v4u w2 = op[k + 2 < n_ops ? k + 2 : n_ops - 1];
-        if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
-        w0 = w1;
-        w1 = w2;
-        M0 = Mn;
-      }
-    }
-    if (relayout) {
-      __syncthreads();  // every gather of the group is done: slots may change owners
-      // (an idle work item still owns 16 slots of the new layout: it stores its zeros)
-      addr_next &= ~7u;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr_next ^ grp->off_out[c])) = r[c];
-      if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
-    } else if (!idle) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ grp->off[c])) = r[c];
-    }
-    addr = addr_next;
-    __syncthreads();
-  }
+  tile2_groups(sb, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
 
   if (MEASURE) {
     if (f.dbg & 2) return;

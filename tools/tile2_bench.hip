@@ -64,6 +64,8 @@ struct Args {
   int outer_bits[32];
   int gbits[8][4];     // per group: 4 tile-local bits, ascending
   int use_asm;
+  int ro;   // read-only pass: no stores, one float per workgroup and tile written instead
+  float *sink;
 };
 
 template <bool ASM>
@@ -186,6 +188,14 @@ __global__ void __launch_bounds__(256) k_t2(const Args a) {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sw(jl + u * 512u) >> 1];
+    if (a.ro) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+      if ((tid & 63) == 0) a.sink[((size_t)b * gridDim.x + blockIdx.x) * 4 + (tid >> 6)] = acc;
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const vf4 w = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -219,6 +229,7 @@ __global__ void __launch_bounds__(256) k_t2p(const Args a, uint32_t n_work) {
   };
   uint32_t w = blockIdx.x;
   if (w >= n_work) return;
+  float racc = 0.f;
   float4 v[8];
   float2 *cur = tile_ptr(w);
 #pragma unroll
@@ -261,14 +272,26 @@ __global__ void __launch_bounds__(256) k_t2p(const Args a, uint32_t n_work) {
       for (int c = 0; c < 16; ++c) reinterpret_cast<u64 *>(s)[bs ^ off[c]] = r[c];
       __syncthreads();
     }
+    if (a.ro) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float4 o = reinterpret_cast<float4 *>(s)[sw(jl + u * 512u) >> 1];
-      const vf4 x = {o.x, o.y, o.z, o.w};
-      __builtin_nontemporal_store(x, reinterpret_cast<vf4 *>(cur + uoff[u]));
+      for (int u = 0; u < 8; ++u) {
+        const float4 o = reinterpret_cast<float4 *>(s)[sw(jl + u * 512u) >> 1];
+        racc += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 o = reinterpret_cast<float4 *>(s)[sw(jl + u * 512u) >> 1];
+        const vf4 x = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<vf4 *>(cur + uoff[u]));
+      }
     }
     cur = nxt;
     __syncthreads();
+  }
+  if (a.ro) {
+    for (int o = 32; o > 0; o >>= 1) racc += __shfl_down(racc, o, 64);
+    if ((tid & 63) == 0) a.sink[(size_t)blockIdx.x * 4 + (tid >> 6)] = racc;
   }
 }
 
@@ -286,12 +309,13 @@ int main(int argc, char **argv) {
   CHK(hipFuncSetAttribute((const void *)k_t2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   CHK(hipFuncSetAttribute((const void *)k_t2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   const int wgs = argc > 3 ? atoi(argv[3]) : 1280;
+  float *dsink; CHK(hipMalloc(&dsink, (size_t)B * 4096 * 4 * sizeof(float)));
   CHK(hipFuncSetAttribute((const void *)k_t2p, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  const int modes[] = {3, 14, 1, 11};
+  const int modes[] = {21, 22, 1};
   for (int use_asm : modes)
     for (int G = 0; G <= 4; ++G) {
       Args a{};
-      a.states = d; a.n = n; a.T = T; a.L = L; a.G = G; a.use_asm = use_asm;
+      a.states = d; a.n = n; a.T = T; a.L = L; a.G = G; a.use_asm = use_asm >= 20 ? use_asm - 20 : use_asm; a.ro = use_asm >= 20; a.sink = dsink;
       // tile: low L bits + the (T - L) bits from 12 upwards
       int nt = 0, no = 0;
       for (int p = 0; p < n; ++p) {
@@ -349,8 +373,8 @@ int main(int argc, char **argv) {
       hipEvent_t e0, e1;
       CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
       auto launch = [&]() {
-        if (use_asm == 2) hipLaunchKernelGGL(k_t2p, dim3(wgs), dim3(256), lds, 0, a, (uint32_t)(grid.x * grid.y));
-        else if (use_asm) hipLaunchKernelGGL(k_t2<true>, grid, dim3(256), lds, 0, a);
+        if (a.use_asm == 2) hipLaunchKernelGGL(k_t2p, dim3(wgs), dim3(256), lds, 0, a, (uint32_t)(grid.x * grid.y));
+        else if (a.use_asm) hipLaunchKernelGGL(k_t2<true>, grid, dim3(256), lds, 0, a);
         else hipLaunchKernelGGL(k_t2<false>, grid, dim3(256), lds, 0, a);
       };
       launch();
