@@ -262,3 +262,15 @@ def test_fast_tile_kernel_equals_generic_kernel_on_cx_rich_tapes():
                 torch.view_as_real(b) if b.is_complex() else b).abs().max()) < 2e-6, (trial, meas)
         got = fast.run(ang, "state").cpu().numpy()[0]
         assert np.abs(got - want).max() < 2e-6, (trial, np.abs(got - want).max())
+        # the same kernel with known-zero tracking on (partial loads, zero tiles, compacted grids,
+        # idle work items): default engine against the oracle, state and <Z>
+        geo = N.plan_flags(tile_bits=T, low_bits=L)
+        for extra in (0, N.PLAN_NO_ABSORB):
+            sp = N.Plan(ops, n, max(1, len(angles)), consts, geo | extra)
+            got = sp.run(ang, "state").cpu().numpy()[0]
+            assert np.abs(got - want).max() < 2e-6, (trial, extra, np.abs(got - want).max())
+            ez = sp.run(ang, "expval", list(range(n))).cpu().numpy()[0]
+            p = np.abs(want) ** 2
+            idx = np.arange(1 << n)
+            wz = np.array([np.sum(p * (1 - 2 * ((idx >> (n - 1 - q)) & 1))) for q in range(n)])
+            assert np.abs(ez - wz).max() < 2e-6, (trial, extra, np.abs(ez - wz).max())
