@@ -42,6 +42,45 @@ __device__ __forceinline__ uint32_t ins0(uint32_t i, int p) {
       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)       \
       : "s"(m00), "s"(m01), "s"(m10), "s"(m11))
 
+
+#define PAIR4(a0, a1, a2, a3, a4, a5, a6, a7)                                                    \
+  asm volatile(                                                                                  \
+      "v_pk_mul_f32 %8, %16, %0 op_sel_hi:[0,1]\n\t"                                             \
+      "v_pk_mul_f32 %9, %18, %0 op_sel_hi:[0,1]\n\t"                                             \
+      "v_pk_mul_f32 %10, %16, %2 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_mul_f32 %11, %18, %2 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_mul_f32 %12, %16, %4 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_mul_f32 %13, %18, %4 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_mul_f32 %14, %16, %6 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_mul_f32 %15, %18, %6 op_sel_hi:[0,1]\n\t"                                            \
+      "v_pk_fma_f32 %8, %16, %0, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %9, %18, %0, %9 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %10, %16, %2, %10 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %11, %18, %2, %11 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %12, %16, %4, %12 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %13, %18, %4, %13 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %14, %16, %6, %14 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %15, %18, %6, %15 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"       \
+      "v_pk_fma_f32 %8, %17, %1, %8 op_sel_hi:[0,1,1]\n\t"                                       \
+      "v_pk_fma_f32 %9, %19, %1, %9 op_sel_hi:[0,1,1]\n\t"                                       \
+      "v_pk_fma_f32 %10, %17, %3, %10 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %11, %19, %3, %11 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %12, %17, %5, %12 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %13, %19, %5, %13 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %14, %17, %7, %14 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %15, %19, %7, %15 op_sel_hi:[0,1,1]\n\t"                                     \
+      "v_pk_fma_f32 %0, %17, %1, %8 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %1, %19, %1, %9 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"         \
+      "v_pk_fma_f32 %2, %17, %3, %10 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      "v_pk_fma_f32 %3, %19, %3, %11 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      "v_pk_fma_f32 %4, %17, %5, %12 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      "v_pk_fma_f32 %5, %19, %5, %13 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      "v_pk_fma_f32 %6, %17, %7, %14 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      "v_pk_fma_f32 %7, %19, %7, %15 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"        \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),          \
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)   \
+      : "s"(m00), "s"(m01), "s"(m10), "s"(m11))
+
 template <int TB>
 __device__ __forceinline__ void gate16(u64 (&a)[16], u64 m00, u64 m01, u64 m10, u64 m11) {
   u64 t0, t1, t2, t3;
@@ -51,8 +90,16 @@ __device__ __forceinline__ void gate16(u64 (&a)[16], u64 m00, u64 m01, u64 m10, 
 #pragma unroll
   for (int c = 0; c < 16; ++c)
     if (!(c & S)) idx[k++] = c;
+#ifdef QUAD
+  u64 t4, t5, t6, t7;
+#pragma unroll
+  for (int q = 0; q < 8; q += 4)
+    PAIR4(a[idx[q]], a[idx[q] | S], a[idx[q + 1]], a[idx[q + 1] | S], a[idx[q + 2]], a[idx[q + 2] | S],
+          a[idx[q + 3]], a[idx[q + 3] | S]);
+#else
 #pragma unroll
   for (int q = 0; q < 8; q += 2) PAIR2(a[idx[q]], a[idx[q] | S], a[idx[q + 1]], a[idx[q + 1] | S]);
+#endif
 }
 
 struct Args {
@@ -64,6 +111,7 @@ struct Args {
   int outer_bits[32];
   int gbits[8][4];     // per group: 4 tile-local bits, ascending
   int use_asm;
+  int mix_mod, mix_mfma;  // modes 5 / 15: (tile + group) % mix_mod < mix_mfma -> matrix-core group
   int ro;   // read-only pass: no stores, one float per workgroup and tile written instead
   float *sink;
 };
@@ -109,7 +157,8 @@ __global__ void __launch_bounds__(256) k_t2(const Args a) {
                   ((c & 4) ? (1u << b2) : 0u) | ((c & 8) ? (1u << b3) : 0u));
     const uint32_t bs = sw(ins0(ins0(ins0(ins0(tid, b0), b1), b2), b3));
     const u64 *m = reinterpret_cast<const u64 *>(mrow + g * 32);
-    if (ASM && (a.use_asm == 3 || a.use_asm == 14)) {
+    const bool mixed_mfma = (a.use_asm == 15 || a.use_asm == 5) && (((blockIdx.x + g) % a.mix_mod) < a.mix_mfma);
+    if (ASM && (a.use_asm == 3 || a.use_asm == 14 || mixed_mfma)) {
       // matrix-core group: the 4 gates merged into one 16x16 complex operator = 32x32 real
       // matrix R; out[32 reals x 32 items] = R . in via 16 x v_mfma_f32_32x32x2_f32 per block of
       // 32 work items (two blocks per wave)
@@ -311,11 +360,11 @@ int main(int argc, char **argv) {
   const int wgs = argc > 3 ? atoi(argv[3]) : 1280;
   float *dsink; CHK(hipMalloc(&dsink, (size_t)B * 4096 * 4 * sizeof(float)));
   CHK(hipFuncSetAttribute((const void *)k_t2p, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  const int modes[] = {21, 22, 1};
+  const int modes[] = {11, 14, 15, 1, 5};
   for (int use_asm : modes)
     for (int G = 0; G <= 4; ++G) {
       Args a{};
-      a.states = d; a.n = n; a.T = T; a.L = L; a.G = G; a.use_asm = use_asm >= 20 ? use_asm - 20 : use_asm; a.ro = use_asm >= 20; a.sink = dsink;
+      a.states = d; a.n = n; a.T = T; a.L = L; a.G = G; a.use_asm = use_asm >= 20 ? use_asm - 20 : use_asm; a.ro = use_asm >= 20; a.sink = dsink; a.mix_mod = getenv("MIX_MOD") ? atoi(getenv("MIX_MOD")) : 3; a.mix_mfma = getenv("MIX_MFMA") ? atoi(getenv("MIX_MFMA")) : 1;
       // tile: low L bits + the (T - L) bits from 12 upwards
       int nt = 0, no = 0;
       for (int p = 0; p < n; ++p) {
