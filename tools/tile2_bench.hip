@@ -1,7 +1,19 @@
-// Stand-alone ceiling experiment for the dense tile pass (round 2): load a 2^T tile -> LDS,
-// G register-tile groups of four dense 2x2 gates each (matrices in SGPRs, packed-fp32 asm with
-// two interleaved pairs, no per-gate dispatch), store.  n = 24, B states, in place.
-//   hipcc -O3 --offload-arch=gfx950 tools/tile2_bench.hip -o /tmp/tile2_bench && /tmp/tile2_bench
+// Stand-alone experiments for the dense tile pass (round 2), n = 24, B states, in place:
+// load a 2^12 tile -> LDS, G register-tile groups of four dense 2x2 gates each, store.
+//   hipcc -O3 --offload-arch=gfx950 tools/tile2_bench.hip -o tools/tile2_bench
+//   tools/tile2_bench [B=32] [L=5] [workgroups of the persistent variant=1280]     (-DQUAD: 4 pairs interleaved)
+// The list `modes` in main() picks what runs; a mode is printed as `asm=<mode>`:
+//    0  hipcc's version of the gate arithmetic (matrices from a uniform pointer)
+//    1  packed-fp32 asm gate blocks, matrices in SGPRs (what k_tile2 uses)
+//    2  the same in a persistent workgroup with the next tile prefetched in registers (k_t2p)
+//    3  matrix core: the group's gates merged into a 32x32 real operator, v_mfma_f32_32x32x2_f32
+//    5  mixed: (tile + group) % MIX_MOD < MIX_MFMA -> matrix core, else vector asm
+//   11 / 14 / 15  = 1 / 3 / 5 without HBM traffic (compute only)
+//   12  gather + scatter only (no gates);  13  gates only (no LDS traffic inside the groups)
+//   21 / 22  = 1 / 2 as a read-only pass (no stores, one float per wave written)
+// Every mode checks state 0 against a host reference (max|err|) except the compute-only ones,
+// whose input is synthetic.  Results: profiles/r02_mfma_ab_tile2_bench.txt,
+// r02_group_cost_split.txt, r02_mfma_mixed_concurrency.txt; DESIGN.md section 9b.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
