@@ -3699,7 +3699,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   // fast path: all-live stage of (controlled) 2x2 gates -- table-addressed groups, CX folded
   // into the LDS layout, SGPR matrices (k_tile2)
   static const bool no_fast = std::getenv("QMLE_NO_FAST_TILE") != nullptr;
-  if (!no_fast && st.fast_ok && st.T < p->n && threads == (1 << (st.T - 4)) && meas != TM_EXPVAL) {
+  // (k_tile2 addresses a tile with 32-bit byte offsets inside one state: n <= 28)
+  if (!no_fast && st.fast_ok && st.T < p->n && p->n <= 28 && threads == (1 << (st.T - 4)) &&
+      meas != TM_EXPVAL) {
     if (first_use_on_device(2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -5017,7 +5019,7 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
         else a.outer_bits[no++] = (int8_t)bit;
       }
       static const bool mw_old = std::getenv("QMLE_MW_OLD") != nullptr;
-      if (!mw_old) {
+      if (!mw_old && n <= 28) {  // k_mw_tile2: 32-bit byte offsets inside one state
         // >= 1 GiB per launch: stream past the caches
         const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
         const size_t lds2 = (size_t)8 << kMwT;

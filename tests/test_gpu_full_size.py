@@ -274,3 +274,27 @@ def test_fast_tile_kernel_equals_generic_kernel_on_cx_rich_tapes():
             idx = np.arange(1 << n)
             wz = np.array([np.sum(p * (1 - 2 * ((idx >> (n - 1 - q)) & 1))) for q in range(n)])
             assert np.abs(ez - wz).max() < 2e-6, (trial, extra, np.abs(ez - wz).max())
+
+
+def test_n29_falls_back_to_64_bit_addressing():
+    """n = 29 (4 GiB per state): the fast tile kernel and k_mw_tile2 address a tile with 32-bit
+    byte offsets, valid up to n = 28; beyond that the generic kernels must take over.  Product
+    state through the fused tile passes: <Z_w> = cos(theta_w) on every wire, Meyer-Wallach 0."""
+    N = _N()
+    n = 29
+    if torch.cuda.mem_get_info()[0] < 16 * (1 << 30):
+        pytest.skip("needs ~10 GiB of free HBM")
+    theta = np.random.default_rng(29).uniform(0.2, 2.9, n)
+    st = _product_state(n, theta)
+    ez = N.expval_z(st, list(range(n))).cpu().numpy()[0]
+    assert np.abs(ez - np.cos(theta)).max() < 3e-6
+    q = N.meyer_wallach(st)
+    assert abs(float(q[0])) < 2e-4
+    # one gate on the top and on the bottom wire through the streaming kernel
+    _apply(st, n, "RX", [0], 0.7)
+    _apply(st, n, "RX", [n - 1], 0.4)
+    ez = N.expval_z(st, [0, n - 1]).cpu().numpy()[0]
+    assert abs(ez[0] - np.cos(theta[0]) * np.cos(0.7)) < 3e-6
+    assert abs(ez[1] - np.cos(theta[n - 1]) * np.cos(0.4)) < 3e-6
+    del st
+    torch.cuda.empty_cache()
