@@ -129,6 +129,8 @@ struct Stage {
   // fast tile path: every gate is a (<= 1 control) 2x2 and T is in k_tile2's range
   bool fast_ok = false;
   int fast_begin = 0, fast_end = 0;  // range in qmle_plan::groups2
+  uint32_t fast_gtab = 0;            // index into qmle_plan::tbl2: per-thread global byte offset of
+                                     // the lane's first float4 inside the tile (k_tile2 prologue)
 };
 
 struct StageProfile {  // optional HIP-event timing of every stage launch (bench.py)

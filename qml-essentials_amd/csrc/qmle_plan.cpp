@@ -417,6 +417,16 @@ static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<Lowered
     }
   }
   (void)ops2_mark; (void)tbl_mark;
+  // global byte offset of every lane's first float4 inside the tile: local index 2 t with its
+  // bits deposited at the tile's global positions (bits below L are contiguous)
+  st.fast_gtab = (uint32_t)p->tbl2.size();
+  for (uint32_t t = 0; t < nt; ++t) {
+    const uint32_t jl = 2u * t;
+    uint32_t g = 0;
+    for (int j = 0; j <= T - 4; ++j)
+      if (jl & (1u << j)) g |= 1u << st.tile_bits[j];
+    p->tbl2.push_back(g << 3);
+  }
   st.fast_end = (int)p->groups2.size();
   st.fast_ok = true;
 }

@@ -501,6 +501,10 @@ struct TileArgs {
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
+  // TM_EXPVAL_PARTIAL, full-size tiles: where thread q finds <Z> of global bit position q among the
+  // per-wave sums: 0..5 lane bit, 6..9 iteration bit, 10 total (q = 32), 16 + k wave-index bit k,
+  // 32 + i outer position i (sign = tile-index bit i), 64 unused
+  uint8_t qsrc[QMLE_MAX_QUBITS + 1];
 };
 
 __device__ __forceinline__ void sort3(int &a, int &b, int &c) {
@@ -714,6 +718,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
                 ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
     const uint32_t cnt = 1u << T;
     if (cnt == 16u * nt) {
+      const int qsrc = tid <= QMLE_MAX_QUBITS ? (int)a.qsrc[tid] : 64;
       // |amplitude|^2 of the 16 elements a lane owns, then a pruned Walsh-Hadamard butterfly over
       // the 4 iteration bits: the total and the four single-bit signed sums in 41 additions
       float pr[16];
@@ -745,25 +750,22 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
         for (int j = 0; j < 11; ++j) red[w * 11 + j] = v[j];
       }
       tile_sync<RAW>();
-      float *row = red + 240;  // 33 floats
-      const int tb = T - 4;    // thread bits: 0..5 lane, 6..tb-1 wave index
-      if (tid < 15) {
+      // thread q < n assembles <Z> of global bit position q itself (qsrc[q], filled on the host:
+      // which of the 11 per-wave sums, or which tile-index bit for an outer position), thread 32
+      // the total: no staging row, no serial walk over the position arrays
+      if (tid <= QMLE_MAX_QUBITS) {
+        const int src = qsrc;  // loaded before the reduction (a per-thread read of the arguments)
         float r = 0.f;
-        if (tid < 6 || tid >= 10) {  // lane bits, h0..h3, total: plain sums over the waves
-          const int k = tid < 6 ? tid : tid - 4;
-          for (int i = 0; i < nw; ++i) r += red[i * 11 + k];
-        } else {                     // wave-index bit (tid - 6)
-          for (int i = 0; i < nw; ++i) r += ((i >> (tid - 6)) & 1) ? -red[i * 11 + 10] : red[i * 11 + 10];
+        if (src < 16) {                     // lane bit 0..5 -> sums 0..5; iteration bit -> 6..9; total -> 10
+          for (int i = 0; i < nw; ++i) r += red[i * 11 + src];
+        } else if (src < 32) {              // wave-index bit (src - 16)
+          for (int i = 0; i < nw; ++i) r += ((i >> (src - 16)) & 1) ? -red[i * 11 + 10] : red[i * 11 + 10];
+        } else if (src < 64) {              // outer position: tile-index bit (src - 32)
+          for (int i = 0; i < nw; ++i) r += red[i * 11 + 10];
+          if ((tile >> (src - 32)) & 1u) r = -r;
         }
-        if (tid < 10) { if (tid < tb) row[a.tile_bits[tid]] = r; }
-        else if (tid < 14) row[a.tile_bits[tb + tid - 10]] = r;
-        else {
-          row[QMLE_MAX_QUBITS] = r;
-          for (int i = 0; i < a.n - T; ++i) row[a.outer_bits[i]] = ((tile >> i) & 1u) ? -r : r;
-        }
+        po[tid] = r;                        // src >= 64: unused position -> 0
       }
-      tile_sync<RAW>();
-      if (tid <= QMLE_MAX_QUBITS) po[tid] = (tid < a.n || tid == QMLE_MAX_QUBITS) ? row[tid] : 0.f;
     } else {  // small tiles (forced geometries in tests): one reduction per local bit
       float acc_t = 0.f;
       for (int j = 0; j < T; ++j) {
@@ -1141,22 +1143,69 @@ struct Tile2Args {
   const LoweredOp *ops;     // qmle_plan::ops2 on the device
   const uint32_t *tbl;      // qmle_plan::tbl2 on the device
   int n_groups;
+  int n_ops_stage;          // ops of all the stage's groups (one contiguous stream in `ops`)
   int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue
+  uint32_t gtab;            // index into tbl: per-lane global byte offset inside the tile
+  uint32_t uoff8[8];        // byte offsets of the lane's 8 float4 (the tile's top three bits)
+  // tile index -> amplitude offset of the tile: the outer bit positions as <= 6 contiguous runs
+  // (base = sum_r ((tile >> run_off[r]) & run_mask[r]) << run_pos[r]); n_runs < 0: generic loop
+  int n_runs;
+  uint32_t run_off[6], run_mask[6], run_pos[6];
+  // the same for the lane's own offset: local bits 1 .. T-4 of index 2 tid -> global positions,
+  // <= 4 runs (n_in_runs < 0: read it from the table at gtab)
+  int n_in_runs;
+  uint32_t in_off[4], in_mask[4], in_pos[4];
 };
 
-// All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this
-// work item's table entry of the first group, already loaded.  Ends with a barrier.
+__device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Args &f, uint32_t tile) {
+  if (f.n_runs < 0) return tile_base(a, tile);
+  uint64_t base = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+    if (r < f.n_runs) base |= (uint64_t)((tile >> f.run_off[r]) & f.run_mask[r]) << f.run_pos[r];
+  return base;
+}
+
+// All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this work item's
+// table entry of the first group, already loaded.  Ends with a barrier.
+// The stage's ops are one contiguous stream (groups are emitted in order), so the scalar-load
+// pipeline -- two descriptors and one matrix ahead of the gate being applied -- runs ACROSS group
+// boundaries: a group's first gate never waits for descriptor -> matrix, and a group's 16 slot
+// offsets are the XOR closure of four words fetched during the previous group.
 __device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile2Args &f,
                                              const u64 QMLE_CONSTANT *mrow, int tid, bool use_skip) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
+  if (f.n_groups <= 0) return;
+  // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats)
+  const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
+  const int last = f.n_ops_stage > 0 ? f.n_ops_stage - 1 : 0;
+  int k = 0;  // index into the stage's op stream
+  v4u w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+  Mat2S M0 = {0ull, 0ull, 0ull, 0ull};
+  if (f.n_ops_stage > 0) {  // (a stage of layout changes only has no op and maybe no matrix row)
+    w0 = op[0];
+    w1 = op[last < 1 ? last : 1];
+    const u64 QMLE_CONSTANT *m = mrow + (w0.z >> 1);
+    M0 = {m[0], m[1], m[2], m[3]};
+  }
+  // header word (n_ops | relayout << 16) and the four basis offsets of the first group
+  uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
+  uint32_t o1 = grp->off[1], o2 = grp->off[2], o4 = grp->off[4], o8 = grp->off[8];
   for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
+    const int n_ops = (int)(hdr & 0xffffu);
+    const bool relayout = ((hdr >> 16) & 0xffu) != 0;
+    uint32_t off[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      off[c] = ((c & 1) ? o1 : 0u) ^ ((c & 2) ? o2 : 0u) ^ ((c & 4) ? o4 : 0u) ^ ((c & 8) ? o8 : 0u);
     // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point
     const bool idle = use_skip && (addr & 1u);
     addr &= ~7u;
     u64 r[16];
     if (!idle) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ grp->off[c]));
+      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ off[c]));
     } else {
 #pragma unroll
       for (int c = 0; c < 16; ++c) r[c] = 0ull;
@@ -1164,52 +1213,46 @@ __device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile
     // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
     // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
     asm volatile("" : "+v"(addr));
-    // scalar loads are dword-wide: header fields are unpacked from whole words
-    const uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
-    const int n_ops = (int)(hdr & 0xffffu);
-    const bool relayout = ((hdr >> 16) & 0xffu) != 0;
+    const bool more = gi + 1 < f.n_groups;
     uint32_t addr_next = 0;
     if (relayout) addr_next = f.tbl[grp->tbl_out + tid];
-    else if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const v4u QMLE_CONSTANT *op = reinterpret_cast<const v4u QMLE_CONSTANT *>(as_constant(f.ops) + grp->op_begin);
-    // LoweredOp words: .y >> 24 = dispatch code, .z = matrix offset (floats).  Scalar loads run
-    // two descriptors and one matrix ahead of the gate being applied, so neither latency (the
-    // matrix address depends on the descriptor) is ever waited for inside the gate loop.
+    else if (more) addr_next = f.tbl[grp[1].tbl + tid];
+    // next group's header and basis offsets: in flight while this group's gates run
+    const Group2 QMLE_CONSTANT *nx = more ? grp + 1 : grp;
+    const uint32_t hdr_n = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(nx)[1];
+    const uint32_t n1 = nx->off[1], n2 = nx->off[2], n4 = nx->off[4], n8 = nx->off[8];
     // (idle work items skip the arithmetic; the branch is per lane, the loads are per wave)
-    if (n_ops > 0) {
-      v4u w0 = op[0];
-      v4u w1 = op[n_ops > 1 ? 1 : 0];
-      const u64 QMLE_CONSTANT *m = mrow + (w0.z >> 1);
-      Mat2S M0 = {m[0], m[1], m[2], m[3]};
-      for (int k = 0; k < n_ops; ++k) {
-        // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
-        // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
-        asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
-        const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
-        const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
-        const v4u w2 = op[k + 2 < n_ops ? k + 2 : n_ops - 1];
-        if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
-        w0 = w1;
-        w1 = w2;
-        M0 = Mn;
-      }
+    for (int j = 0; j < n_ops; ++j, ++k) {
+      // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
+      // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
+      asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
+      const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
+      const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
+      const v4u w2 = op[k + 2 < last ? k + 2 : last];
+      if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
+      w0 = w1;
+      w1 = w2;
+      M0 = Mn;
     }
     if (relayout) {
       __syncthreads();  // every gather of the group is done: slots may change owners
       // (an idle work item still owns 16 slots of the new layout: it stores its zeros)
       addr_next &= ~7u;
+      const uint32_t q1 = grp->off_out[1], q2 = grp->off_out[2], q4 = grp->off_out[4], q8 = grp->off_out[8];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr_next ^ grp->off_out[c])) = r[c];
-      if (gi + 1 < f.n_groups) addr_next = f.tbl[grp[1].tbl + tid];
+      for (int c = 0; c < 16; ++c)
+        *reinterpret_cast<u64 *>(sb + (addr_next ^ ((c & 1) ? q1 : 0u) ^ ((c & 2) ? q2 : 0u) ^
+                                       ((c & 4) ? q4 : 0u) ^ ((c & 8) ? q8 : 0u))) = r[c];
+      if (more) addr_next = f.tbl[grp[1].tbl + tid];
     } else if (!idle) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ grp->off[c])) = r[c];
+      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ off[c])) = r[c];
     }
     addr = addr_next;
+    hdr = hdr_n;
+    o1 = n1; o2 = n2; o4 = n4; o8 = n8;
     __syncthreads();
   }
-
 }
 
 template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own
@@ -1234,23 +1277,31 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     }
   }
   const size_t D = (size_t)1 << a.n;
-  const uint64_t base = tile_base(a, tile);
+  const uint64_t base = tile2_base(a, f, tile);
   // global addresses: wave-uniform 64-bit base (SGPRs) + one 32-bit byte offset per lane
   char *st = reinterpret_cast<char *>(a.states + (size_t)b * D + base);
   // a lane's 8 float4: local index j = 2 (tid + u nt): bit 0 rides in the access, bits 1..T-4
   // come from tid, the top three from u (wave-uniform)
+  // (both come precomputed: indexing the int8 position arrays of the kernel arguments with
+  // run-time indices costs a chain of vector loads in front of the tile's own loads)
   const uint32_t jl = 2u * tid;
-  uint32_t goff = jl & ((1u << a.L) - 1u);
-  for (int p = a.L; p <= T - 4; ++p) goff |= ((jl >> p) & 1u) << a.tile_bits[p];
+  uint32_t goff8;  // < 2^31 for n <= 28
+  if (f.n_in_runs < 0) {
+    goff8 = f.tbl[f.gtab + tid];
+  } else {
+    uint32_t g = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < f.n_in_runs) g |= ((jl >> f.in_off[r]) & f.in_mask[r]) << f.in_pos[r];
+    goff8 = g << 3;
+  }
   uint32_t uoff[8], soff[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    uoff[u] = (((u & 1u) << a.tile_bits[T - 3]) | (((u >> 1) & 1u) << a.tile_bits[T - 2]) |
-               (((u >> 2) & 1u) << a.tile_bits[T - 1])) << 3;  // bytes
+    uoff[u] = f.uoff8[u];
     soff[u] = sw((uint32_t)u << (T - 3)) >> 1;  // float4 index; sw() is linear over XOR
   }
   const uint32_t sl = sw(jl) >> 1;
-  const uint32_t goff8 = goff << 3;  // < 2^31 for n <= 28
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0) {
     // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
@@ -3545,6 +3596,14 @@ static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *stat
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
   if (obs_masks) std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
   a.op_begin = st.op_begin;
+  for (int q = 0; q <= QMLE_MAX_QUBITS; ++q) a.qsrc[q] = 64;
+  a.qsrc[QMLE_MAX_QUBITS] = 10;
+  if (st.T >= 10) {  // element e = tid + it * 2^(T-4): bits 0..5 lane, 6..T-5 wave, T-4..T-1 iteration
+    const int tb = st.T - 4;
+    for (int j = 0; j < st.T; ++j)
+      a.qsrc[(int)st.tile_bits[j]] = (uint8_t)(j < 6 ? j : j < tb ? 16 + (j - 6) : 6 + (j - tb));
+    for (int i = 0; i < p->n - st.T; ++i) a.qsrc[(int)st.outer_bits[i]] = (uint8_t)(32 + i);
+  }
   if (from_zero && st.zero_in && !init_zero) {
     for (int j = 0; j < st.T; ++j)
       if (st.zero_in & (1u << st.tile_bits[j])) a.zin_local |= 1u << j;
@@ -3717,6 +3776,45 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     f.ops = p->dev.d_ops2;
     f.tbl = p->dev.d_tbl2;
     f.n_groups = st.fast_end - st.fast_begin;
+    f.n_ops_stage = 0;
+    for (int g = st.fast_begin; g < st.fast_end; ++g) f.n_ops_stage += p->groups2[g].n_ops;
+    f.gtab = st.fast_gtab;
+    {  // outer bit positions (ascending) as contiguous runs
+      int r = 0;
+      const int n_outer = p->n - st.T;
+      for (int i = 0; i < n_outer && r <= 6;) {
+        int len = 1;
+        while (i + len < n_outer && st.outer_bits[i + len] == st.outer_bits[i] + len) ++len;
+        if (r < 6) {
+          f.run_off[r] = (uint32_t)i;
+          f.run_mask[r] = len >= 32 ? 0xffffffffu : ((1u << len) - 1u);
+          f.run_pos[r] = (uint32_t)st.outer_bits[i];
+        }
+        ++r;
+        i += len;
+      }
+      f.n_runs = r <= 6 ? r : -1;
+      for (int k = r < 6 ? r : 6; k < 6; ++k) f.run_off[k] = f.run_mask[k] = f.run_pos[k] = 0;
+      // local bits 0 .. T-4 (bit 0 of 2 tid is always clear, harmless) as runs
+      r = 0;
+      const int top = st.T - 4;
+      for (int j = 0; j <= top && r <= 4;) {
+        int len = 1;
+        while (j + len <= top && st.tile_bits[j + len] == st.tile_bits[j] + len) ++len;
+        if (r < 4) {
+          f.in_off[r] = (uint32_t)j;
+          f.in_mask[r] = (1u << len) - 1u;
+          f.in_pos[r] = (uint32_t)st.tile_bits[j];
+        }
+        ++r;
+        j += len;
+      }
+      f.n_in_runs = r <= 4 ? r : -1;
+      for (int k = r < 4 ? r : 4; k < 4; ++k) f.in_off[k] = f.in_mask[k] = f.in_pos[k] = 0;
+    }
+    for (unsigned u = 0; u < 8; ++u)
+      f.uoff8[u] = (((u & 1u) << st.tile_bits[st.T - 3]) | (((u >> 1) & 1u) << st.tile_bits[st.T - 2]) |
+                    (((u >> 2) & 1u) << st.tile_bits[st.T - 1])) << 3;
     static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
     f.dbg = dbg;
     if (dbg & 1) f.n_groups = 0;
