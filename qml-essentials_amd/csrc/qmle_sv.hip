@@ -3062,6 +3062,13 @@ struct MwArgs {
   int n;
   int8_t tile_bits[kMwT];
   int8_t outer_bits[QMLE_MAX_QUBITS];
+  // k_mw_tile2: the same positions as contiguous runs (scalar registers instead of indexed
+  // reads of the byte arrays): tile index -> base, lane index -> offset, u = 0..7 -> offset
+  int n_runs;
+  uint32_t run_off[4], run_mask[4], run_pos[4];
+  int n_in_runs;
+  uint32_t in_off[3], in_mask[3], in_pos[3];
+  uint32_t uo8[8];
 };
 
 // LOW: also the sums of the 4 low bits, which every pass stages but only the first one reports
@@ -3164,21 +3171,23 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) 
   float *red = reinterpret_cast<float *>(smem4);  // reduction scratch aliases the tile
   const int tid = threadIdx.x, b = blockIdx.y;
   const uint32_t jl = 2u * tid;  // local bits 1..8 from tid (bits 0..3 contiguous), 9..11 from u
-  uint32_t goff = jl & ((1u << kMwL) - 1u);
-  for (int p = kMwL; p <= kMwT - 4; ++p) goff |= ((jl >> p) & 1u) << a.tile_bits[p];
+  uint32_t goff = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (r < a.n_in_runs) goff |= ((jl >> a.in_off[r]) & a.in_mask[r]) << a.in_pos[r];
   const uint32_t goff8 = goff << 3;
   uint32_t uo[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    uo[u] = (((u & 1u) << a.tile_bits[kMwT - 3]) | (((u >> 1) & 1u) << a.tile_bits[kMwT - 2]) |
-             (((u >> 2) & 1u) << a.tile_bits[kMwT - 1])) << 3;
+  for (int u = 0; u < 8; ++u) uo[u] = a.uo8[u];
   const uint32_t sl = sw(jl) >> 1;
   const uint32_t tidv = (uint32_t)tid;
   // a workgroup walks 2^q tiles: the next tile's 8 float4 per lane are in flight (registers)
   // while the gathers run on the current one, and the 37 sums stay per work item until the end
   auto tile_ptr = [&](uint32_t tile) {
     uint64_t base = 0;
-    for (int i = 0; i < a.n - kMwT; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < a.n_runs) base |= (uint64_t)((tile >> a.run_off[r]) & a.run_mask[r]) << a.run_pos[r];
     return reinterpret_cast<const char *>(a.states + ((size_t)b << a.n) + base);
   };
   const uint32_t tile0 = blockIdx.x << q, n_it = 1u << q;
@@ -5117,6 +5126,30 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
         else a.outer_bits[no++] = (int8_t)bit;
       }
       static const bool mw_old = std::getenv("QMLE_MW_OLD") != nullptr;
+      {  // position arrays as runs (tile = 4 low bits + one run of 8: <= 2 outer runs, <= 2 inner)
+        int r = 0;
+        for (int i = 0; i < no;) {
+          int len = 1;
+          while (i + len < no && a.outer_bits[i + len] == a.outer_bits[i] + len) ++len;
+          if (r < 4) { a.run_off[r] = (uint32_t)i; a.run_mask[r] = (1u << len) - 1u; a.run_pos[r] = (uint32_t)a.outer_bits[i]; }
+          ++r;
+          i += len;
+        }
+        a.n_runs = r;
+        int q = 0;
+        for (int j = 0; j <= kMwT - 4;) {
+          int len = 1;
+          while (j + len <= kMwT - 4 && a.tile_bits[j + len] == a.tile_bits[j] + len) ++len;
+          if (q < 3) { a.in_off[q] = (uint32_t)j; a.in_mask[q] = (1u << len) - 1u; a.in_pos[q] = (uint32_t)a.tile_bits[j]; }
+          ++q;
+          j += len;
+        }
+        a.n_in_runs = q;
+        for (unsigned u = 0; u < 8; ++u)
+          a.uo8[u] = (((u & 1u) << a.tile_bits[kMwT - 3]) | (((u >> 1) & 1u) << a.tile_bits[kMwT - 2]) |
+                      (((u >> 2) & 1u) << a.tile_bits[kMwT - 1])) << 3;
+        if (r > 4 || q > 3) return QMLE_ERR_UNSUPPORTED;  // cannot happen with this tile shape
+      }
       if (!mw_old && n <= 28) {  // k_mw_tile2: 32-bit byte offsets inside one state
         // >= 1 GiB per launch: stream past the caches
         const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
