@@ -3161,8 +3161,9 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t
 // path instead of 63 LDS-crossbar exchanges, and 2^q tiles per workgroup with the next tile in
 // flight in registers (one reduction and one 37-float row per 16 tiles at n = 28).
 // Measured (MI355X, n = 28, three reads of 2 GiB): 1.93 ms (k_mw_tile + 2 x k_mw_direct) ->
-// 2.01 ms one tile per workgroup -> 1.80 ms at q = 4; hipcc gives the loop form 180-204 VGPRs
-// (2 waves per SIMD), and capping it at 128 spills (5 ms).  See DESIGN.md section 5 for why two
+// 2.01 ms one tile per workgroup -> 1.80 ms at q = 4 -> 1.41 ms with the bit positions as runs
+// in scalar registers (MwArgs::run_*) instead of indexed byte-array reads; hipcc gives the loop
+// form 180-204 VGPRs (2 waves per SIMD), and capping it at 128 spills (5 ms).  See DESIGN.md section 5 for why two
 // reads are out of reach with 160 KiB of LDS.
 template <bool LOW, bool NT>
 __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) {
