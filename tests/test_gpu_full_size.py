@@ -298,3 +298,17 @@ def test_n29_falls_back_to_64_bit_addressing():
     assert abs(ez[1] - np.cos(theta[n - 1]) * np.cos(0.4)) < 3e-6
     del st
     torch.cuda.empty_cache()
+
+
+def test_known_zero_fuzz_short():
+    """A short run of tools/fuzz_sparse_kernels.py inside the suite: random shallow tapes on random
+    wire subsets and tile geometries, state / probs / <Z> / parities with known-zero tracking
+    against the all-live plan (both now run on k_tile2 wherever the stage qualifies)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_N="24", FUZZ_SEED="7")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sparse_kernels.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
