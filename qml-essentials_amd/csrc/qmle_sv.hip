@@ -1262,7 +1262,8 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   float2 *s = reinterpret_cast<float2 *>(smem4);
   char *sb = reinterpret_cast<char *>(smem4);
   const int T = a.T;
-  float *red = reinterpret_cast<float *>(s);  // measuring epilogues: scratch aliases the tile
+  // measuring epilogues: scratch aliases the tile, except the whole-state one (own region)
+  float *red = a.meas == TM_EXPVAL ? reinterpret_cast<float *>(s + (1u << T)) : reinterpret_cast<float *>(s);
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
   const int b = blockIdx.y;
   uint32_t tile = blockIdx.x;
@@ -3768,9 +3769,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   // fast path: all-live stage of (controlled) 2x2 gates -- table-addressed groups, CX folded
   // into the LDS layout, SGPR matrices (k_tile2)
   static const bool no_fast = std::getenv("QMLE_NO_FAST_TILE") != nullptr;
-  // (k_tile2 addresses a tile with 32-bit byte offsets inside one state: n <= 28)
-  if (!no_fast && st.fast_ok && st.T < p->n && p->n <= 28 && threads == (1 << (st.T - 4)) &&
-      meas != TM_EXPVAL) {
+  // (k_tile2 addresses a tile with 32-bit byte offsets inside one state: n <= 28; a whole state
+  // of 10..13 qubits is one tile per sample: T == n, <Z> through the TM_EXPVAL epilogue)
+  static const bool no_fast_whole = std::getenv("QMLE_NO_FAST_WHOLE") != nullptr;
+  if (!no_fast && st.fast_ok && p->n <= 28 && threads == (1 << (st.T - 4)) &&
+      (st.T < p->n ? meas != TM_EXPVAL : !no_fast_whole)) {
     if (first_use_on_device(2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -3828,7 +3831,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
     f.dbg = dbg;
     if (dbg & 1) f.n_groups = 0;
-    const size_t lds2 = (size_t)8 << st.T;  // T >= 10: the epilogues' scratch fits inside
+    // T >= 10: the per-tile epilogues' scratch fits inside the tile; the whole-state <Z> epilogue
+    // reduces while amplitudes are still being read and gets its own 288 floats
+    const size_t lds2 = ((size_t)8 << st.T) + (meas == TM_EXPVAL ? 288 * sizeof(float) : 0);
     const bool measure = !(meas == TM_STORE || meas == TM_PROBS);
     if (measure) {
       if (a.nt) hipLaunchKernelGGL((k_tile2<true, true>), grid, dim3(threads), lds2, stream, a, f);
