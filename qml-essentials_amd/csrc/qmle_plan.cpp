@@ -9,6 +9,7 @@
 // LDS and applies every gate whose wires fall inside the tile.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <sstream>
@@ -690,7 +691,12 @@ int compile_plan(qmle_plan *p) {
     return QMLE_ERR_INVALID_ARG;
 
   // ---- 3. schedule into stages (for one tile geometry) ---------------------------
-  auto schedule = [&](int T, int L) {
+  // lazy: X / CX whose wires are not in the tile yet wait (the fast tile path folds them into
+  // the LDS layout for free, so they should never claim a tile bit a dense gate could use);
+  // whatever room is left after the first sweep is filled by a second, plain greedy sweep.
+  // HE layer at n = 24: dense gates per pass 12/7/5 -> 12/8/4, the measuring pass drops from
+  // two register-tile groups to one.
+  auto schedule = [&](int T, int L, bool lazy = false) {
     if (p->whole_state_lds) T = n;
     if (T > kLdsMaxQubits) T = kLdsMaxQubits;
     if (T > n) T = n;
@@ -744,22 +750,33 @@ int compile_plan(qmle_plan *p) {
         const uint64_t fm = op_mask(fo, n);
         while (stageL > 1 && popc((bit(stageL) - 1) | fm) > T) --stageL;
         Q = bit(stageL) - 1;
-        uint64_t blocked = 0;
-        for (size_t i = first; i < nl; ++i) {
-          if (done[i]) continue;
-          const LoweredOp &o = p->lowered[i];
-          const uint64_t m = op_mask(o, n);
-          if (o.kind == LK_DIAG_ALL || (m & blocked)) {
-            blocked |= m;
-          } else if (popc(Q | m) <= T) {
-            Q |= m;
-            members.push_back((int)i);
-            if (no_fusion) break;
-          } else {
-            blocked |= m;
+        std::vector<char> taken;
+        if (lazy) taken.assign(nl, 0);
+        for (int sweep = lazy ? 0 : 1; sweep < 2; ++sweep) {
+          uint64_t blocked = 0;
+          for (size_t i = first; i < nl; ++i) {
+            if (done[i] || (lazy && taken[i])) continue;
+            const LoweredOp &o = p->lowered[i];
+            const uint64_t m = op_mask(o, n);
+            const bool wait = sweep == 0 && o.kind == LK_1Q && o.nc <= 1 && (o.flags & LF_PERMX) &&
+                              (m & ~Q) != 0;
+            if (o.kind == LK_DIAG_ALL || (m & blocked)) {
+              blocked |= m;
+            } else if (!wait && popc(Q | m) <= T) {
+              Q |= m;
+              members.push_back((int)i);
+              if (lazy) taken[i] = 1;
+              if (no_fusion) break;
+            } else {
+              blocked |= m;
+            }
+            if ((blocked & all_mask) == all_mask) break;
           }
-          if ((blocked & all_mask) == all_mask) break;
+          if (popc(Q) >= T) break;
         }
+        // (an op taken by the second sweep never shares a wire with a LATER op of the first: that
+        // one would have been blocked behind it -- so index order is a valid execution order)
+        if (lazy) std::sort(members.begin(), members.end());
       }
 
       Stage st;
@@ -912,13 +929,14 @@ int compile_plan(qmle_plan *p) {
     static const int cand[][2] = {{13, 7}, {13, 5}, {12, 4}, {13, 4}, {12, 5}, {13, 6}};
     int best = 0;
     double best_cost = 1e300;
-    for (int k = 0; k < 6; ++k) {
-      if (cand[k][0] >= n) continue;
-      schedule(cand[k][0], cand[k][1]);
+    static const bool no_lazy = std::getenv("QMLE_NO_LAZY_CX") != nullptr;
+    for (int k = 0; k < (no_lazy ? 6 : 12); ++k) {  // 0..5 eager (ties keep the eager schedule), 6..11 lazy
+      if (cand[k % 6][0] >= n) continue;
+      schedule(cand[k % 6][0], cand[k % 6][1], k >= 6);
       const double c = cost();
       if (c < best_cost) { best_cost = c; best = k; }
     }
-    schedule(cand[best][0], cand[best][1]);
+    schedule(cand[best % 6][0], cand[best % 6][1], best >= 6);
   }
   return QMLE_OK;
 }

@@ -184,11 +184,14 @@ def test_fast_tile_groups_fold_cx_into_the_layout():
     st = d["stages"]
     assert len(st) == 3 and all(s["fast"] for s in st)
     assert sum(s["n_lowered"] for s in st) == 48                 # 24 merged 2x2 + 24 CX
+    # CX gates wait for a pass that holds both wires anyway ("lazy" schedule): dense gates per
+    # pass 12 / 8 / 4, so the measuring pass is ONE group
+    assert [sum(g["n_ops"] for g in s["fast_groups"]) for s in st] == [12, 8, 4]
+    assert [len(s["fast_groups"]) for s in st] == [3, 2, 1]
     for s in st[1:]:
         groups = s["fast_groups"]
-        assert len(groups) == 2 and len(s["groups"]) >= 3        # generic grouping needs >= 3
-        assert sum(g["n_ops"] for g in groups) <= 8              # only the dense gates are left
-        assert groups[-1]["relayout"] == 1 and groups[0]["relayout"] == 0
+        assert len(s["groups"]) >= 3                             # generic grouping needs >= 3
+        assert groups[-1]["relayout"] == 1 and all(g["relayout"] == 0 for g in groups[:-1])
         assert s["read_bytes_from_zero"] == 8 * 2**24            # all amplitudes live
     # a stage with a gate the fast path does not cover (CCX, 4x4) keeps the generic kernel
     mixed = N.Plan([("H", [0], [], -1), ("CCX", [0, 1, 2], [], -1), ("RXX", [3, 4], [0], -1)], 16, 1,
