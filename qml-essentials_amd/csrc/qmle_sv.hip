@@ -1025,19 +1025,42 @@ struct Mat2S {  // a 2x2 complex matrix as four (re, im) SGPR pairs
   u64 m00, m01, m10, m11;
 };
 
+// The 16 amplitudes of a work item: 16 named scalars, indexed at compile time only (at<I>).
+// (An array walked by unrolled loops is turned into one <16 x i64> value by the AMDGPU
+// alloca-to-vector promotion before the loops are unrolled; every gate then copies the whole
+// 32-register tuple in and out.)
+struct A16 {
+  u64 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;
+};
+template <int I> __device__ __forceinline__ u64 &at(A16 &a) {
+  static_assert(I >= 0 && I < 16, "amplitude index");
+  if constexpr (I == 0) return a.v0; else if constexpr (I == 1) return a.v1;
+  else if constexpr (I == 2) return a.v2; else if constexpr (I == 3) return a.v3;
+  else if constexpr (I == 4) return a.v4; else if constexpr (I == 5) return a.v5;
+  else if constexpr (I == 6) return a.v6; else if constexpr (I == 7) return a.v7;
+  else if constexpr (I == 8) return a.v8; else if constexpr (I == 9) return a.v9;
+  else if constexpr (I == 10) return a.v10; else if constexpr (I == 11) return a.v11;
+  else if constexpr (I == 12) return a.v12; else if constexpr (I == 13) return a.v13;
+  else if constexpr (I == 14) return a.v14; else return a.v15;
+}
+
+// pair q (0..7) of target bit TB: q with a zero inserted at bit TB
+template <int TB> __device__ __forceinline__ constexpr int pair_idx(int q) {
+  return ((q & ~((1 << TB) - 1)) << 1) | (q & ((1 << TB) - 1));
+}
 template <int TB>
-__device__ __forceinline__ void f_dense(u64 (&a)[16], const Mat2S &M) {
+__device__ __forceinline__ void f_dense(A16 &a, const Mat2S &M) {
   const u64 m00 = M.m00, m01 = M.m01, m10 = M.m10, m11 = M.m11;
   u64 t0, t1, t2, t3;
   constexpr int S = 1 << TB;
-  constexpr int lo = S - 1;
-  // pair q (0..7): c = q with a zero inserted at bit TB
-#define QMLE_IDX(q) ((((q) & ~lo) << 1) | ((q) & lo))
-  QMLE_PAIR2(a[QMLE_IDX(0)], a[QMLE_IDX(0) | S], a[QMLE_IDX(1)], a[QMLE_IDX(1) | S]);
-  QMLE_PAIR2(a[QMLE_IDX(2)], a[QMLE_IDX(2) | S], a[QMLE_IDX(3)], a[QMLE_IDX(3) | S]);
-  QMLE_PAIR2(a[QMLE_IDX(4)], a[QMLE_IDX(4) | S], a[QMLE_IDX(5)], a[QMLE_IDX(5) | S]);
-  QMLE_PAIR2(a[QMLE_IDX(6)], a[QMLE_IDX(6) | S], a[QMLE_IDX(7)], a[QMLE_IDX(7) | S]);
-#undef QMLE_IDX
+#define QMLE_P(q) at<pair_idx<TB>(q)>(a), at<pair_idx<TB>(q) | S>(a)
+#define QMLE_PAIR2X(...) QMLE_PAIR2(__VA_ARGS__)
+  QMLE_PAIR2X(QMLE_P(0), QMLE_P(1));
+  QMLE_PAIR2X(QMLE_P(2), QMLE_P(3));
+  QMLE_PAIR2X(QMLE_P(4), QMLE_P(5));
+  QMLE_PAIR2X(QMLE_P(6), QMLE_P(7));
+#undef QMLE_PAIR2X
+#undef QMLE_P
 }
 // index r (0..3) deposited into the two bits that are neither CB nor TB, control bit set
 template <int CB, int TB>
@@ -1050,57 +1073,59 @@ __device__ __forceinline__ constexpr int ctl_idx(int r) {
   return c;
 }
 template <int CB, int TB>
-__device__ __forceinline__ void f_cdense(u64 (&a)[16], const Mat2S &M) {
+__device__ __forceinline__ void f_cdense(A16 &a, const Mat2S &M) {
   const u64 m00 = M.m00, m01 = M.m01, m10 = M.m10, m11 = M.m11;
   u64 t0, t1, t2, t3;
   constexpr int S = 1 << TB;
   constexpr int i0 = ctl_idx<CB, TB>(0), i1 = ctl_idx<CB, TB>(1), i2 = ctl_idx<CB, TB>(2),
                 i3 = ctl_idx<CB, TB>(3);
-  QMLE_PAIR2(a[i0], a[i0 | S], a[i1], a[i1 | S]);
-  QMLE_PAIR2(a[i2], a[i2 | S], a[i3], a[i3 | S]);
+  QMLE_PAIR2(at<i0>(a), at<i0 | S>(a), at<i1>(a), at<i1 | S>(a));
+  QMLE_PAIR2(at<i2>(a), at<i2 | S>(a), at<i3>(a), at<i3 | S>(a));
 }
 template <int TB>
-__device__ __forceinline__ void f_diag(u64 (&a)[16], const Mat2S &M) {
+__device__ __forceinline__ void f_diag(A16 &a, const Mat2S &M) {
   const u64 m00 = M.m00, m11 = M.m11;
   u64 t0, t1, t2, t3;
   constexpr int S = 1 << TB;
-  constexpr int lo = S - 1;
-#define QMLE_IDX(q) ((((q) & ~lo) << 1) | ((q) & lo))
-  QMLE_CMUL4(a[QMLE_IDX(0)], a[QMLE_IDX(1)], a[QMLE_IDX(2)], a[QMLE_IDX(3)], m00);
-  QMLE_CMUL4(a[QMLE_IDX(4)], a[QMLE_IDX(5)], a[QMLE_IDX(6)], a[QMLE_IDX(7)], m00);
-  QMLE_CMUL4(a[QMLE_IDX(0) | S], a[QMLE_IDX(1) | S], a[QMLE_IDX(2) | S], a[QMLE_IDX(3) | S], m11);
-  QMLE_CMUL4(a[QMLE_IDX(4) | S], a[QMLE_IDX(5) | S], a[QMLE_IDX(6) | S], a[QMLE_IDX(7) | S], m11);
-#undef QMLE_IDX
+#define QMLE_I(q) pair_idx<TB>(q)
+  QMLE_CMUL4(at<QMLE_I(0)>(a), at<QMLE_I(1)>(a), at<QMLE_I(2)>(a), at<QMLE_I(3)>(a), m00);
+  QMLE_CMUL4(at<QMLE_I(4)>(a), at<QMLE_I(5)>(a), at<QMLE_I(6)>(a), at<QMLE_I(7)>(a), m00);
+  QMLE_CMUL4(at<QMLE_I(0) | S>(a), at<QMLE_I(1) | S>(a), at<QMLE_I(2) | S>(a), at<QMLE_I(3) | S>(a), m11);
+  QMLE_CMUL4(at<QMLE_I(4) | S>(a), at<QMLE_I(5) | S>(a), at<QMLE_I(6) | S>(a), at<QMLE_I(7) | S>(a), m11);
+#undef QMLE_I
 }
 template <int CB, int TB>
-__device__ __forceinline__ void f_cdiag(u64 (&a)[16], const Mat2S &M) {
+__device__ __forceinline__ void f_cdiag(A16 &a, const Mat2S &M) {
   const u64 m00 = M.m00, m11 = M.m11;
   u64 t0, t1, t2, t3;
   constexpr int S = 1 << TB;
   constexpr int i0 = ctl_idx<CB, TB>(0), i1 = ctl_idx<CB, TB>(1), i2 = ctl_idx<CB, TB>(2),
                 i3 = ctl_idx<CB, TB>(3);
-  QMLE_CMUL4(a[i0], a[i1], a[i2], a[i3], m00);
-  QMLE_CMUL4(a[i0 | S], a[i1 | S], a[i2 | S], a[i3 | S], m11);
+  QMLE_CMUL4(at<i0>(a), at<i1>(a), at<i2>(a), at<i3>(a), m00);
+  QMLE_CMUL4(at<i0 | S>(a), at<i1 | S>(a), at<i2 | S>(a), at<i3 | S>(a), m11);
+}
+template <int I, int J> __device__ __forceinline__ void swap_amp(A16 &a) {
+  const u64 t = at<I>(a);
+  at<I>(a) = at<J>(a);
+  at<J>(a) = t;
 }
 template <int TB>
-__device__ __forceinline__ void f_x(u64 (&a)[16]) {
+__device__ __forceinline__ void f_x(A16 &a) {
   constexpr int S = 1 << TB;
-#pragma unroll
-  for (int c = 0; c < 16; ++c)
-    if (!(c & S)) { const u64 t = a[c]; a[c] = a[c | S]; a[c | S] = t; }
+  swap_amp<pair_idx<TB>(0), pair_idx<TB>(0) | S>(a); swap_amp<pair_idx<TB>(1), pair_idx<TB>(1) | S>(a);
+  swap_amp<pair_idx<TB>(2), pair_idx<TB>(2) | S>(a); swap_amp<pair_idx<TB>(3), pair_idx<TB>(3) | S>(a);
+  swap_amp<pair_idx<TB>(4), pair_idx<TB>(4) | S>(a); swap_amp<pair_idx<TB>(5), pair_idx<TB>(5) | S>(a);
+  swap_amp<pair_idx<TB>(6), pair_idx<TB>(6) | S>(a); swap_amp<pair_idx<TB>(7), pair_idx<TB>(7) | S>(a);
 }
 template <int CB, int TB>
-__device__ __forceinline__ void f_cx(u64 (&a)[16]) {
+__device__ __forceinline__ void f_cx(A16 &a) {
   constexpr int S = 1 << TB;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int c = ctl_idx<CB, TB>(r);
-    const u64 t = a[c]; a[c] = a[c | S]; a[c | S] = t;
-  }
+  swap_amp<ctl_idx<CB, TB>(0), ctl_idx<CB, TB>(0) | S>(a); swap_amp<ctl_idx<CB, TB>(1), ctl_idx<CB, TB>(1) | S>(a);
+  swap_amp<ctl_idx<CB, TB>(2), ctl_idx<CB, TB>(2) | S>(a); swap_amp<ctl_idx<CB, TB>(3), ctl_idx<CB, TB>(3) | S>(a);
 }
 
 // one op of a Group2 on the 16 amplitudes a thread holds; `code` is wave-uniform (FastCode)
-__device__ __forceinline__ void fast_dispatch(u64 (&a)[16], int code, const Mat2S &M) {
+__device__ __forceinline__ void fast_dispatch(A16 &a, int code, const Mat2S &M) {
 #define QMLE_C12(F, base, ...)                                                                   \
   case base + 0: F<0, 1>(__VA_ARGS__); break; case base + 1: F<0, 2>(__VA_ARGS__); break;        \
   case base + 2: F<0, 3>(__VA_ARGS__); break; case base + 3: F<1, 0>(__VA_ARGS__); break;        \
@@ -1166,13 +1191,38 @@ __device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Arg
   return base;
 }
 
+// LDS access by byte offset (address space 3: the offset IS the address -- no 64-bit generic
+// pointer arithmetic, no `base + offset` add per access)
+typedef u64 __attribute__((address_space(3))) lds_u64_t;
+typedef float f4n_t __attribute__((ext_vector_type(4)));
+typedef f4n_t __attribute__((address_space(3))) lds_f4_t;
+__device__ __forceinline__ float4 lds_ld128(uint32_t byte) {
+  const f4n_t v = *(const lds_f4_t *)(uintptr_t)byte;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_st128(uint32_t byte, const float4 &v) {
+  const f4n_t w = {v.x, v.y, v.z, v.w};
+  *(lds_f4_t *)(uintptr_t)byte = w;
+}
+__device__ __forceinline__ u64 lds_ld64(uint32_t byte) { return *(const lds_u64_t *)(uintptr_t)byte; }
+__device__ __forceinline__ void lds_st64(uint32_t byte, u64 v) { *(lds_u64_t *)(uintptr_t)byte = v; }
+__device__ __forceinline__ uint32_t lds_offset_of(const void *p) {  // low half of a generic LDS address
+  return (uint32_t)(uintptr_t)p;
+}
+#define QMLE_X16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
 // All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this work item's
-// table entry of the first group, already loaded.  Ends with a barrier.
+// table entry of the first group, already loaded; `sb` = LDS byte offset of the tile (a multiple
+// of the tile size, so it commutes with the XOR addressing).  Ends with a barrier.
 // The stage's ops are one contiguous stream (groups are emitted in order), so the scalar-load
 // pipeline -- two descriptors and one matrix ahead of the gate being applied -- runs ACROSS group
 // boundaries: a group's first gate never waits for descriptor -> matrix, and a group's 16 slot
 // offsets are the XOR closure of four words fetched during the previous group.
-__device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile2Args &f,
+// The 16 amplitudes are 16 scalars r0..r15 addressed with literal indices only: as an array
+// walked by (unrolled) loops they become one <16 x i64> value early in the optimiser, a
+// 32-register tuple that was then copied whole around every gate (32 v_mov_b64 per dense gate,
+// a third of its instructions, until round 2's second profile pass found it).
+__device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const Tile2Args &f,
                                              const u64 QMLE_CONSTANT *mrow, int tid, bool use_skip) {
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
@@ -1192,23 +1242,21 @@ __device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile
   // header word (n_ops | relayout << 16) and the four basis offsets of the first group
   uint32_t hdr = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(grp)[1];
   uint32_t o1 = grp->off[1], o2 = grp->off[2], o4 = grp->off[4], o8 = grp->off[8];
+#define QMLE_OFF(c, b1, b2, b4, b8) \
+  ((((c) & 1) ? (b1) : 0u) ^ (((c) & 2) ? (b2) : 0u) ^ (((c) & 4) ? (b4) : 0u) ^ (((c) & 8) ? (b8) : 0u))
   for (int gi = 0; gi < f.n_groups; ++gi, ++grp) {
     const int n_ops = (int)(hdr & 0xffffu);
     const bool relayout = ((hdr >> 16) & 0xffu) != 0;
-    uint32_t off[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-      off[c] = ((c & 1) ? o1 : 0u) ^ ((c & 2) ? o2 : 0u) ^ ((c & 4) ? o4 : 0u) ^ ((c & 8) ? o8 : 0u);
-    // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point
-    const bool idle = use_skip && (addr & 1u);
-    addr &= ~7u;
-    u64 r[16];
-    if (!idle) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = *reinterpret_cast<const u64 *>(sb + (addr ^ off[c]));
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = 0ull;
+    // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point.
+    // Wave-uniform use only: a wave of idle work items skips the group; an idle work item inside
+    // a busy wave runs it on the zeros its slots hold (no per-lane branch around the gates)
+    const bool busy = !use_skip || __builtin_amdgcn_ballot_w64(!(addr & 1u)) != 0ull;
+    addr = (addr & ~7u) + sb;
+    A16 r;
+    if (busy || relayout) {  // (a relayout stores every slot of the new layout, zeros included)
+#define QMLE_LD(c) r.v##c = lds_ld64(addr ^ QMLE_OFF(c, o1, o2, o4, o8));
+      QMLE_X16(QMLE_LD)
+#undef QMLE_LD
     }
     // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
     // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
@@ -1221,7 +1269,6 @@ __device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile
     const Group2 QMLE_CONSTANT *nx = more ? grp + 1 : grp;
     const uint32_t hdr_n = reinterpret_cast<const uint32_t QMLE_CONSTANT *>(nx)[1];
     const uint32_t n1 = nx->off[1], n2 = nx->off[2], n4 = nx->off[4], n8 = nx->off[8];
-    // (idle work items skip the arithmetic; the branch is per lane, the loads are per wave)
     for (int j = 0; j < n_ops; ++j, ++k) {
       // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
       // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
@@ -1229,30 +1276,30 @@ __device__ __forceinline__ void tile2_groups(char *sb, uint32_t addr, const Tile
       const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
       const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
       const v4u w2 = op[k + 2 < last ? k + 2 : last];
-      if (!idle) fast_dispatch(r, (int)(w0.y >> 24), M0);
+      if (busy) fast_dispatch(r, (int)(w0.y >> 24), M0);
       w0 = w1;
       w1 = w2;
       M0 = Mn;
     }
     if (relayout) {
       __syncthreads();  // every gather of the group is done: slots may change owners
-      // (an idle work item still owns 16 slots of the new layout: it stores its zeros)
-      addr_next &= ~7u;
+      addr_next = (addr_next & ~7u) + sb;
       const uint32_t q1 = grp->off_out[1], q2 = grp->off_out[2], q4 = grp->off_out[4], q8 = grp->off_out[8];
-#pragma unroll
-      for (int c = 0; c < 16; ++c)
-        *reinterpret_cast<u64 *>(sb + (addr_next ^ ((c & 1) ? q1 : 0u) ^ ((c & 2) ? q2 : 0u) ^
-                                       ((c & 4) ? q4 : 0u) ^ ((c & 8) ? q8 : 0u))) = r[c];
+#define QMLE_ST(c) lds_st64(addr_next ^ QMLE_OFF(c, q1, q2, q4, q8), r.v##c);
+      QMLE_X16(QMLE_ST)
+#undef QMLE_ST
       if (more) addr_next = f.tbl[grp[1].tbl + tid];
-    } else if (!idle) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) *reinterpret_cast<u64 *>(sb + (addr ^ off[c])) = r[c];
+    } else if (busy) {
+#define QMLE_ST(c) lds_st64(addr ^ QMLE_OFF(c, o1, o2, o4, o8), r.v##c);
+      QMLE_X16(QMLE_ST)
+#undef QMLE_ST
     }
     addr = addr_next;
     hdr = hdr_n;
     o1 = n1; o2 = n2; o4 = n4; o8 = n8;
     __syncthreads();
   }
+#undef QMLE_OFF
 }
 
 template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own
@@ -1260,8 +1307,11 @@ template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* e
 __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
-  char *sb = reinterpret_cast<char *>(smem4);
   const int T = a.T;
+  // LDS byte offset of the tile; the XOR addressing needs it aligned to the tile size (it is 0:
+  // the kernel has no static LDS)
+  const uint32_t sbo = lds_offset_of(smem4);
+  if (sbo & ((8u << T) - 1u)) __builtin_trap();
   // measuring epilogues: scratch aliases the tile, except the whole-state one (own region)
   float *red = a.meas == TM_EXPVAL ? reinterpret_cast<float *>(s + (1u << T)) : reinterpret_cast<float *>(s);
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
@@ -1300,9 +1350,9 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     uoff[u] = f.uoff8[u];
-    soff[u] = sw((uint32_t)u << (T - 3)) >> 1;  // float4 index; sw() is linear over XOR
+    soff[u] = sw((uint32_t)u << (T - 3)) << 3;  // LDS byte offset; sw() is linear over XOR
   }
-  const uint32_t sl = sw(jl) >> 1;
+  const uint32_t sl = (sw(jl) << 3) + sbo;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0) {
     // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
@@ -1325,7 +1375,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
   if (a.init_zero) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = z4;
+    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], z4);
     __syncthreads();
     if (tid == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
   } else if (a.zin_local) {
@@ -1342,18 +1392,18 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = v[u];
+    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
   } else {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ soff[u]] = v[u];
+    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
   }
   __syncthreads();
 
   const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
-  tile2_groups(sb, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
+  tile2_groups(sbo, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
 
   if (MEASURE) {
     if (f.dbg & 2) return;
@@ -1361,14 +1411,14 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   } else if (a.meas == TM_STORE) {
     float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
+    for (int u = 0; u < 8; ++u) v[u] = lds_ld128(sl ^ soff[u]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), v[u]);
   } else {
     char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float4 v = reinterpret_cast<float4 *>(s)[sl ^ soff[u]];
+      const float4 v = lds_ld128(sl ^ soff[u]);
       *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) =
           make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
     }
