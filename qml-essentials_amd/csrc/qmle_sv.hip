@@ -115,6 +115,26 @@ __device__ __forceinline__ void apply2(const Mat2 &m, float2 &a0, float2 &a1) {
   a1 = b1;
 }
 
+typedef unsigned long long u64;
+// LDS access by byte offset (address space 3: the offset IS the address -- no 64-bit generic
+// pointer arithmetic, no `base + offset` add per access)
+typedef u64 __attribute__((address_space(3))) lds_u64_t;
+typedef float f4n_t __attribute__((ext_vector_type(4)));
+typedef f4n_t __attribute__((address_space(3))) lds_f4_t;
+__device__ __forceinline__ float4 lds_ld128(uint32_t byte) {
+  const f4n_t v = *(const lds_f4_t *)(uintptr_t)byte;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_st128(uint32_t byte, const float4 &v) {
+  const f4n_t w = {v.x, v.y, v.z, v.w};
+  *(lds_f4_t *)(uintptr_t)byte = w;
+}
+__device__ __forceinline__ u64 lds_ld64(uint32_t byte) { return *(const lds_u64_t *)(uintptr_t)byte; }
+__device__ __forceinline__ void lds_st64(uint32_t byte, u64 v) { *(lds_u64_t *)(uintptr_t)byte = v; }
+__device__ __forceinline__ uint32_t lds_offset_of(const void *p) {  // low half of a generic LDS address
+  return (uint32_t)(uintptr_t)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
@@ -131,6 +151,32 @@ __device__ __forceinline__ float wave_sum_dpp63(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
   return v;
+}
+// Four wave sums at once, written out: one v_add_f32_dpp per step and value (24 instructions).
+// hipcc turns the builtin form above into v_mov_b32_dpp + v_pk_add_f32 pairs and materialises a
+// zero per masked row broadcast -- about twice the instructions (seen in the measuring
+// epilogue of k_tile2: 140 for 11 values).  Stage-major order keeps three independent
+// instructions between a write and the DPP read of it (the hazard needs two).
+__device__ __forceinline__ void wave_sum4_dpp63(float &a, float &b, float &c, float &d) {
+#define QMLE_DPP4(ctrl)                                                                          \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                   \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+  asm volatile("s_nop 1\n\t"
+               QMLE_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               QMLE_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               QMLE_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+               QMLE_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+               QMLE_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               QMLE_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef QMLE_DPP4
+}
+// N values (padded to a multiple of four with a dummy)
+template <int N> __device__ __forceinline__ void wave_sums_dpp63(float (&v)[N]) {
+  float pad = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; j += 4)
+    wave_sum4_dpp63(v[j], j + 1 < N ? v[j + 1] : pad, j + 2 < N ? v[j + 2] : pad, j + 3 < N ? v[j + 3] : pad);
 }
 // Sum over the block; result valid in thread 0.  `red` holds >= 16 floats.
 __device__ __forceinline__ float block_sum(float v, float *red) {
@@ -673,17 +719,18 @@ __device__ __forceinline__ void tile_compute(const TileArgs &a, float2 *s, const
 }
 
 // Store / measure the finished tile.  n_tiles = tiles per state.
-template <bool RAW>
+template <bool RAW, bool PARTIAL_ONLY = false>  // PARTIAL_ONLY: a.meas is TM_EXPVAL_PARTIAL (k_tile2's
+                                                 // multi-tile instantiation keeps its register budget)
 __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, const uint32_t *lut,
                                               float *red, uint32_t tile, uint32_t n_tiles, int b,
-                                              uint64_t base) {
+                                              uint64_t base, int qsrc_of_thread = -1) {
   const int T = a.T, L = a.L;
   const int tid = threadIdx.x, nt = blockDim.x;
   const size_t D = (size_t)1 << a.n;
   const uint32_t half = 1u << (T - 1);
   const uint32_t lowmask = (1u << L) - 1u;
   float2 *st = a.states + (size_t)b * D;
-  if (a.meas == TM_STORE) {
+  if (!PARTIAL_ONLY && a.meas == TM_STORE) {
     if ((half % (8u * nt)) == 0) {
       for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
         float4 v[8];
@@ -704,7 +751,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
             reinterpret_cast<float4 *>(s)[sw(j) >> 1];
       }
     }
-  } else if (a.meas == TM_PROBS) {
+  } else if (!PARTIAL_ONLY && a.meas == TM_PROBS) {
     float *po = reinterpret_cast<float *>(a.out) + (size_t)b * D;
     for (uint32_t jc = tid; jc < half; jc += nt) {
       const uint32_t j = jc * 2u;
@@ -712,18 +759,30 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
       const float4 v = reinterpret_cast<float4 *>(s)[sw(j) >> 1];
       *reinterpret_cast<float2 *>(po + g) = make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
     }
-  } else if (a.meas == TM_EXPVAL_PARTIAL) {
+  } else if (PARTIAL_ONLY || a.meas == TM_EXPVAL_PARTIAL) {
     // element e = tid + it * nt: bits [0, tb) come from tid, the top bits from `it`
     float *po = reinterpret_cast<float *>(a.out) +
                 ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
     const uint32_t cnt = 1u << T;
-    if (cnt == 16u * nt) {
-      const int qsrc = tid <= QMLE_MAX_QUBITS ? (int)a.qsrc[tid] : 64;
+    if (PARTIAL_ONLY || cnt == 16u * nt) {  // (k_tile2 always has 16 amplitudes per work item)
+      const int qsrc = qsrc_of_thread >= 0 ? qsrc_of_thread : tid <= QMLE_MAX_QUBITS ? (int)a.qsrc[tid] : 64;
       // |amplitude|^2 of the 16 elements a lane owns, then a pruned Walsh-Hadamard butterfly over
       // the 4 iteration bits: the total and the four single-bit signed sums in 41 additions
+      // (sw() is linear over XOR and nt a power of two: one address per lane, 16 wave-uniform
+      // offsets -- not 16 adds + swizzles)
       float pr[16];
+      const uint32_t e0 = (sw((uint32_t)tid) << 3) + lds_offset_of(s);
 #pragma unroll
-      for (int it = 0; it < 16; ++it) pr[it] = norm2(s[sw(tid + it * nt)]);
+      for (int h = 0; h < 16; h += 8) {  // 8 reads in flight (hipcc would keep 3, to save registers)
+        u64 amp[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) amp[it] = lds_ld64(e0 ^ (sw((uint32_t)(h + it) << (T - 4)) << 3));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+          pr[h + it] = norm2(make_float2(__uint_as_float((uint32_t)amp[it]), __uint_as_float((uint32_t)(amp[it] >> 32))));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3, tot;
       float s1[8], s2[4], s3[2];
 #pragma unroll
@@ -741,8 +800,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
 #pragma unroll
       for (int j = 0; j < 6; ++j) v[j] = ((lane >> j) & 1) ? -tot : tot;
       v[6] = h0; v[7] = h1; v[8] = h2; v[9] = h3; v[10] = tot;
-#pragma unroll
-      for (int j = 0; j < 11; ++j) v[j] = wave_sum_dpp63(v[j]);
+      wave_sums_dpp63(v);
       tile_sync<RAW>();  // k_tile2 keeps `red` INSIDE the tile buffer (32 KiB per workgroup = 5
                          // workgroups per CU): every amplitude must have been read by now
       if (lane == kWave - 1) {
@@ -983,7 +1041,6 @@ __global__ void k_tile(const TileArgs a) {
 //     pipe never waits on its own result (hipcc serialises each chain behind s_nop);
 //   * no lookup table in LDS: the 8 float4 of a lane differ in wave-uniform high bits only, so
 //     a tile of 2^12 amplitudes needs exactly 32 KiB -> 5 workgroups per CU.
-typedef unsigned long long u64;
 
 // (b0, b1) = M (a0, a1) for two amplitude pairs under the same 2x2 matrix; complex products as
 // 2 packed instructions each: (m.x, m.x) * (a.x, a.y), then (-m.y, m.y) * (a.y, a.x) + ...
@@ -1180,6 +1237,8 @@ struct Tile2Args {
   // <= 4 runs (n_in_runs < 0: read it from the table at gtab)
   int n_in_runs;
   uint32_t in_off[4], in_mask[4], in_pos[4];
+  int tpw;                  // consecutive tiles per workgroup (plain all-live stages; else 1)
+  uint32_t tile_stride;     // amplitudes between consecutive tiles of a workgroup (2^lowest outer bit)
 };
 
 __device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Args &f, uint32_t tile) {
@@ -1191,24 +1250,6 @@ __device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Arg
   return base;
 }
 
-// LDS access by byte offset (address space 3: the offset IS the address -- no 64-bit generic
-// pointer arithmetic, no `base + offset` add per access)
-typedef u64 __attribute__((address_space(3))) lds_u64_t;
-typedef float f4n_t __attribute__((ext_vector_type(4)));
-typedef f4n_t __attribute__((address_space(3))) lds_f4_t;
-__device__ __forceinline__ float4 lds_ld128(uint32_t byte) {
-  const f4n_t v = *(const lds_f4_t *)(uintptr_t)byte;
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void lds_st128(uint32_t byte, const float4 &v) {
-  const f4n_t w = {v.x, v.y, v.z, v.w};
-  *(lds_f4_t *)(uintptr_t)byte = w;
-}
-__device__ __forceinline__ u64 lds_ld64(uint32_t byte) { return *(const lds_u64_t *)(uintptr_t)byte; }
-__device__ __forceinline__ void lds_st64(uint32_t byte, u64 v) { *(lds_u64_t *)(uintptr_t)byte = v; }
-__device__ __forceinline__ uint32_t lds_offset_of(const void *p) {  // low half of a generic LDS address
-  return (uint32_t)(uintptr_t)p;
-}
 #define QMLE_X16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 // All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this work item's
@@ -1302,8 +1343,10 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
 #undef QMLE_OFF
 }
 
-template <bool NT, bool MEASURE>  // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own
-                                  // instantiation: the storing kernel keeps a small register budget)
+// MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own instantiation: the storing kernel keeps
+// a small register budget).  MULTI: several tiles per workgroup (f.tpw), plain all-live stages
+// with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
+template <bool NT, bool MEASURE, bool MULTI>
 __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -1316,8 +1359,14 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   float *red = a.meas == TM_EXPVAL ? reinterpret_cast<float *>(s + (1u << T)) : reinterpret_cast<float *>(s);
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
   const int b = blockIdx.y;
-  uint32_t tile = blockIdx.x;
-  if (a.compact) {  // blockIdx.x enumerates the tiles that can be non-zero (launch_tile)
+  // Plain all-live stages give a workgroup `tpw` consecutive tiles: the next tile's 8 float4 per
+  // lane are in flight (in registers) while this tile's gates and epilogue run, so a workgroup
+  // that computes still has HBM requests outstanding.  (One tile per workgroup left the
+  // measuring pass at 30 us per state with 20 us of traffic: five workgroups per CU, of which
+  // too few were in their load phase at any time.)  Known-zero stages keep one tile each.
+  const int tpw = MULTI ? f.tpw : 1;
+  uint32_t tile = blockIdx.x * (uint32_t)tpw;
+  if (!MULTI && a.compact) {  // blockIdx.x enumerates the tiles that can be non-zero (launch_tile)
     uint32_t rest = tile, free_bits = a.tile_free;
     tile = 0;
     while (rest) {
@@ -1327,8 +1376,9 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
       rest >>= 1;
     }
   }
+  const uint32_t n_tiles = gridDim.x * (uint32_t)tpw;
   const size_t D = (size_t)1 << a.n;
-  const uint64_t base = tile2_base(a, f, tile);
+  uint64_t base = tile2_base(a, f, tile);
   // global addresses: wave-uniform 64-bit base (SGPRs) + one 32-bit byte offset per lane
   char *st = reinterpret_cast<char *>(a.states + (size_t)b * D + base);
   // a lane's 8 float4: local index j = 2 (tid + u nt): bit 0 rides in the access, bits 1..T-4
@@ -1354,7 +1404,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
   }
   const uint32_t sl = (sw(jl) << 3) + sbo;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0) {
+  if (!MULTI && (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0)) {
     // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
     // (Stage::zero_in) stays exactly zero -- write the zeros, skip the gates
     if (!MEASURE && a.meas == TM_STORE) {
@@ -1366,62 +1416,94 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
       for (int u = 0; u < 8; ++u) *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) = make_float2(0.f, 0.f);
     } else {
       float *po = reinterpret_cast<float *>(a.out) +
-                  ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
+                  ((size_t)b * n_tiles + tile) * (QMLE_MAX_QUBITS + 1);
       if (tid <= QMLE_MAX_QUBITS) po[tid] = 0.f;
     }
     return;
   }
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
-  uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
-  if (a.init_zero) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], z4);
-    __syncthreads();
-    if (tid == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
-  } else if (a.zin_local) {
-    // only the amplitudes that can be non-zero are read; the rest of the tile is zero-filled
-    const uint32_t zl = a.zin_local & ~1u;
-    const bool z0 = (a.zin_local & 1u) != 0;
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      v[u] = z4;
-      if (((jl | ((uint32_t)u << (T - 3))) & zl) == 0) {
-        v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
-        if (z0) v[u].z = v[u].w = 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
-  } else {
-    float4 v[8];
+  const uint32_t addr = f.n_groups > 0 ? f.tbl[grp->tbl + tid] : 0u;  // in flight beside the tile
+  const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
+  // (TM_EXPVAL_PARTIAL: where thread q finds <Z> of position q -- read once, through the kernel
+  // argument segment: indexing the by-value struct inside the tile loop makes hipcc copy it to
+  // scratch)
+  int qsrc = -1;
+  if (MEASURE) {
+    const int8_t QMLE_CONSTANT *ka = (const int8_t QMLE_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
+    qsrc = tid <= QMLE_MAX_QUBITS ? (int)ka[offsetof(TileArgs, qsrc) + tid] : 64;
+  }
+  const bool plain = MULTI || (!a.init_zero && !a.zin_local);
+  float4 v[8];
+  if (plain) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
-#pragma unroll
-    for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
   }
-  __syncthreads();
-
-  const u64 QMLE_CONSTANT *mrow = as_constant(reinterpret_cast<const u64 *>(a.mats + (size_t)b * a.mat_floats));
-  tile2_groups(sbo, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
-
-  if (MEASURE) {
-    if (f.dbg & 2) return;
-    tile_epilogue<false>(a, s, nullptr, red, tile, gridDim.x, b, base);
-  } else if (a.meas == TM_STORE) {
-    float4 v[8];
+  for (int i = 0; i < tpw; ++i) {
+    if (!MULTI && a.init_zero) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = lds_ld128(sl ^ soff[u]);
+      for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], z4);
+      __syncthreads();
+      if (tid == 0) s[sw(0)] = make_float2(1.f, 0.f);  // |0...0>, simulation.py:100
+    } else if (!MULTI && a.zin_local) {
+      // only the amplitudes that can be non-zero are read; the rest of the tile is zero-filled
+      const uint32_t zl = a.zin_local & ~1u;
+      const bool z0 = (a.zin_local & 1u) != 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), v[u]);
-  } else {
-    char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base);
+      for (int u = 0; u < 8; ++u) {
+        v[u] = z4;
+        if (((jl | ((uint32_t)u << (T - 3))) & zl) == 0) {
+          v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+          if (z0) v[u].z = v[u].w = 0.f;
+        }
+      }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float4 v = lds_ld128(sl ^ soff[u]);
-      *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) =
-          make_float2(v.x * v.x + v.y * v.y, v.z * v.z + v.w * v.w);
+      for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], v[u]);
     }
+    __syncthreads();
+    char *st_cur = st;
+    const uint64_t base_cur = base;
+    if (i + 1 < tpw) {  // (plain stages only) the next tile: loads in flight from here on
+      base += f.tile_stride;  // (tpw tiles share all but the lowest outer bits: launch_tile)
+      st += f.tile_stride * sizeof(float2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+    }
+
+    tile2_groups(sbo, addr, f, mrow, tid, !MULTI && a.zin_local != 0);  // known zeros: Stage::zero_in
+
+    if (MEASURE) {
+      if (!(f.dbg & 2))
+        tile_epilogue<false, MULTI>(a, s, nullptr, red, tile + (uint32_t)i, n_tiles, b, base_cur, qsrc);
+    } else if (a.meas == TM_STORE) {
+      if (MULTI) {  // (the next tile's 8 float4 are live: two batches of four keep <= 96 VGPRs)
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+          float4 w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = lds_ld128(sl ^ soff[h + u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[h + u] + goff8), w[u]);
+        }
+      } else {
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = lds_ld128(sl ^ soff[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[u] + goff8), w[u]);
+      }
+    } else {
+      char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base_cur);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 w = lds_ld128(sl ^ soff[u]);
+        *reinterpret_cast<float2 *>(po + (uoff[u] >> 1) + (goff8 >> 1)) =
+            make_float2(w.x * w.x + w.y * w.y, w.z * w.z + w.w * w.w);
+      }
+    }
+    if (i + 1 < tpw) __syncthreads();  // the tile buffer (and the epilogue's scratch in it) is reused
   }
 }
 
@@ -3307,8 +3389,12 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) 
     }
   }
   const int lane = tid & (kWave - 1), w = tid / kWave;
-#pragma unroll
-  for (int k = LOW ? 0 : 12; k < 37; ++k) acc[k] = wave_sum_dpp63(acc[k]);
+  if (LOW) {
+    wave_sums_dpp63(acc);
+  } else {  // (the first 12 are not used by the later reads)
+    float (&tail)[25] = *reinterpret_cast<float (*)[25]>(&acc[12]);
+    wave_sums_dpp63(tail);
+  }
   __syncthreads();  // every gather has been read: the tile becomes scratch
   if (lane == kWave - 1) {
 #pragma unroll
@@ -3825,14 +3911,13 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   if (!no_fast && st.fast_ok && p->n <= 28 && threads == (1 << (st.T - 4)) &&
       (st.T < p->n ? meas != TM_EXPVAL : !no_fast_whole)) {
     if (first_use_on_device(2)) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define QMLE_T2_LDS(NT, ME, MU)                                                   \
+  HIPCHK(hipFuncSetAttribute((const void *)k_tile2<NT, ME, MU>,                    \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+      QMLE_T2_LDS(false, false, false); QMLE_T2_LDS(true, false, false);
+      QMLE_T2_LDS(false, true, false); QMLE_T2_LDS(true, true, false);
+      QMLE_T2_LDS(false, false, true); QMLE_T2_LDS(true, false, true);
+#undef QMLE_T2_LDS
     }
     Tile2Args f;
     f.groups = p->dev.d_groups2 + st.fast_begin;
@@ -3878,6 +3963,25 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     for (unsigned u = 0; u < 8; ++u)
       f.uoff8[u] = (((u & 1u) << st.tile_bits[st.T - 3]) | (((u >> 1) & 1u) << st.tile_bits[st.T - 2]) |
                     (((u >> 2) & 1u) << st.tile_bits[st.T - 1])) << 3;
+    // plain all-live stages: several consecutive tiles per workgroup (next tile prefetched into
+    // registers), as long as the grid still fills the chip a few times over
+    static const int tpw_max = std::getenv("QMLE_T2_TPW") ? atoi(std::getenv("QMLE_T2_TPW")) : 4;
+    f.tpw = 1;
+    f.tile_stride = 0;
+    if (!a.init_zero && !a.zin_local && !a.zin_outer && !a.compact && st.T < p->n &&
+        (meas == TM_STORE || meas == TM_PROBS)) {
+      // (measured for the TM_EXPVAL_PARTIAL epilogue too: no gain -- that pass is bound by its
+      // vector instructions, not by loads in flight -- so it keeps one tile per workgroup)
+      // (consecutive tile indices differ in the lowest run of outer bit positions only)
+      int run0 = 1;
+      while (run0 < p->n - st.T && st.outer_bits[run0] == st.outer_bits[0] + run0) ++run0;
+      f.tile_stride = 1u << st.outer_bits[0];
+      while (f.tpw * 2 <= tpw_max && f.tpw * 2 <= (1 << run0) && grid.x % 2u == 0 &&
+             (uint64_t)(grid.x / 2u) * grid.y >= 5120) {
+        f.tpw *= 2;
+        grid.x /= 2u;
+      }
+    }
     static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
     f.dbg = dbg;
     if (dbg & 1) f.n_groups = 0;
@@ -3885,13 +3989,16 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     // reduces while amplitudes are still being read and gets its own 288 floats
     const size_t lds2 = ((size_t)8 << st.T) + (meas == TM_EXPVAL ? 288 * sizeof(float) : 0);
     const bool measure = !(meas == TM_STORE || meas == TM_PROBS);
+#define QMLE_T2_GO(NT, ME, MU) \
+  hipLaunchKernelGGL((k_tile2<NT, ME, MU>), grid, dim3(threads), lds2, stream, a, f)
+    const bool multi = f.tpw > 1;
     if (measure) {
-      if (a.nt) hipLaunchKernelGGL((k_tile2<true, true>), grid, dim3(threads), lds2, stream, a, f);
-      else hipLaunchKernelGGL((k_tile2<false, true>), grid, dim3(threads), lds2, stream, a, f);
+      if (a.nt) QMLE_T2_GO(true, true, false); else QMLE_T2_GO(false, true, false);
     } else {
-      if (a.nt) hipLaunchKernelGGL((k_tile2<true, false>), grid, dim3(threads), lds2, stream, a, f);
-      else hipLaunchKernelGGL((k_tile2<false, false>), grid, dim3(threads), lds2, stream, a, f);
+      if (multi) { if (a.nt) QMLE_T2_GO(true, false, true); else QMLE_T2_GO(false, false, true); }
+      else { if (a.nt) QMLE_T2_GO(true, false, false); else QMLE_T2_GO(false, false, false); }
     }
+#undef QMLE_T2_GO
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }

@@ -136,11 +136,14 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
         assert r["Occupancy"] >= 4 and r["VGPRs"] <= 128, (name, r)
     direct = [v for k, v in res.items() if "k_direct_1q" in k]
     assert direct and all(r["Occupancy"] >= 7 for r in direct)
-    # the fast tile kernel: <= 96 VGPRs = 5 waves per SIMD = the 5 workgroups of 32 KiB a CU holds
+    # the fast tile kernel: far below the 96 VGPRs that 5 workgroups of 32 KiB per CU allow (the 16
+    # amplitudes live in 32 registers, no copies around the gate dispatch); the multi-tile variant
+    # adds the next tile's 8 float4 per lane and runs 4 workgroups per CU
     fast = {k: v for k, v in res.items() if "k_tile2" in k}
-    assert len(fast) == 4
+    assert len(fast) == 6
     for name, r in fast.items():
-        assert r["Occupancy"] >= 5 and r["VGPRs"] <= 96, (name, r)
+        multi = "ELb1EEEv" in name
+        assert r["Occupancy"] >= (4 if multi else 5) and r["VGPRs"] <= (104 if multi else 64), (name, r)
 
 
 def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
