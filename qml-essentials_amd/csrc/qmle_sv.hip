@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include "qmle_internal.h"
 
@@ -1250,6 +1251,16 @@ __device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Arg
   return base;
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>).  Register arrays indexed this
+// way are split into scalars by the first SROA run; arrays walked by `#pragma unroll` loops are
+// turned into one wide vector value first (AMDGPU alloca-to-vector promotion) and copied around.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
 #define QMLE_X16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 // All register-tile groups of a stage on the tile in LDS (k_tile2); `addr` = this work item's
@@ -3311,8 +3322,7 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) 
     if (r < a.n_in_runs) goff |= ((jl >> a.in_off[r]) & a.in_mask[r]) << a.in_pos[r];
   const uint32_t goff8 = goff << 3;
   uint32_t uo[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) uo[u] = a.uo8[u];
+  static_for<8>([&](auto u) { uo[u] = a.uo8[u]; });
   const uint32_t sl = sw(jl) >> 1;
   const uint32_t tidv = (uint32_t)tid;
   // a workgroup walks 2^q tiles: the next tile's 8 float4 per lane are in flight (registers)
@@ -3328,65 +3338,57 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) 
   float4 v[8];
   {
     const char *st = tile_ptr(tile0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8));
+    static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
   }
   float acc[37];
-#pragma unroll
-  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
+  static_for<37>([&](auto k) { acc[k] = 0.f; });
+  const uint32_t sbo = lds_offset_of(smem4);
+  const uint32_t slb = (sl << 4) + sbo;  // staging: LDS byte offset of the lane's first float4
   for (uint32_t it = 0; it < n_it; ++it) {
     if (it) __syncthreads();  // the previous tile's gathers are done
-#pragma unroll
-    for (int u = 0; u < 8; ++u) reinterpret_cast<float4 *>(s)[sl ^ (sw((uint32_t)u << (kMwT - 3)) >> 1)] = v[u];
+    static_for<8>([&](auto u) { lds_st128(slb ^ (sw((uint32_t)u << (kMwT - 3)) << 3), v[u]); });
     __syncthreads();
     if (it + 1 < n_it) {
       const char *st = tile_ptr(tile0 + it + 1);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8));
+      static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
     }
-#pragma unroll
-    for (int g = LOW ? 0 : 1; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
-      const uint32_t bs = sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3));
+    static_for<LOW ? 3 : 2>([&](auto gg) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
+      constexpr int g = LOW ? (int)gg : (int)gg + 1;
+      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3)) << 3) + sbo;
       v2f r[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const float2 x = s[bs ^ sw((uint32_t)c << (4 * g))];
-        r[c] = (v2f){x.x, x.y};
-      }
+      static_for<16>([&](auto c) {
+        const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << (4 * g)) << 3));
+        r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+      });
       float pr[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
+      static_for<16>([&](auto c) {
         const v2f qq = r[c] * r[c];
         pr[c] = qq.x + qq.y;
-      }
+      });
       // populations: signed sums over each of the 4 bits + the total, pruned butterfly
       float h0 = 0.f, h1 = 0.f, h2 = 0.f, s1[8], s2[4], s3[2];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; }
+      static_for<8>([&](auto i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; });
+      static_for<4>([&](auto i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; });
+      static_for<2>([&](auto i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; });
       acc[3 * (4 * g + 0) + 2] += h0;
       acc[3 * (4 * g + 1) + 2] += h1;
       acc[3 * (4 * g + 2) + 2] += h2;
       acc[3 * (4 * g + 3) + 2] += s3[0] - s3[1];
       if (g == 1) acc[36] += s3[0] + s3[1];
       // cross terms x conj(y) over the 8 pairs of each bit: two packed fmas per pair
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        v2f sum = {0.f, 0.f};  // (accumulating from zero and adding afterwards saves hipcc 34 VGPRs)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c & (1 << t)) continue;
+      static_for<4>([&](auto t) {
+        v2f sum = {0.f, 0.f};  // (accumulating from zero and adding afterwards keeps the chains short)
+        static_for<8>([&](auto pq) {
+          constexpr int lo = (1 << t) - 1;
+          constexpr int c = ((pq & ~lo) << 1) | (pq & lo);
           const v2f x = r[c], y = r[c | (1 << t)];
           sum = __builtin_elementwise_fma(x, y.xx, sum);
           sum = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, sum);
-        }
+        });
         acc[3 * (4 * g + t)] += sum.x;
         acc[3 * (4 * g + t) + 1] += sum.y;
-      }
-    }
+      });
+    });
   }
   const int lane = tid & (kWave - 1), w = tid / kWave;
   if (LOW) {

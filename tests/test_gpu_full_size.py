@@ -178,6 +178,34 @@ def test_k2_one_gib_launch_default_vs_all_live_vs_c_port():
         assert np.abs(ez - e_live[b]).max() < 2e-6, (b, np.abs(ez - e_live[b]).max())
 
 
+def test_multi_tile_workgroups_state_and_probs_vs_c_port():
+    """All-live storing passes hand a workgroup several consecutive tiles once the grid is large
+    enough (n = 22 x 16 states: 2 tiles per workgroup, next tile prefetched into registers).  The
+    TM_STORE and TM_PROBS epilogues of that variant against the oracle's C port, and against the
+    default engine (known zeros tracked, one tile per workgroup)."""
+    N = _N()
+    from oracle import c_port
+    from tests.test_abi_cpu import he_layer_ops
+
+    n, B = 22, 16
+    ops, slots = he_layer_ops(n)
+    rng = np.random.default_rng(22016)
+    ang_h = rng.uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)
+    ang = torch.from_numpy(ang_h).cuda()
+    dense = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+    assert all(s["fast"] for s in dense.describe()["stages"])
+    st = dense.run(ang, "state")
+    pr = dense.run(ang, "probs")
+    ref = N.Plan(ops, n, slots).run(ang, "state")
+    assert float((torch.view_as_real(st) - torch.view_as_real(ref)).abs().max()) < 3e-7
+    assert float((pr - (ref.real ** 2 + ref.imag ** 2)).abs().max()) < 1e-9
+    for b in (0, 7, B - 1):
+        tape = [(name, wires, tuple(float(ang_h[b, s]) for s in sl)) for name, wires, sl, _ in ops]
+        psi = c_port.simulate(tape, n)
+        assert np.abs(st[b].cpu().numpy() - psi).max() < 3e-7
+        assert np.abs(pr[b].cpu().numpy() - np.abs(psi) ** 2).max() < 2e-8
+
+
 def test_c3_expressibility_full_size_sampled_oracle():
     """BASELINE config 3: 12 qubits, 1024 pairs (2048 parameter sets), HE 3 layers, no DRU."""
     from oracle import circuits as OC, einsum_sim as OE
