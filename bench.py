@@ -179,6 +179,14 @@ def roofline_of(run, dense, traffic_key=None):
             rec = json.load(open(tpath)).get(traffic_key)
             if rec:
                 traffic, source = rec["hbm_bytes_per_launch"], rec.get("source")
+                # per launch like `achieved`: the counters were collected at rec["states_per_launch"]
+                per_launch = run["B"] * run["steps"] * sum(
+                    1 for i, st in enumerate(run["desc"]["stages"])
+                    if kernel_of_stage(st, i, len(run["desc"]["stages"]), run["n"], dense) == name
+                ) / max(1, dom["launches"])
+                if rec.get("states_per_launch") and abs(per_launch - rec["states_per_launch"]) > 0.5:
+                    traffic = round(traffic * per_launch / rec["states_per_launch"])
+                    source = (source or "") + f" (scaled from {rec['states_per_launch']} to {per_launch:g} states per launch)"
         except Exception:
             pass
     return {

@@ -4308,12 +4308,21 @@ static int default_states_in_flight(const qmle_plan *p, int batch) {
   // from 1 to 32 states in flight, +1 % more at 128 (profiles/r01_in_flight_sweep.txt); runs
   // that skip known zeros are launch-bound at 32 (11.5 M -> 14.3 M -> 15.2 M gate-applies/s at
   // 32 / 128 / 512 states, K2).  32 GiB of state buffers = 256 states at n = 24.
+  // Round 2: a plan whose every pass streams the whole state (no known zeros left to skip) is
+  // not launch-bound, and its passes run faster on a 4 GiB than on a 32 GiB working set -- K2
+  // all-live at n = 24: 111.0 / 111.6 / 108.3 / 107.2 / 107.7 ms per 1024 states for 32 / 16 /
+  // 8 / 4 / 2 GiB per launch (the read+write pass: 56.6 vs 51.6 us per state at 256 vs 64
+  // states); the known-zero plans keep 32 GiB (3.0 vs 4.9 ms per step at 4 GiB).
   const size_t sb = (size_t)8 << p->n;
-  static const size_t budget_mib = [] {
+  static const long env_mib = [] {
     const char *e = getenv("QMLE_IN_FLIGHT_MIB");  // tuning knob; default from measurements
-    const long v = e ? atol(e) : 0;
-    return (size_t)(v > 0 ? v : 32768);
+    return e ? atol(e) : 0L;
   }();
+  bool whole_state_every_pass = p->stages.size() >= 2;
+  if (plan_sparse(p))
+    for (size_t si = 1; si < p->stages.size(); ++si)
+      if (p->stages[si].zero_in != 0) whole_state_every_pass = false;
+  const size_t budget_mib = env_mib > 0 ? (size_t)env_mib : whole_state_every_pass ? 4096 : 32768;
   size_t s = (budget_mib << 20) / sb;
   if (s < 1) s = 1;
   if (s > (size_t)batch) s = (size_t)batch;

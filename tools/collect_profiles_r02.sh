@@ -15,8 +15,8 @@ echo "[2] kernel stats of the headline command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- \
   python3 $R/bench.py --steps 2 --warmup 1 --skip-aux > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -n 1) $OUT/${TAG}_bench_kernel_stats.csv
-echo "[3] HBM counters, all-live K2 plan at the bench's 256 states per launch"
-export PMC_N=24 PMC_B=256 PMC_FLAGS=160   # QMLE_PLAN_NO_SPARSE | QMLE_PLAN_NO_ABSORB
+echo "[3] HBM counters, all-live K2 plan at the engine's 32 states per launch (4 GiB of states)"
+export PMC_N=24 PMC_B=32 PMC_FLAGS=160   # QMLE_PLAN_NO_SPARSE | QMLE_PLAN_NO_ABSORB
 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/rd -o rd -- \
   python3 $R/tools/pmc_target.py > $OUT/rd.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/wr -o wr -- \
