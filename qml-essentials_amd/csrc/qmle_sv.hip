@@ -772,7 +772,12 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
       // (sw() is linear over XOR and nt a power of two: one address per lane, 16 wave-uniform
       // offsets -- not 16 adds + swizzles)
       float pr[16];
-      const uint32_t e0 = (sw((uint32_t)tid) << 3) + lds_offset_of(s);
+      // (opaque copy of the thread index: inside k_tile2's tile loop hipcc would otherwise hoist
+      // the 16 addresses and the six lane-bit masks out of the loop and keep ~30 registers live
+      // across the gates)
+      uint32_t tid_e = (uint32_t)tid;
+      asm volatile("" : "+v"(tid_e));
+      const uint32_t e0 = (sw(tid_e) << 3) + lds_offset_of(s);
 #pragma unroll
       for (int h = 0; h < 16; h += 8) {  // 8 reads in flight (hipcc would keep 3, to save registers)
         u64 amp[8];
@@ -796,7 +801,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
       h3 = s3[0] - s3[1];
       // per wave: the total, the six lane-bit signed totals and h0..h3 through DPP wave sums
       // (66 v_add_f32_dpp, nothing on the LDS crossbar); wave-index bits are signed afterwards
-      const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
+      const int lane = (int)(tid_e & (kWave - 1)), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
       float v[11];
 #pragma unroll
       for (int j = 0; j < 6; ++j) v[j] = ((lane >> j) & 1) ? -tot : tot;
@@ -1162,10 +1167,15 @@ __device__ __forceinline__ void f_cdiag(A16 &a, const Mat2S &M) {
   QMLE_CMUL4(at<i0>(a), at<i1>(a), at<i2>(a), at<i3>(a), m00);
   QMLE_CMUL4(at<i0 | S>(a), at<i1 | S>(a), at<i2 | S>(a), at<i3 | S>(a), m11);
 }
+// A swap as three real moves, in place: as a renaming (t = a; a = b; b = t in C++) it is free in
+// the X / CX cases but makes every amplitude's register depend on the case taken, and the joins
+// of the gate switch then cost ~21 v_mov_b64 per gate on EVERY path (measured: 419 instead of 292
+// vector instructions for a group of four dense gates).  X / CX inside a group are rare (most are
+// folded into the LDS layout), the dense cases are what the loop runs.
 template <int I, int J> __device__ __forceinline__ void swap_amp(A16 &a) {
-  const u64 t = at<I>(a);
-  at<I>(a) = at<J>(a);
-  at<J>(a) = t;
+  u64 t;
+  asm volatile("v_mov_b64 %2, %0\n\tv_mov_b64 %0, %1\n\tv_mov_b64 %1, %2"
+               : "+v"(at<I>(a)), "+v"(at<J>(a)), "=&v"(t));
 }
 template <int TB>
 __device__ __forceinline__ void f_x(A16 &a) {
@@ -1358,7 +1368,7 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
 // a small register budget).  MULTI: several tiles per workgroup (f.tpw), plain all-live stages
 // with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
 template <bool NT, bool MEASURE, bool MULTI>
-__global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args f) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
   const int T = a.T;
@@ -1449,7 +1459,19 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
   }
+  const uint32_t sl_outer = sl;
   for (int i = 0; i < tpw; ++i) {
+    uint32_t sl = sl_outer;  // (opaque per tile: keeps the 8 staging addresses out of loop-carried registers)
+    if (MULTI) asm volatile("" : "+v"(sl));
+    if (MULTI && MEASURE && i > 0) {
+      // measuring passes walk their tiles without prefetch: with the next tile's 32 registers
+      // live across the epilogue the kernel needs 121 VGPRs (4 workgroups per CU) and gains
+      // nothing; what the walk saves is the workgroup turnover (launch gap + prologue per tile)
+      base += f.tile_stride;
+      st += f.tile_stride * sizeof(float2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+    }
     if (!MULTI && a.init_zero) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) lds_st128(sl ^ soff[u], z4);
@@ -1476,7 +1498,7 @@ __global__ void __launch_bounds__(512) k_tile2(const TileArgs a, const Tile2Args
     __syncthreads();
     char *st_cur = st;
     const uint64_t base_cur = base;
-    if (i + 1 < tpw) {  // (plain stages only) the next tile: loads in flight from here on
+    if (!MEASURE && i + 1 < tpw) {  // (plain storing stages only) the next tile: loads in flight from here on
       base += f.tile_stride;  // (tpw tiles share all but the lowest outer bits: launch_tile)
       st += f.tile_stride * sizeof(float2);
 #pragma unroll
@@ -3919,6 +3941,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       QMLE_T2_LDS(false, false, false); QMLE_T2_LDS(true, false, false);
       QMLE_T2_LDS(false, true, false); QMLE_T2_LDS(true, true, false);
       QMLE_T2_LDS(false, false, true); QMLE_T2_LDS(true, false, true);
+      QMLE_T2_LDS(false, true, true); QMLE_T2_LDS(true, true, true);
 #undef QMLE_T2_LDS
     }
     Tile2Args f;
@@ -3971,9 +3994,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     f.tpw = 1;
     f.tile_stride = 0;
     if (!a.init_zero && !a.zin_local && !a.zin_outer && !a.compact && st.T < p->n &&
-        (meas == TM_STORE || meas == TM_PROBS)) {
-      // (measured for the TM_EXPVAL_PARTIAL epilogue too: no gain -- that pass is bound by its
-      // vector instructions, not by loads in flight -- so it keeps one tile per workgroup)
+        (meas == TM_STORE || meas == TM_PROBS || meas == TM_EXPVAL_PARTIAL)) {
       // (consecutive tile indices differ in the lowest run of outer bit positions only)
       int run0 = 1;
       while (run0 < p->n - st.T && st.outer_bits[run0] == st.outer_bits[0] + run0) ++run0;
@@ -3995,7 +4016,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   hipLaunchKernelGGL((k_tile2<NT, ME, MU>), grid, dim3(threads), lds2, stream, a, f)
     const bool multi = f.tpw > 1;
     if (measure) {
-      if (a.nt) QMLE_T2_GO(true, true, false); else QMLE_T2_GO(false, true, false);
+      if (multi) { if (a.nt) QMLE_T2_GO(true, true, true); else QMLE_T2_GO(false, true, true); }
+      else { if (a.nt) QMLE_T2_GO(true, true, false); else QMLE_T2_GO(false, true, false); }
     } else {
       if (multi) { if (a.nt) QMLE_T2_GO(true, false, true); else QMLE_T2_GO(false, false, true); }
       else { if (a.nt) QMLE_T2_GO(true, false, false); else QMLE_T2_GO(false, false, false); }

@@ -137,13 +137,13 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
     direct = [v for k, v in res.items() if "k_direct_1q" in k]
     assert direct and all(r["Occupancy"] >= 7 for r in direct)
     # the fast tile kernel: far below the 96 VGPRs that 5 workgroups of 32 KiB per CU allow (the 16
-    # amplitudes live in 32 registers, no copies around the gate dispatch); the multi-tile variant
-    # adds the next tile's 8 float4 per lane and runs 4 workgroups per CU
+    # amplitudes live in 32 registers, no copies around the gate dispatch); the multi-tile variants
+    # (next tile's 8 float4 per lane in flight / tile loop around the epilogue) stay within 96 too
     fast = {k: v for k, v in res.items() if "k_tile2" in k}
-    assert len(fast) == 6
+    assert len(fast) == 8
     for name, r in fast.items():
         multi = "ELb1EEEv" in name
-        assert r["Occupancy"] >= (4 if multi else 5) and r["VGPRs"] <= (104 if multi else 64), (name, r)
+        assert r["Occupancy"] >= 5 and r["VGPRs"] <= (96 if multi else 64), (name, r)
 
 
 def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
