@@ -1364,6 +1364,82 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
 #undef QMLE_OFF
 }
 
+// <Z> of every bit for the multi-tile measuring variant: the per-tile part only squares and adds
+// (pruned Walsh-Hadamard butterfly over the four in-thread bits); the sums stay per work item
+// across the tiles a workgroup walks -- acc = {total, h0..h3, total signed by bit 0 / 1 / 2 of
+// the tile's index inside the walk} -- and the cross-lane reduction, the row assembly and the
+// store run once per workgroup (`tile_z_finish`): no barrier, no DPP chain, no global store per
+// tile.
+__device__ __forceinline__ void tile_z_accumulate(uint32_t sbo, int T, int tid, int i, float (&acc)[8]) {
+  uint32_t tid_e = (uint32_t)tid;
+  asm volatile("" : "+v"(tid_e));  // (keeps the 16 addresses out of loop-carried registers)
+  const uint32_t e0 = (sw(tid_e) << 3) + sbo;
+  float pr[16];
+#pragma unroll
+  for (int h = 0; h < 16; h += 8) {
+    u64 amp[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) amp[it] = lds_ld64(e0 ^ (sw((uint32_t)(h + it) << (T - 4)) << 3));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      pr[h + it] = norm2(make_float2(__uint_as_float((uint32_t)amp[it]), __uint_as_float((uint32_t)(amp[it] >> 32))));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, s1[8], s2[4], s3[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = pr[2 * k] + pr[2 * k + 1]; h0 += pr[2 * k] - pr[2 * k + 1]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s2[k] = s1[2 * k] + s1[2 * k + 1]; h1 += s1[2 * k] - s1[2 * k + 1]; }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { s3[k] = s2[2 * k] + s2[2 * k + 1]; h2 += s2[2 * k] - s2[2 * k + 1]; }
+  const float tot = s3[0] + s3[1];
+  acc[0] += tot;
+  acc[1] += h0;
+  acc[2] += h1;
+  acc[3] += h2;
+  acc[4] += s3[0] - s3[1];
+  acc[5] += (i & 1) ? -tot : tot;  // (i is wave-uniform)
+  acc[6] += (i & 2) ? -tot : tot;
+  acc[7] += (i & 4) ? -tot : tot;
+}
+// Row [33] of workgroup `row` of sample b: thread q < n assembles <Z> of position q from qsrc
+// (see TileArgs::qsrc): lane bit, in-thread bit, wave bit, or outer position = bit of the tile
+// index -- one of the `lg` walk bits (own signed sums) or a bit of the workgroup index.
+__device__ __forceinline__ void tile_z_finish(float *out, float *red, float (&acc)[8], int qsrc, int tid,
+                                              int nt, int lg, uint32_t row, uint32_t n_rows, int b) {
+  const int lane = tid & (kWave - 1), w = tid / kWave, nw = (nt + kWave - 1) / kWave;
+  float v[14];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) v[j] = ((lane >> j) & 1) ? -acc[0] : acc[0];
+  v[6] = acc[1]; v[7] = acc[2]; v[8] = acc[3]; v[9] = acc[4]; v[10] = acc[0];
+  v[11] = acc[5]; v[12] = acc[6]; v[13] = acc[7];
+  wave_sums_dpp63(v);
+  __syncthreads();  // every amplitude of the last tile has been read: the tile buffer is scratch
+  if (lane == kWave - 1) {
+#pragma unroll
+    for (int j = 0; j < 14; ++j) red[w * 14 + j] = v[j];
+  }
+  __syncthreads();
+  if (tid <= QMLE_MAX_QUBITS) {
+    float r = 0.f;
+    if (qsrc < 16) {
+      for (int k = 0; k < nw; ++k) r += red[k * 14 + qsrc];
+    } else if (qsrc < 32) {
+      for (int k = 0; k < nw; ++k) r += ((k >> (qsrc - 16)) & 1) ? -red[k * 14 + 10] : red[k * 14 + 10];
+    } else if (qsrc < 64) {
+      const int t = qsrc - 32;
+      if (t < lg) {
+        for (int k = 0; k < nw; ++k) r += red[k * 14 + 11 + t];
+      } else {
+        for (int k = 0; k < nw; ++k) r += red[k * 14 + 10];
+        if ((row >> (t - lg)) & 1u) r = -r;
+      }
+    }
+    out[((size_t)b * n_rows + row) * (QMLE_MAX_QUBITS + 1) + tid] = r;
+  }
+}
+
 // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own instantiation: the storing kernel keeps
 // a small register budget).  MULTI: several tiles per workgroup (f.tpw), plain all-live stages
 // with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
@@ -1460,6 +1536,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
   }
   const uint32_t sl_outer = sl;
+  float zacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // MEASURE && MULTI: tile_z_accumulate
   for (int i = 0; i < tpw; ++i) {
     uint32_t sl = sl_outer;  // (opaque per tile: keeps the 8 staging addresses out of loop-carried registers)
     if (MULTI) asm volatile("" : "+v"(sl));
@@ -1507,9 +1584,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
 
     tile2_groups(sbo, addr, f, mrow, tid, !MULTI && a.zin_local != 0);  // known zeros: Stage::zero_in
 
-    if (MEASURE) {
+    if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
+      if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
+    } else if (MEASURE) {
       if (!(f.dbg & 2))
-        tile_epilogue<false, MULTI>(a, s, nullptr, red, tile + (uint32_t)i, n_tiles, b, base_cur, qsrc);
+        tile_epilogue<false>(a, s, nullptr, red, tile + (uint32_t)i, n_tiles, b, base_cur, qsrc);
     } else if (a.meas == TM_STORE) {
       if (MULTI) {  // (the next tile's 8 float4 are live: two batches of four keep <= 96 VGPRs)
 #pragma unroll
@@ -1538,6 +1617,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     }
     if (i + 1 < tpw) __syncthreads();  // the tile buffer (and the epilogue's scratch in it) is reused
   }
+  if (MEASURE && MULTI && !(f.dbg & 2))
+    tile_z_finish(reinterpret_cast<float *>(a.out), red, zacc, qsrc, tid, nt, 31 - __builtin_clz((unsigned)tpw),
+                  blockIdx.x, gridDim.x, b);
 }
 
 // ---- measuring pass in registers -----------------------------------------------------------
@@ -3794,7 +3876,9 @@ static bool plan_sparse(const qmle_plan *p) {
 int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float *mats,
                 const float *angles, int batch, bool init_zero, int meas, void *out,
                 const uint32_t *obs_masks, int n_obs, hipStream_t stream,
-                bool from_zero = false, float2 *cols = nullptr) {
+                bool from_zero = false, float2 *cols = nullptr, int *row_shift = nullptr) {
+  // *row_shift: TM_EXPVAL_PARTIAL rows cover 2^row_shift tiles each (multi-tile k_tile2)
+  if (row_shift) *row_shift = 0;
   from_zero = from_zero && plan_sparse(p);
   TileArgs a = fill_tile_args(p, st, states, mats, angles, init_zero, meas, out, obs_masks, n_obs,
                               from_zero);
@@ -3990,7 +4074,10 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                     (((u >> 2) & 1u) << st.tile_bits[st.T - 1])) << 3;
     // plain all-live stages: several consecutive tiles per workgroup (next tile prefetched into
     // registers), as long as the grid still fills the chip a few times over
-    static const int tpw_max = std::getenv("QMLE_T2_TPW") ? atoi(std::getenv("QMLE_T2_TPW")) : 4;
+    // (default 4 for storing passes, 8 for the measuring pass, whose per-workgroup reduction is
+    // then shared by 8 tiles: K2 pass 3 29.2 / 24.5 / 23.8 / 23.6 us per state at 1 / 2 / 4 / 8)
+    static const int tpw_env = std::getenv("QMLE_T2_TPW") ? atoi(std::getenv("QMLE_T2_TPW")) : 0;
+    const int tpw_max = tpw_env > 0 ? tpw_env : meas == TM_EXPVAL_PARTIAL ? 8 : 4;
     f.tpw = 1;
     f.tile_stride = 0;
     if (!a.init_zero && !a.zin_local && !a.zin_outer && !a.compact && st.T < p->n &&
@@ -4003,6 +4090,14 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
              (uint64_t)(grid.x / 2u) * grid.y >= 5120) {
         f.tpw *= 2;
         grid.x /= 2u;
+      }
+    }
+    if (meas == TM_EXPVAL_PARTIAL && f.tpw > 1) {
+      if (!row_shift || f.tpw > 8) {  // the caller must know the row layout
+        grid.x *= (unsigned)f.tpw;
+        f.tpw = 1;
+      } else {
+        *row_shift = 31 - __builtin_clz((unsigned)f.tpw);
       }
     }
     static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
@@ -4578,6 +4673,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
     const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
     bool initialised = false;
     int reg_q = -1;  // >= 0: the last pass ran as k_reg_measure with 2^reg_q tiles per row
+    int tile_row_shift = 0;  // k_tile2's multi-tile measuring variant: 2^shift tiles per row
     for (size_t si = 0; si < plan->stages.size(); ++si) {
       const Stage &st = plan->stages[si];
       ProfScope prof_scope(plan, (int)si, stream);
@@ -4593,7 +4689,8 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
         rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
                          last_fused ? n_obs : 0, stream, /*from_zero=*/true,
-                         d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr);
+                         d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr,
+                         last_fused ? &tile_row_shift : nullptr);
         initialised = true;
       } else {
         if (!initialised) {
@@ -4625,7 +4722,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
       ObsBits ob;  // column of the 33-float row: the bit's sum, or (masks) the observable's own
       for (int k = 0; k < n_obs; ++k) ob.bits[k] = (single_bits && reg_q < 0) ? obs_bits[k] : (int8_t)k;
-      const int tiles = (1 << (n - plan->stages.back().T)) >> (reg_q < 0 ? 0 : reg_q);
+      const int tiles = (1 << (n - plan->stages.back().T)) >> (reg_q < 0 ? tile_row_shift : reg_q);
       hipLaunchKernelGGL(k_expval_final, dim3(bc, n_obs), dim3(256), 0, stream, (const float *)d_partial,
                          tiles, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {
