@@ -3448,17 +3448,26 @@ __global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) 
   static_for<37>([&](auto k) { acc[k] = 0.f; });
   const uint32_t sbo = lds_offset_of(smem4);
   const uint32_t slb = (sl << 4) + sbo;  // staging: LDS byte offset of the lane's first float4
+  constexpr bool kMwPrefetch = true;  // (without it: 1.43 - 1.44 instead of 1.39 - 1.41 ms at n = 28)
   for (uint32_t it = 0; it < n_it; ++it) {
     if (it) __syncthreads();  // the previous tile's gathers are done
+    if (!kMwPrefetch && it) {
+      const char *st = tile_ptr(tile0 + it);
+      static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
+    }
     static_for<8>([&](auto u) { lds_st128(slb ^ (sw((uint32_t)u << (kMwT - 3)) << 3), v[u]); });
     __syncthreads();
-    if (it + 1 < n_it) {
+    if (kMwPrefetch && it + 1 < n_it) {
       const char *st = tile_ptr(tile0 + it + 1);
       static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
     }
+    // (opaque per tile: hipcc would hoist the 32 - 48 gather addresses out of the tile loop and
+    // keep them in registers across it)
+    uint32_t tid_i = tidv;
+    asm volatile("" : "+v"(tid_i));
     static_for<LOW ? 3 : 2>([&](auto gg) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
       constexpr int g = LOW ? (int)gg : (int)gg + 1;
-      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3)) << 3) + sbo;
+      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tid_i, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3)) << 3) + sbo;
       v2f r[16];
       static_for<16>([&](auto c) {
         const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << (4 * g)) << 3));
