@@ -936,6 +936,9 @@ int compile_plan(qmle_plan *p) {
       const double c = cost();
       if (c < best_cost) { best_cost = c; best = k; }
     }
+    // (tuning only: force one of the 12 candidates to measure it against the model's choice)
+    static const int force = std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;
+    if (force >= 0 && force < 12 && cand[force % 6][0] < n) best = force;
     schedule(cand[best % 6][0], cand[best % 6][1], best >= 6);
   }
   return QMLE_OK;
