@@ -1456,11 +1456,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   float *red = a.meas == TM_EXPVAL ? reinterpret_cast<float *>(s + (1u << T)) : reinterpret_cast<float *>(s);
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
   const int b = blockIdx.y;
-  // Plain all-live stages give a workgroup `tpw` consecutive tiles: the next tile's 8 float4 per
-  // lane are in flight (in registers) while this tile's gates and epilogue run, so a workgroup
-  // that computes still has HBM requests outstanding.  (One tile per workgroup left the
-  // measuring pass at 30 us per state with 20 us of traffic: five workgroups per CU, of which
-  // too few were in their load phase at any time.)  Known-zero stages keep one tile each.
+  // Plain all-live stages give a workgroup `tpw` consecutive tiles (MULTI).  Storing passes keep
+  // the next tile's 8 float4 per lane in flight in registers while this tile's gates run;
+  // measuring passes walk without that prefetch but keep their <Z> sums in registers across the
+  // walk and reduce once (tile_z_accumulate / tile_z_finish).  Both save the workgroup turnover
+  // (launch gap + prologue) per tile.  K2 at n = 24: read+write pass 54 -> 51 us per state,
+  // measuring pass 29 -> 23.6.  Known-zero stages keep one tile per workgroup.
   const int tpw = MULTI ? f.tpw : 1;
   uint32_t tile = blockIdx.x * (uint32_t)tpw;
   if (!MULTI && a.compact) {  // blockIdx.x enumerates the tiles that can be non-zero (launch_tile)
@@ -1541,9 +1542,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     uint32_t sl = sl_outer;  // (opaque per tile: keeps the 8 staging addresses out of loop-carried registers)
     if (MULTI) asm volatile("" : "+v"(sl));
     if (MULTI && MEASURE && i > 0) {
-      // measuring passes walk their tiles without prefetch: with the next tile's 32 registers
-      // live across the epilogue the kernel needs 121 VGPRs (4 workgroups per CU) and gains
-      // nothing; what the walk saves is the workgroup turnover (launch gap + prologue per tile)
+      // measuring passes walk their tiles without prefetch (measured with it, before and after
+      // the sums moved into registers: no gain)
       base += f.tile_stride;
       st += f.tile_stride * sizeof(float2);
 #pragma unroll
@@ -1576,7 +1576,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     char *st_cur = st;
     const uint64_t base_cur = base;
     if (!MEASURE && i + 1 < tpw) {  // (plain storing stages only) the next tile: loads in flight from here on
-      base += f.tile_stride;  // (tpw tiles share all but the lowest outer bits: launch_tile)
+      base += f.tile_stride;  // (the tiles of a walk differ in the lowest outer bits only: launch_tile)
       st += f.tile_stride * sizeof(float2);
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
