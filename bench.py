@@ -443,9 +443,15 @@ def main():
                       "amplitudes are never touched")
         result["exact_shortcuts"] = s2
         del sc
-        # all amplitudes live, trailing CX layer folded into the observables: 72 gates applied
+        # all amplitudes live, observable folding left to the engine: on live input it now applies
+        # the trailing CX layer (free in the fast tile path) instead of folding it -- the folded
+        # form's last pass (k_reg_measure) was the slower one (112 vs 100 ms per step)
         fo = timed_k2(n, B, size, max(3, a.steps // 4), 1, N.PLAN_NO_SPARSE)
         result["k2_all_live_cx_folded"] = summarize(fo, True, count_gates=n_gates - fo["folded"])
+        result["k2_all_live_cx_folded"]["gates_folded_into_observables"] = fo["folded"]
+        result["k2_all_live_cx_folded"]["note"] = (
+            "QMLE_PLAN_NO_SPARSE only: the engine chooses between folding the trailing CX layer into "
+            "the observables and applying it (pass-cost model, DESIGN 4.6); 0 folded = it applied them")
         del fo
         # a deeper circuit: 4 layers with data re-uploading = 5 ansatz + 4 encoding layers
         try:

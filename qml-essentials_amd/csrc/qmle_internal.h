@@ -174,6 +174,7 @@ struct qmle_plan {
   std::vector<qmle::Stage> stages;
   uint32_t mat_floats = 0;                // per-sample matrix row length
   int fold_groups = 0;                    // most gate groups of any Stage::product_ok stage
+  double model_cost = 0.0;                // pass-cost model of the chosen schedule (us per state at n = 24 scale)
   bool whole_state_lds = false;
   int tile_T = 0, tile_L = 0;
   double algo_bytes_per_state = 0;

@@ -941,6 +941,7 @@ int compile_plan(qmle_plan *p) {
     if (force >= 0 && force < 12 && cand[force % 6][0] < n) best = force;
     schedule(cand[best % 6][0], cand[best % 6][1], best >= 6);
   }
+  p->model_cost = cost();
   return QMLE_OK;
 }
 
@@ -987,7 +988,7 @@ std::string describe_plan(const qmle_plan *p) {
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
      << ",\"n_lowered\":" << p->lowered.size()
      << ",\"whole_state_lds\":" << (p->whole_state_lds ? "true" : "false")
-     << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
+     << ",\"model_cost\":" << p->model_cost << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
      << ",\"mat_floats\":" << p->mat_floats
      << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state << ",\"stages\":[";
   for (size_t s = 0; s < p->stages.size(); ++s) {

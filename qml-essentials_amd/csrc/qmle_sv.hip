@@ -4371,6 +4371,36 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
         c->extra_algo_last_stage = p->absorbed_algo_bytes;
         if (compile_plan(c) == QMLE_OK) p->expval_child = c;
         else delete c;
+        // Folding is not free any more (round 2): a folded CX tail turns <Z_w> into parities,
+        // which the last tile pass measures with the general-mask epilogue (per tile: full
+        // Walsh-Hadamard transform across the lanes) or, one-group passes on live input, with
+        // k_reg_measure -- while the fast tile path applies X / CX for nothing (LDS layout) and
+        // then takes the single-bit epilogue, whose sums stay in registers across a workgroup's
+        // tiles.  Measured (MI355X, HE circuits, us per state, folded vs applied): n = 24: 2
+        // layers 61.9 vs 45.5, 4 layers 115.8 vs 135.0; n = 22, 3 layers 25.4 vs 20.8; n = 20, 4
+        // layers 8.9 vs 11.2.  The pass-cost model plus 17 (general-mask epilogue) resp. 12
+        // (k_reg_measure on live input), in its units of 36 per read+write pass, picks the faster
+        // plan in all of them; plans whose folded form ends in a known-zero special kernel keep it.
+        static const bool always_fold = std::getenv("QMLE_ALWAYS_FOLD") != nullptr;
+        if (p->expval_child && !always_fold && !c->stages.empty() && !c->whole_state_lds) {
+          bool parity = false;
+          for (int w = 0; w < p->n; ++w) {
+            const uint32_t m = pull_back_z(p->absorbed, w);
+            if (m & (m - 1u)) parity = true;
+          }
+          const size_t last = c->stages.size() - 1;
+          const Stage &ls = c->stages[last];
+          const int kind = expval_kernel_of(c, last, plan_sparse(c));
+          double penalty = 0.0;
+          if (ls.kind == ST_TILE && parity) {
+            if (kind == 0) penalty = 17.0;
+            else if (kind == 1 && (!plan_sparse(c) || ls.zero_in == 0)) penalty = 12.0;
+          }
+          if (penalty > 0.0 && c->model_cost + penalty > p->model_cost) {
+            delete c;
+            p->expval_child = nullptr;
+          }
+        }
       }
     }
     if (!p->expval_child) p->absorbed.clear();

@@ -167,9 +167,23 @@ def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
     assert st[0]["read_bytes_from_zero"] == 0 and st[0]["write_bytes_from_zero"] == 8 * 2**12
     assert st[1]["read_bytes_from_zero"] == 8 * 2**12 and st[1]["write_bytes_from_zero"] == 8 * 2**20
     assert st[2]["read_bytes_from_zero"] == 8 * 2**20
-    # switched off: dense passes, the k_tile epilogue's register-resident sibling still measures
-    dense = N.Plan(ops, 24, slots, flags=N.plan_flags(no_sparse=True)).describe()["expval_plan"]["stages"]
-    assert dense[1]["read_bytes_from_zero"] == 8 * 2**24 and dense[2]["expval_kernel"] == "k_reg_measure"
+    # switched off: dense passes.  The folded form would end in k_reg_measure on live input; the
+    # engine now applies the trailing CX layer instead (free in the fast tile path, single-bit
+    # epilogue) unless told to fold regardless
+    top_dense = N.Plan(ops, 24, slots, flags=N.plan_flags(no_sparse=True)).describe()
+    assert "expval_plan" not in top_dense and all(s["fast"] for s in top_dense["stages"])
+    assert top_dense["stages"][1]["read_bytes_from_zero"] == 8 * 2**24
+    # deeper circuits: folding stays where the model says it pays (4 layers), not where the
+    # folded plan's general-mask epilogue costs more than the CX layer (2 layers)
+    def layers(k):
+        o, s = [], 0
+        for _ in range(k):
+            oo, ss = he_layer_ops(24)
+            o += [(g, w, [x + s for x in sl], m) for g, w, sl, m in oo]
+            s += ss
+        return o, s
+    assert "expval_plan" not in N.Plan(*((lambda t: (t[0], 24, t[1]))(layers(2)))).describe()
+    assert N.Plan(*((lambda t: (t[0], 24, t[1]))(layers(4)))).describe()["absorbed_ops"] == 24
     # tape order keeps the old schedule (high wires first)
     tape = N.Plan(ops, 24, slots, flags=N.plan_flags(tape_order=True)).describe()["expval_plan"]["stages"]
     assert tape[0]["bits"] == [0, 1, 2, 3] + list(range(16, 24))
