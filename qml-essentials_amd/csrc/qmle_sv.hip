@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <utility>
 
@@ -2794,7 +2795,10 @@ k_expval_partial(const float4 *__restrict__ states, int n, float *__restrict__ p
 }
 
 struct ObsBits {
-  int8_t bits[QMLE_MAX_QUBITS];
+  int8_t bits[QMLE_MAX_QUBITS] = {};
+  // row i of observable k counts with sign (-1)^popcount(row_mask[k] & i): observables that are Z
+  // on ONE position of the last tile times Z's on outer positions (bits of the tile index)
+  uint32_t row_mask[QMLE_MAX_QUBITS] = {};
 };
 
 // one block per (state, observable): fp64 sum of that bit's column over all partial rows
@@ -2804,9 +2808,12 @@ k_expval_final(const float *__restrict__ partial, int n_blocks, int n_obs, ObsBi
   __shared__ double red[16];
   const int b = blockIdx.x, k = blockIdx.y;
   const float *pp = partial + (size_t)b * n_blocks * (QMLE_MAX_QUBITS + 1) + obs.bits[k];
+  const uint32_t rm = obs.row_mask[k];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x)
-    acc += (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1)];
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+    const double v = (double)pp[(size_t)i * (QMLE_MAX_QUBITS + 1)];
+    acc += (__popc(rm & (uint32_t)i) & 1) ? -v : v;
+  }
   const double tot = block_sum_d(acc, red);
   if (threadIdx.x == 0) out[(size_t)b * n_obs + k] = (float)tot;
 }
@@ -4292,6 +4299,7 @@ int run_expval(const float2 *states, int n, int batch, const int8_t *obs_bits, i
   const size_t need = (size_t)batch * nb * (QMLE_MAX_QUBITS + 1) * sizeof(float);
   if (ws_bytes < need) return QMLE_ERR_WORKSPACE;
   ObsBits ob;
+  for (int k = 0; k < QMLE_MAX_QUBITS; ++k) ob.row_mask[k] = 0u;
   for (int k = 0; k < n_obs; ++k) {
     if (obs_bits[k] < 0 || obs_bits[k] >= n) return QMLE_ERR_WIRE_RANGE;
     ob.bits[k] = obs_bits[k];
@@ -4621,6 +4629,31 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
       obs_bits[k] = (int8_t)(m ? __builtin_ctz(m) : 0);
     }
   }
+  // Parities that touch the LAST tile in at most one position (the rest are outer positions =
+  // bits of the tile index) also come out of the 33-sums epilogue: column of that position (or
+  // of the total) summed over the tile rows with the sign of the outer part; the general-mask
+  // epilogue costs 13 - 17 us per state at n = 24, this one 4 - 6.  (A CX tail that would make
+  // every folded parity of an HE ring meet the last tile in one position does not exist: the
+  // restrictions of those parities to T wires are T + 1 or T + 2 distinct ranges.)
+  bool semi_single = false;
+  uint32_t row_masks[QMLE_MAX_QUBITS];
+  static const bool no_semi = std::getenv("QMLE_NO_SEMI_SINGLE") != nullptr;
+  if (meas_type == QMLE_MEAS_EXPVAL_Z && !single_bits && !no_semi && !plan->stages.empty() &&
+      plan->stages.back().kind == ST_TILE && !plan->whole_state_lds) {
+    const Stage &ls = plan->stages.back();
+    uint32_t tile_mask = 0;
+    for (int j = 0; j < ls.T; ++j) tile_mask |= 1u << ls.tile_bits[j];
+    semi_single = true;
+    for (int k = 0; k < n_obs && semi_single; ++k) {
+      const uint32_t m = obs_masks[k], in = m & tile_mask;
+      if (m == 0 || (in & (in - 1u))) { semi_single = false; break; }
+      obs_bits[k] = (int8_t)(in ? __builtin_ctz(in) : QMLE_MAX_QUBITS);  // column 32: the tile's total
+      uint32_t rm = 0;
+      for (int i = 0; i < n - ls.T; ++i)
+        if ((m >> ls.outer_bits[i]) & 1u) rm |= 1u << i;
+      row_masks[k] = rm;
+    }
+  }
   int rc = ensure_device_plan(plan);
   if (rc != QMLE_OK) return rc;
 
@@ -4718,9 +4751,12 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
       ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE) {
         const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
-        const int tm = !last_fused ? TM_STORE : single_bits ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
+        const int tm = !last_fused ? TM_STORE : (single_bits || semi_single) ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
         reg_q = -1;
-        const int reg_kind = last_fused && initialised ? reg_measure_kind(plan, si, n_obs) : 0;
+        int reg_kind = last_fused && initialised ? reg_measure_kind(plan, si, n_obs) : 0;
+        // (k_reg_measure on live input is the slowest way to take parities; its known-zero forms
+        // -- FOLD, mono -- keep priority)
+        if (reg_kind == 1 && semi_single) reg_kind = 0;
         if (reg_kind) {
           rc = launch_reg_measure(plan, st, reg_kind, stc, mats, ang, bc, d_partial, obs_masks,
                                   n_obs, stream, &reg_q, d_coef + (size_t)b0 * 32);
@@ -4729,7 +4765,7 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
                          last_fused ? n_obs : 0, stream, /*from_zero=*/true,
                          d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr,
-                         last_fused ? &tile_row_shift : nullptr);
+                         last_fused && single_bits ? &tile_row_shift : nullptr);
         initialised = true;
       } else {
         if (!initialised) {
@@ -4760,7 +4796,12 @@ static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, in
                          reinterpret_cast<float2 *>((float *)d_out + (size_t)b0 * D), tc);
     } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
       ObsBits ob;  // column of the 33-float row: the bit's sum, or (masks) the observable's own
-      for (int k = 0; k < n_obs; ++k) ob.bits[k] = (single_bits && reg_q < 0) ? obs_bits[k] : (int8_t)k;
+      const bool by_position = (single_bits || semi_single) && reg_q < 0;
+      for (int k = 0; k < QMLE_MAX_QUBITS; ++k) ob.row_mask[k] = 0u;
+      for (int k = 0; k < n_obs; ++k) {
+        ob.bits[k] = by_position ? obs_bits[k] : (int8_t)k;
+        if (by_position && semi_single) ob.row_mask[k] = row_masks[k];
+      }
       const int tiles = (1 << (n - plan->stages.back().T)) >> (reg_q < 0 ? tile_row_shift : reg_q);
       hipLaunchKernelGGL(k_expval_final, dim3(bc, n_obs), dim3(256), 0, stream, (const float *)d_partial,
                          tiles, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs);

@@ -336,6 +336,38 @@ def test_trailing_permutation_gates_fold_into_z_observables(n, flags_kw):
                                   ref.run(ang, "probs").cpu().numpy())
 
 
+@pytest.mark.parametrize("n", [17, 20])
+def test_parities_with_one_position_in_the_last_tile_take_the_33_sums_epilogue(n):
+    """Z-parities that meet the last tile pass in at most one bit position (all other factors sit
+    on outer positions = bits of the tile index) are measured by the single-bit epilogue with
+    per-row signs (run_batch_masks: `semi_single`) instead of the general-mask one: same numbers
+    as the general path (QMLE_NO_SEMI_SINGLE is read once per process, so the reference here is
+    the state + stand-alone parity kernel)."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    ops, slots = he_layer_ops(n)
+    rng = np.random.default_rng(170 + n)
+    ang = torch.from_numpy(rng.uniform(0, 2 * np.pi, (3, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+    last = plan.describe()["stages"][-1]
+    assert last["kind"] == "tile" and last["T"] < n
+    tile_wires = sorted(n - 1 - b for b in last["bits"])
+    outer_wires = sorted(set(range(n)) - set(tile_wires))
+    assert len(outer_wires) >= 3
+    groups = [[tile_wires[0], outer_wires[0]], [outer_wires[0], outer_wires[-1]],
+              [tile_wires[-1], outer_wires[1], outer_wires[2]], [tile_wires[3]], outer_wires[:3]]
+    got = plan.run_parity(ang, groups).cpu().numpy()
+    states = plan.run(ang, "state")
+    want = N.expval_parity(states, groups).cpu().numpy()
+    assert np.allclose(got, want, atol=2e-6), np.abs(got - want).max()
+    # a parity with two positions inside the last tile: the general-mask epilogue, same answer
+    groups2 = groups + [[tile_wires[0], tile_wires[1]]]
+    got2 = plan.run_parity(ang, groups2).cpu().numpy()
+    want2 = N.expval_parity(states, groups2).cpu().numpy()
+    assert np.allclose(got2, want2, atol=2e-6), np.abs(got2 - want2).max()
+
+
 @pytest.mark.parametrize("n", [6, 13, 17, 19])
 def test_run_batch_parity_matches_oracle_and_standalone_kernel(n):
     """qmle_run_batch_parity: Z-parity observables measured out of the last pass (with the
