@@ -189,8 +189,13 @@ def roofline_of(run, dense, traffic_key=None):
                     source = (source or "") + f" (scaled from {rec['states_per_launch']} to {per_launch:g} states per launch)"
         except Exception:
             pass
+    fam_note = None
+    if dense and name == "k_tile2" and run["desc"]["stages"] and run["desc"]["stages"][0]["kind"] == "tile":
+        fam_note = ("the initialising pass is two launches on the same stream, k_fill_zero (the zeros of every "
+                    "tile but tile 0) + k_tile2 (tile 0 of every state); both are inside this pass's HIP events "
+                    "and its bytes")
     return {
-        "bound": "hbm", "kernel": name,
+        "bound": "hbm", "kernel": name, "kernel_family_note": fam_note,
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": source,

@@ -2725,6 +2725,15 @@ k_init_zero(float4 *__restrict__ states, int n) {
     st[k] = make_float4(k == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f);
 }
 
+// Zero fill of `count` float4 (the all-live initialising pass: every tile but tile 0 of a state is
+// zeros).  ONE plain store per thread and no loop: 6.79 TB/s on 4 GiB; four stores per thread
+// 6.29, sixteen 5.71, a grid-stride loop 5.35, hipMemsetAsync 6.59, non-temporal stores a little
+// below each (tools/fill_bench.hip) -- and one workgroup per 32 KiB tile inside k_tile2 6.0.
+__global__ void __launch_bounds__(256) k_fill_zero(float4 *__restrict__ p, uint64_t count) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (k < count) p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---------------------------------------------------------------------------
 // all-qubit <Z> in one read.  Element index bits: bit0 = position inside the
 // float4 chunk, bits 1..8 = thread id, bits 9..10 = unroll slot u, bits >= 11 =
@@ -3961,6 +3970,23 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     return QMLE_OK;
   }
   dim3 grid(tiles, (unsigned)batch);
+  // All-live initialising pass (no known-zero bookkeeping downstream, so every tile must be
+  // stored): the zeros come from a plain fill at the rate of a fill, tile 0 of every state from
+  // the tile kernel behind it (15 us per 32 states) -- 22.4 -> 20.2 us per 2^24-amplitude state.
+  static const bool no_fill = std::getenv("QMLE_NO_INIT_FILL") != nullptr;
+  if (init_zero && !from_zero && meas == TM_STORE && st.T < p->n && !no_fill && tiles > 1 &&
+      st.fast_ok && p->n <= 28 && threads == (1 << (st.T - 4)) && !(p->flags & QMLE_PLAN_PREFETCH)) {
+    const uint64_t count = ((uint64_t)batch << p->n) / 2u;  // float4 = two amplitudes
+    for (uint64_t done = 0; done < count;) {  // (grid.x < 2^31 workgroups per launch)
+      const uint64_t part = std::min<uint64_t>(count - done, (uint64_t)1 << 38);
+      hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((part + 255u) / 256u)), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(states) + done, part);
+      done += part;
+    }
+    a.compact = 1;  // grid = the tiles that can be non-zero = tile 0
+    a.tile_free = 0u;
+    grid.x = 1u;
+  }
   if (from_zero && meas == TM_STORE && st.next_tile) {
     // the zero tiles are not even launched: the next tile stage never reads them
     const uint32_t all_outer = tiles - 1u;

@@ -6,6 +6,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pm = json.load(open(sys.argv[1])); n = int(sys.argv[2]); states = int(sys.argv[3])
 tag = sys.argv[4] if len(sys.argv) > 4 else "fused"   # "dense": the all-amplitudes-live plan
 source = sys.argv[5] if len(sys.argv) > 5 else None
+# the all-live initialising pass = k_fill_zero (the zeros) + a k_tile2 launch for tile 0 of every state:
+# its fill traffic belongs to k_tile2's per-launch average (one k_tile2 launch per pass either way)
+if tag == "dense" and "k_fill_zero" in pm and "k_tile2" in pm:
+    f, k = pm["k_fill_zero"], pm["k_tile2"]
+    share = f.get("launches", 0) / max(1, k.get("launches", 1))
+    for key in ("hbm_read_bytes_per_launch_x2_corrected", "hbm_write_bytes_per_launch"):
+        k[key] = k.get(key, 0.0) + f.get(key, 0.0) * share
 path = os.path.join(root, "profiles", "traffic.json")
 t = json.load(open(path))
 for fam, d in pm.items():
