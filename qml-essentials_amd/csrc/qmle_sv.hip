@@ -2858,6 +2858,34 @@ struct KeepBits {
   int n_keep;
 };
 
+// Few kept wires (<= 12): every workgroup bins its share of |a|^2 in LDS first and adds one value
+// per bin to the output -- 2^n / grid terms per global atomic instead of one.  (One global float
+// atomic per amplitude left partial probabilities 2e-6 .. 2e-5 apart between two runs on the
+// same state at n = 18, and it is the slowest way to add.)
+__global__ void __launch_bounds__(256)
+k_marginal_lds(const float2 *__restrict__ states, float *__restrict__ out, int n, KeepBits kb) {
+  extern __shared__ float4 smem4[];
+  float *bins = reinterpret_cast<float *>(smem4);
+  const int b = blockIdx.y;
+  const uint32_t n_bins = 1u << kb.n_keep;
+  for (uint32_t k = threadIdx.x; k < n_bins; k += blockDim.x) bins[k] = 0.f;
+  __syncthreads();
+  const uint64_t D = (uint64_t)1 << n;
+  const float2 *st = states + (size_t)b * D;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += stride) {
+    uint32_t idx = 0;
+    for (int k = 0; k < kb.n_keep; ++k) idx |= (uint32_t)((i >> kb.bits[k]) & 1ull) << k;
+    atomicAdd(bins + idx, norm2(st[i]));
+  }
+  __syncthreads();
+  float *o = out + ((size_t)b << kb.n_keep);
+  for (uint32_t k = threadIdx.x; k < n_bins; k += blockDim.x) {
+    const float v = bins[k];
+    if (v != 0.f) atomicAdd(o + k, v);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_marginal(const float2 *__restrict__ states, float *__restrict__ out, int n, KeepBits kb) {
   const int b = blockIdx.y;
@@ -5342,8 +5370,14 @@ int qmle_marginal_probs(const void *d_states, int n_qubits, int batch, const int
     if (mask & (1ull << w)) kb.bits[k++] = (int8_t)(n_qubits - 1 - w);
   HIPCHK(hipMemsetAsync(d_out, 0, ((size_t)batch << n_keep) * sizeof(float), stream));
   const uint64_t D = (uint64_t)1 << n_qubits;
-  hipLaunchKernelGGL(k_marginal, dim3(grid_for(D, 256, 4096), batch), dim3(256), 0, stream,
-                     (const float2 *)d_states, d_out, n_qubits, kb);
+  if (n_keep <= 12) {
+    // (<= 512 workgroups per state: >= 2^n / 512 terms are summed in LDS per global atomic)
+    hipLaunchKernelGGL(k_marginal_lds, dim3(grid_for(D, 256, 512), batch), dim3(256),
+                       sizeof(float) << n_keep, stream, (const float2 *)d_states, d_out, n_qubits, kb);
+  } else {
+    hipLaunchKernelGGL(k_marginal, dim3(grid_for(D, 256, 4096), batch), dim3(256), 0, stream,
+                       (const float2 *)d_states, d_out, n_qubits, kb);
+  }
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

@@ -41,14 +41,14 @@ for trial in range(int(os.environ.get("FUZZ_N", "60"))):
         err = a if not ok else "both raise"
     else:
         err = float(np.abs(a - b).max())
-        ok = err < (1e-5 if et == "probs" else 2e-6)  # partial probs: float atomics in k_marginal
+        ok = err < (3e-6 if et == "probs" else 2e-6)  # partial probs: LDS bins + one float atomic per bin and workgroup
     if not ok and not isinstance(a, str) and et == "probs":
         # partial probabilities are summed with float atomics (k_marginal): measure the run-to-run
         # noise of ONE mode before calling the difference between the two a mismatch
         again = np.asarray(m(params=P, inputs=X, execution_type=et))
         noise = float(np.abs(again - b).max())
         print("   run-to-run difference of the dense mode alone:", noise, flush=True)
-        ok = err < 1e-5 + 4 * noise
+        ok = err < 3e-6 + 4 * noise
     if not ok:
         bad += 1
     print(trial, n, L, et, kw["circuit_type"], kw.get("encoding") is not None, "output" in str(kw.keys()), err, "" if ok else "<<< MISMATCH", flush=True)
