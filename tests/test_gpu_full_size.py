@@ -198,7 +198,8 @@ def test_multi_tile_workgroups_state_and_probs_vs_c_port():
     pr = dense.run(ang, "probs")
     ref = N.Plan(ops, n, slots).run(ang, "state")
     assert float((torch.view_as_real(st) - torch.view_as_real(ref)).abs().max()) < 3e-7
-    assert float((pr - (ref.real ** 2 + ref.imag ** 2)).abs().max()) < 1e-9
+    assert float((pr - (st.real ** 2 + st.imag ** 2)).abs().max()) < 1e-9   # same plan, same arithmetic
+    assert float((pr - (ref.real ** 2 + ref.imag ** 2)).abs().max()) < 2e-8
     for b in (0, 7, B - 1):
         tape = [(name, wires, tuple(float(ang_h[b, s]) for s in sl)) for name, wires, sl, _ in ops]
         psi = c_port.simulate(tape, n)
