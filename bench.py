@@ -165,6 +165,29 @@ def families(run, dense):
     return fam
 
 
+def per_pass(run, dense):
+    """HIP-event time and bytes of every pass, one entry per stage: what the rocprofv3 kernel
+    rows of profiles/ are to be compared with (the all-live initialising pass is two kernels)."""
+    desc, n, B, steps = run["desc"], run["n"], run["B"], run["steps"]
+    ns = len(desc["stages"])
+    out = []
+    for i, st in enumerate(desc["stages"]):
+        k = kernel_of_stage(st, i, ns, n, dense)
+        kernels = [k]
+        if dense and i == 0 and st["kind"] == "tile" and k == "k_tile2":
+            kernels = ["k_fill_zero", "k_tile2 (one workgroup per state: tile 0)"]
+        moved = st["read_bytes_from_zero"] + st["write_bytes_from_zero"]
+        if i == ns - 1 and st["kind"] == "tile":
+            moved = st["read_bytes_from_zero"]
+        cnt = max(1, run["stage_cnt"][i])
+        ms = run["stage_ms"][i] / cnt
+        per_launch = moved * B * steps / cnt
+        out.append({"pass": i + 1, "kernels": kernels, "launches": run["stage_cnt"][i],
+                    "avg_launch_ms": round(ms, 5), "bytes_moved_per_launch": round(per_launch),
+                    "moved_GBps": round(per_launch / ms / 1e6, 1) if ms > 0 else None})
+    return out
+
+
 def roofline_of(run, dense, traffic_key=None):
     fam = families(run, dense)
     name = max(fam, key=lambda k: fam[k]["ms"])
@@ -209,6 +232,7 @@ def roofline_of(run, dense, traffic_key=None):
         "moved_frac": round(moved / HBM_PEAK_GBPS, 4),
         "kernel_share_of_step": round(dom["ms"] / (run["elapsed"] * 1e3), 4),
         "all_kernels_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
+        "per_pass": per_pass(run, dense),
         "note": "achieved = algorithmic bytes (SURVEY 8-d: 16 D per 1-qubit gate, 8 D per CX) of the "
                 "reference gates the kernel's launches applied / its summed launch time: a fused pass "
                 "applies ~8-30 gates per HBM round trip, so frac > 1 is expected and bounded by the "
