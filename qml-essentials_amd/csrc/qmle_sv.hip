@@ -1202,11 +1202,14 @@ __device__ __forceinline__ void fast_dispatch(A16 &a, int code, const Mat2S &M) 
   case base + 6: F<2, 0>(__VA_ARGS__); break; case base + 7: F<2, 1>(__VA_ARGS__); break;        \
   case base + 8: F<2, 3>(__VA_ARGS__); break; case base + 9: F<3, 0>(__VA_ARGS__); break;        \
   case base + 10: F<3, 1>(__VA_ARGS__); break; case base + 11: F<3, 2>(__VA_ARGS__); break;
+  // (the uncontrolled dense gate is what deep circuits are made of: two scalar branches to reach
+  // it instead of the six of a balanced tree over all 48 codes)
+  if (code < FC_CDENSE) {
+    if (code < 2) { if (code == 0) f_dense<0>(a, M); else f_dense<1>(a, M); }
+    else { if (code == 2) f_dense<2>(a, M); else f_dense<3>(a, M); }
+    return;
+  }
   switch (code) {
-    case FC_DENSE + 0: f_dense<0>(a, M); break;
-    case FC_DENSE + 1: f_dense<1>(a, M); break;
-    case FC_DENSE + 2: f_dense<2>(a, M); break;
-    case FC_DENSE + 3: f_dense<3>(a, M); break;
     QMLE_C12(f_cdense, FC_CDENSE, a, M)
     case FC_DIAG + 0: f_diag<0>(a, M); break;
     case FC_DIAG + 1: f_diag<1>(a, M); break;
