@@ -786,9 +786,13 @@ int compile_plan(qmle_plan *p) {
       // a control on bits 1..3 selects 16/32/64-byte runs inside every 128-byte line: the
       // streaming kernel would move whole lines for half the work (measured 2-4x slower
       // than a tile pass at n = 28), so those go through the LDS tile instead
+      // (round 2: with the target on bits 1..6 too, the lane-exchange mode of the streaming
+      // kernel takes those controls: k_direct_1q mode 7)
       const bool direct_ok = !p->whole_state_lds && !force_tile && members.size() == 1 &&
                              m0.kind == LK_1Q &&
-                             (m0.nc == 0 || (m0.nc == 1 && (m0.c0 == 0 || m0.c0 >= 4)));
+                             (m0.nc == 0 ||
+                              (m0.nc == 1 && (m0.c0 == 0 || m0.c0 >= 4 ||
+                                              (!(m0.flags & LF_DIAG) && n >= 14 && m0.t0 >= 1 && m0.t0 <= 6))));
       if (direct_ok) {
         st.kind = ST_DIRECT;
         p->dev_ops.push_back(m0);

@@ -2578,7 +2578,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
   const uint64_t chunks = (uint64_t)1 << (n - 1);
   float4 *st = states + (size_t)b * chunks;
   const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (MODE < 5 && k >= items) return;  // modes 5 / 6: exact grids, whole waves
+  if (MODE < 5 && k >= items) return;  // modes 5 / 6 / 7: exact grids, whole waves
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
   if constexpr (MODE == 0) {
     if constexpr (DIAG) {  // items = all chunks
@@ -2656,6 +2656,27 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     }
     st4<NT>(st + c0, v[0]);
     st4<NT>(st + c1, v[1]);
+  } else if constexpr (MODE == 7) {
+    // controlled gate with the control on bits 0..3 and the target on bits 1..6: both live inside
+    // the 1 KiB a wave covers with one float4 per lane, and every 128-byte line holds both
+    // control values, so all 16 D bytes move whatever the kernel does.  Stream them like the
+    // diagonal gate -- one contiguous float4 per lane in, one out --, fetch the partner through
+    // the cross-lane path and rewrite only the amplitudes whose control bit is set.  (A single-
+    // gate LDS tile pass did this at 0.757 ms for n = 28; 8 D accounting: 0.35 -> 0.39.)
+    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // items = all chunks, exact grid
+    const bool up = (threadIdx.x >> (pt - 1)) & 1u;
+    const float2 ms = up ? m.m11 : m.m00, mo = up ? m.m10 : m.m01;
+    const float4 v = ld4<NT>(st + c);
+    float4 o;
+    o.x = __shfl_xor(v.x, 1 << (pt - 1), kWave); o.y = __shfl_xor(v.y, 1 << (pt - 1), kWave);
+    o.z = __shfl_xor(v.z, 1 << (pt - 1), kWave); o.w = __shfl_xor(v.w, 1 << (pt - 1), kWave);
+    const bool lane_ctl = pc == 0 ? true : ((threadIdx.x >> (pc - 1)) & 1u) != 0;
+    float2 x = make_float2(v.x, v.y), y = make_float2(v.z, v.w);
+    if (lane_ctl) {
+      if (pc != 0) x = cfma(mo, make_float2(o.x, o.y), cmul(ms, x));  // control bit 0: only the odd amplitude
+      y = cfma(mo, make_float2(o.z, o.w), cmul(ms, y));
+    }
+    st4<NT>(st + c, make_float4(x.x, x.y, y.x, y.y));
   } else if constexpr (MODE == 6) {
     // uncontrolled dense gate on a high bit (>= 21): a wave takes 4 ADJACENT rows of each of the
     // two streams (4 KiB contiguous per stream), all loads of one stream first: the DRAM banks
@@ -4304,6 +4325,9 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     if (pc >= 1 && pt >= 1) { mode = 2; items = diag ? chunks >> 1 : chunks >> 2; }
     else if (pt == 0) { mode = 3; items = chunks >> 1; }
     else { mode = 4; items = diag ? chunks : chunks >> 1; }
+    // control and target both inside a wave's 1 KiB: one contiguous float4 per lane (mode 7)
+    // (controls on bits >= 4 select whole 128-byte lines: mode 2 moves half the state, 0.37 vs 0.65 ms)
+    if (!diag && !k1_plain && n >= 14 && pt >= 1 && pt <= 6 && pc >= 0 && pc <= 3) { mode = 7; items = chunks; }
   }
   if (items == 0) items = 1;
   // streaming (non-temporal) accesses once the working set dwarfs the Infinity Cache
@@ -4317,6 +4341,7 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     case 3: launch_direct_mode<3>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     case 5: launch_direct_mode<5>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 7: launch_direct_mode<7>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
     default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
   }
   HIPCHK(hipGetLastError());

@@ -71,9 +71,13 @@ def test_no_fusion_is_one_pass_per_gate():
     ops, slots = he_layer_ops(24)
     p = N.Plan(ops, 24, slots, flags=N.plan_flags(no_fusion=True))
     st = p.stats()
-    # CX with the control on bits 1..3 (wires 20, 21, 22 -> targets 21, 22, 23) take a
-    # single-gate tile pass; every other gate streams through the direct kernel
-    assert st["n_passes"] == 96 and st["direct_passes"] == 93
+    # every gate but one streams through the direct kernel -- since round 2 also the CX with the
+    # control on bits 2 / 3 and the target on bits 1 / 2 (wires 21 -> 22, 20 -> 21: lane-exchange
+    # mode); CX 22 -> 23 (control on bit 1, target on bit 0) keeps its single-gate tile pass
+    assert st["n_passes"] == 96 and st["direct_passes"] == 95
+    # a control on bits 1..3 with a HIGH target still takes a single-gate tile pass
+    hi = N.Plan([("CX", [22, 3], [], -1)], 24, 0, flags=N.plan_flags(no_fusion=True)).stats()
+    assert hi["n_passes"] == 1 and hi["direct_passes"] == 0
     # (72*256 + 24*128) MiB per state
     assert st["algo_bytes_per_state"] == (72 * 256 + 24 * 128) * 2**20
 
