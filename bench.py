@@ -27,6 +27,15 @@ the GPU (``qmle_build_angles``), the statevectors are produced and consumed on t
 result is a CUDA tensor -- no host<->device traffic inside a step.  Weak scaling: every rank
 simulates its own 1024 states and one RCCL all-gather returns the (1024 N, 24) expectation values.
 
+**Ranks.**  ``python bench.py --gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment is a
+*launcher*: the parent never touches the GPU, starts ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...`` on this same file as a CHILD process (never an
+exec), relays rank 0's JSON line and exits with the child's code.  Inside, ``world_size`` must equal
+``--gpus`` and the backend must be ``nccl`` (= RCCL; ``QMLE_DIST_BACKEND=gloo`` only for rehearsals
+with several ranks on one GPU) or the run exits non-zero.  Besides the weak-scaling K2 step the line
+carries the strong-scaling legs BASELINE names: C3 (1024 Expressibility pairs split over the ranks)
+and C4 (the 4096-point Fourier grid, 512 points per GPU at N = 8).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
 ``roofline`` (dominant kernel, timed live with HIP events on the launch stream) and
 ``cpu_baseline`` (the oracle's C/OpenMP port on a bounded sample, N=1 only; its <Z> values are
@@ -36,8 +45,11 @@ from __future__ import annotations
 
 import argparse
 import contextlib
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,7 +63,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -61,7 +73,43 @@ def parse_args():
     ap.add_argument("--no-fusion", action="store_true", help="one HBM pass per reference gate")
     ap.add_argument("--skip-aux", action="store_true", help="headline only (no K1 / deep / CPU legs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, run the one collective on a token tensor, print the line's "
+                         "rank bookkeeping and stop (launcher / process-group plumbing; needs no GPU)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv):
+    """`--gpus N` without a launcher: start N ranks of this file under torch.distributed.run as a
+    CHILD process (this parent has not initialised the GPU and never does; nothing is exec'd),
+    relay rank 0's JSON line to stdout and return the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["QMLE_BENCH_LAUNCHED_BY"] = "bench.py"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__), *argv]
+    print("[bench] launching:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:  # ranks' diagnostics go to stderr; stdout carries the JSON line
+        if out.lstrip().startswith("{"):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited without printing a result line", file=sys.stderr)
+        rc = 3
+    if line is not None:
+        print(line, flush=True)
+    return rc
 
 
 @contextlib.contextmanager
@@ -90,6 +138,20 @@ def kernel_of_stage(st, i, n_stages, n, dense):
         live = bin(~st["zero_in"] & ((1 << n) - 1)).count("1")
         return "k_product_stream" if live >= 9 and not st["zero_in"] & 1 else "k_tile_product"
     return "k_tile2" if st.get("fast") and st["zero_in"] == 0 else "k_tile"
+
+
+def max_over_ranks(value):
+    """Every rank's `value` (one float), as a list indexed by rank -- one all-gather."""
+    from qml_essentials_amd import distributed
+
+    rank, size = distributed.world()
+    if size == 1:
+        return [float(value)]
+    dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    every = torch.empty(size, dtype=torch.float64, device=dev)
+    torch.distributed.all_gather_into_tensor(every, mine)
+    return [float(v) for v in every.cpu()]
 
 
 def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, profile=True):
@@ -133,13 +195,11 @@ def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, prof
         stage_ms = stage_cnt = overflow = None
         if profile and rank == 0:
             stage_ms, stage_cnt, overflow = plan.profile_end()
-    if size > 1:
-        dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank = max_over_ranks(elapsed)
+    elapsed = max(per_rank)
     assert tuple(out.shape) == (B * size, n) and bool(torch.isfinite(out).all())
-    return {"elapsed": elapsed, "out": out, "desc": desc, "n_gates": len(low.ops), "folded": folded,
+    return {"elapsed": elapsed, "elapsed_per_rank": per_rank, "out": out, "desc": desc,
+            "n_gates": len(low.ops), "folded": folded,
             "stage_ms": stage_ms, "stage_cnt": stage_cnt, "overflow": overflow, "params": params,
             "flags": flags, "steps": steps, "B": B, "n": n}
 
@@ -188,30 +248,65 @@ def per_pass(run, dense):
     return out
 
 
+def source_sha16():
+    """Hash of the sources that decide what a kernel launch moves: profiles/traffic.json records the
+    one its PMC counters were collected for, and a mismatch makes `traffic` null (never stale)."""
+    h = hashlib.sha256()
+    for rel in ("qml-essentials_amd/csrc/qmle_sv.hip", "qml-essentials_amd/csrc/qmle_plan.cpp",
+                "qml-essentials_amd/csrc/qmle_internal.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(key, path=None, sha=None):
+    """(bytes per launch, source, states per launch, error) for `key` of profiles/traffic.json;
+    bytes is None -- with the reason in `error` -- when the file is missing, has no such key, or
+    was collected for other kernel sources than the ones in this tree."""
+    path = path or os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None, None, "profiles/traffic.json missing"
+    try:
+        doc = json.load(open(path))
+    except Exception as e:  # pragma: no cover
+        return None, None, None, f"profiles/traffic.json unreadable: {e}"
+    rec = doc.get(key)
+    if not rec:
+        return None, None, None, f"no PMC record {key!r} in profiles/traffic.json"
+    want = rec.get("source_sha16") or doc.get("_source_sha16")
+    have = sha or source_sha16()
+    if want != have:
+        msg = (f"STALE: PMC record {key!r} was collected for kernel sources {want}, this tree is {have}; "
+               f"re-run tools/collect_profiles_r03.sh on a GPU box")
+        print("bench.py: " + msg, file=sys.stderr)
+        return None, None, None, msg
+    return rec["hbm_bytes_per_launch"], rec.get("source"), rec.get("states_per_launch"), None
+
+
 def roofline_of(run, dense, traffic_key=None):
+    """`roofline` object of a K2-style run.  achieved / frac are BYTES REALLY MOVED by the dominant
+    kernel's launches (the plan compiler's per-pass read + write bytes, which the PMC counters in
+    profiles/ confirm) / its HIP-event launch time / the 8 TB/s peak -- a fraction <= 1.  The
+    SURVEY 8-d per-reference-gate bytes over the same time are `algorithmic_GBps`; their ratio to
+    the bytes moved is the fusion factor (reference gates applied per HBM round trip)."""
     fam = families(run, dense)
     name = max(fam, key=lambda k: fam[k]["ms"])
     dom = fam[name]
     sec = dom["ms"] * 1e-3
-    achieved = dom["algo"] / sec / 1e9 if sec > 0 else 0.0
+    algo = dom["algo"] / sec / 1e9 if sec > 0 else 0.0
     moved = dom["moved"] / sec / 1e9 if sec > 0 else 0.0
-    traffic, source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if traffic_key and os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get(traffic_key)
-            if rec:
-                traffic, source = rec["hbm_bytes_per_launch"], rec.get("source")
-                # per launch like `achieved`: the counters were collected at rec["states_per_launch"]
-                per_launch = run["B"] * run["steps"] * sum(
-                    1 for i, st in enumerate(run["desc"]["stages"])
-                    if kernel_of_stage(st, i, len(run["desc"]["stages"]), run["n"], dense) == name
-                ) / max(1, dom["launches"])
-                if rec.get("states_per_launch") and abs(per_launch - rec["states_per_launch"]) > 0.5:
-                    traffic = round(traffic * per_launch / rec["states_per_launch"])
-                    source = (source or "") + f" (scaled from {rec['states_per_launch']} to {per_launch:g} states per launch)"
-        except Exception:
-            pass
+    traffic = source = terr = None
+    if traffic_key:
+        traffic, source, per_rec, terr = load_traffic(traffic_key)
+        if traffic is not None:
+            # per launch like `achieved`: the counters were collected at `per_rec` states per launch
+            per_launch = run["B"] * run["steps"] * sum(
+                1 for i, st in enumerate(run["desc"]["stages"])
+                if kernel_of_stage(st, i, len(run["desc"]["stages"]), run["n"], dense) == name
+            ) / max(1, dom["launches"])
+            if per_rec and abs(per_launch - per_rec) > 0.5:
+                traffic = round(traffic * per_launch / per_rec)
+                source = (source or "") + f" (scaled from {per_rec} to {per_launch:g} states per launch)"
     fam_note = None
     if dense and name == "k_tile2" and run["desc"]["stages"] and run["desc"]["stages"][0]["kind"] == "tile":
         fam_note = ("the initialising pass is two launches on the same stream, k_fill_zero (the zeros of every "
@@ -219,25 +314,26 @@ def roofline_of(run, dense, traffic_key=None):
                     "and its bytes")
     return {
         "bound": "hbm", "kernel": name, "kernel_family_note": fam_note,
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-        "traffic_source": source,
+        "achieved": round(moved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(moved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "traffic_source": source, "traffic_error": terr,
         "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5),
         "launches": dom["launches"],
         "passes_per_state": sum(1 for i, st in enumerate(run["desc"]["stages"])
                                 if kernel_of_stage(st, i, len(run["desc"]["stages"]), run["n"], dense) == name),
-        "algorithmic_bytes_per_launch": round(dom["algo"] / max(1, dom["launches"])),
         "bytes_moved_per_launch": round(dom["moved"] / max(1, dom["launches"])),
-        "moved_GBps": round(moved, 1),
-        "moved_frac": round(moved / HBM_PEAK_GBPS, 4),
+        "algorithmic_bytes_per_launch": round(dom["algo"] / max(1, dom["launches"])),
+        "algorithmic_GBps": round(algo, 1),
+        "fusion_factor": round(dom["algo"] / dom["moved"], 2) if dom["moved"] else None,
         "kernel_share_of_step": round(dom["ms"] / (run["elapsed"] * 1e3), 4),
         "all_kernels_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         "per_pass": per_pass(run, dense),
-        "note": "achieved = algorithmic bytes (SURVEY 8-d: 16 D per 1-qubit gate, 8 D per CX) of the "
-                "reference gates the kernel's launches applied / its summed launch time: a fused pass "
-                "applies ~8-30 gates per HBM round trip, so frac > 1 is expected and bounded by the "
-                "gates per pass; moved_frac = bytes the launches really read + wrote / time / 8 TB/s "
-                "(<= 1 by construction; matches the PMC traffic in profiles/)",
+        "note": "achieved / frac = bytes the dominant kernel's launches really read + wrote (plan model, "
+                "confirmed by the PMC `traffic`) / their HIP-event time / 8 TB/s.  algorithmic_GBps = SURVEY "
+                "8-d bytes (16 D per 1-qubit gate, 8 D per CX) of the reference gates those launches applied "
+                "/ the same time; fusion_factor = algorithmic / moved = reference gates' worth of bytes per "
+                "HBM round trip (a fused pass applies ~8-30 gates).  The one-pass-per-reference-gate run "
+                "(`k2_unfused`) has fusion_factor <= 1 by construction",
         "event_pool_overflow": run["overflow"],
     }
 
@@ -303,19 +399,188 @@ def k1_sweep(n=28, reps=8):
     return out
 
 
-def expressibility_wallclock(n=12, samples=1024):
-    """BASELINE config 3: KL-to-Haar, 12 qubits, 1024 pairs, HE 3 layers, no DRU."""
+VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _wall(fn, reps):
+    """Median wall-clock of `fn` over `reps` calls, each bracketed by synchronize + barrier;
+    max over ranks per call (the job is done when the slowest rank is)."""
+    from qml_essentials_amd import distributed
+
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        distributed.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        ts.append(max(max_over_ranks(time.perf_counter() - t0)))
+    return sorted(ts)[len(ts) // 2], out
+
+
+def expressibility_leg(n=12, samples=1024, reps=5):
+    """BASELINE config 3 (strong scaling): KL-to-Haar, 12 qubits, 1024 pairs (2048 states), HE 3
+    layers, no DRU; the PAIRS are split over the ranks, one all-gather of 1024 floats."""
+    from qml_essentials_amd import distributed
     from qml_essentials_amd.expressibility import Expressibility
     from qml_essentials_amd.model import Model
 
     m = Model(n, 3, "Hardware_Efficient", data_reupload=False)
-    Expressibility.kl_divergence_to_haar(m, n_samples=64, n_bins=75, random_key=1)  # warm
+    Expressibility.kl_divergence_to_haar(m, n_samples=max(64, distributed.world()[1]), n_bins=75, random_key=1)
+    sec, kl = _wall(lambda: Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75,
+                                                                 random_key=1000), reps)
+    size = distributed.world()[1]
+    return {"seconds": round(sec, 6), "kl": float(np.mean(kl)), "n_qubits": n, "pairs": samples,
+            "pairs_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(samples, size)],
+            "scaling": "strong", "collective": "one all-gather of the fidelities (4 KiB)",
+            "note": "median of %d calls, max over ranks; host-side parameter sampling + histogram included" % reps}
+
+
+def fourier_grid_leg(n=10, layers=6, points=4096, reps=5):
+    """BASELINE config 4 (strong scaling): Model(10, 6, HE) on the 2^12-point input grid,
+    expval averaged over the wires; the GRID is split over the ranks (512 points per GPU at N = 8),
+    one all-gather of (4096, 10) floats; the FFT of the 4096 values runs on the host."""
+    from qml_essentials_amd import distributed
+    from qml_essentials_amd.model import Model
+
+    m = Model(n, layers, "Hardware_Efficient")
+    x = torch.from_numpy((2 * np.pi * np.arange(points) / points).astype(np.float32).reshape(-1, 1)).cuda()
+
+    def call():
+        y = m(inputs=x, force_mean=True)
+        return np.fft.fft(y.cpu().numpy().astype(np.float64)) / points
+
+    call()
+    sec, coeffs = _wall(call, reps)
+    size = distributed.world()[1]
+    return {"seconds": round(sec, 6), "n_qubits": n, "n_layers": layers, "grid_points": points,
+            "points_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(points, size)],
+            "c0": float(coeffs[0].real), "max_abs_coeff_beyond_degree": float(np.abs(coeffs[layers * n + 1:points // 2]).max()),
+            "scaling": "strong", "collective": "one all-gather of the expectation values (160 KiB)",
+            "note": "median of %d calls, max over ranks; device -> host copy + host FFT included" % reps}
+
+
+def lds_regime_leg(n, layers, dru, batch, meas, reps=10):
+    """Whole-state-in-LDS regime (n <= 14): circuit (+ measurement) of `batch` states in ONE launch,
+    HIP-event timed.  SURVEY 8-d: the bound is LDS bandwidth / fp32 VALU, HBM traffic is parameters
+    in and results out -- reported as states/s and executed fp32 TFLOP/s against the vector peak,
+    not as an HBM fraction."""
+    from qml_essentials_amd import _native as N
+    from qml_essentials_amd import simulation
+    from qml_essentials_amd.model import Model
+
+    model = Model(n, layers, "Hardware_Efficient", data_reupload=dru)
+    rng = np.random.default_rng(1000)
+    params = rng.uniform(0, 2 * np.pi, (batch, *model.params.shape[1:])).astype(np.float32)
+    x = None if not dru else np.full((1, 1), 0.5, dtype=np.float32)
+    tape, _ = model.record_tape(params=params[:2], inputs=x)
+    low = simulation.LoweredTape(tape, n)
+    top = simulation.get_plan(low)
+    plan = (top.expval_child() or top) if meas == "expval" else top
+    desc = plan.describe()
+    pd = torch.from_numpy(params).cuda()
+    xd = None if x is None else torch.from_numpy(x).cuda()
+    kw = dict(execution_type=meas)
+
+    def call():
+        return model(params=pd, **kw) if xd is None else model(params=pd, inputs=xd, **kw)
+
+    call()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kl = Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75, random_key=1000)
+    plan.profile_begin(len(desc["stages"]) * reps * 4 + 16)
+    for _ in range(reps):
+        call()
+    ms, cnt, _ = plan.profile_end()
+    kernel_ms = sum(ms) / reps
+    flops = desc["flops_per_state"] * batch
+    tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    lds_bytes = 0.0  # one LDS round trip (read + write of the 8 D-byte state) per register-tile group
+    for st in desc["stages"]:
+        lds_bytes += 16.0 * (1 << n) * max(1, len(st.get("fast_groups") or st.get("groups") or []))
+    return {"n_qubits": n, "gates_per_state": len(low.ops), "operators_applied_per_state": desc["n_lowered"],
+            "states_per_launch": batch, "measurement": meas, "whole_state_lds": desc["whole_state_lds"],
+            "kernel_ms": round(kernel_ms, 5), "launches": int(sum(cnt) / reps),
+            "states_per_s": round(batch / (kernel_ms * 1e-3), 1),
+            "gate_applies_per_s": round(len(low.ops) * batch / (kernel_ms * 1e-3), 1),
+            "fp32_flops_per_state": desc["flops_per_state"],
+            "tflops": round(tf, 2), "valu_peak_tflops": VALU_PEAK_TFLOPS,
+            "frac_of_valu_peak": round(tf / VALU_PEAK_TFLOPS, 4),
+            "lds_GBps": round(lds_bytes * batch / (kernel_ms * 1e-3) / 1e9, 1),
+            "bound": "lds/valu"}
+
+
+def k2_unfused_leg(n, B, steps=2):
+    """SURVEY 8-d `achieved_unfused`: one HBM pass per REFERENCE gate (QMLE_PLAN_NO_FUSION | NO_MERGE,
+    all amplitudes live, nothing folded) -- what simulation.py:102-103 does.  frac = the SURVEY 8-d
+    bytes of the 96 gates / the summed HIP-event time of their launches / 8 TB/s, <= 1 by construction."""
+    from qml_essentials_amd import _native as N
+
+    fl = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB | N.PLAN_NO_FUSION | N.PLAN_NO_MERGE
+    run = timed_k2(n, B, 1, steps, 1, fl)
+    desc = run["desc"]
+    states = B * steps
+    kinds = {}
+    for i, st in enumerate(desc["stages"]):
+        k = kinds.setdefault(st["kind"], {"ms": 0.0, "launches": 0, "algo": 0.0, "passes": 0})
+        k["ms"] += run["stage_ms"][i]
+        k["launches"] += run["stage_cnt"][i]
+        k["algo"] += st["algo_bytes_per_state"] * states
+        k["passes"] += 1
+    d = kinds.get("direct", {"ms": 0.0, "launches": 0, "algo": 0.0, "passes": 0})
+    sec = d["ms"] * 1e-3
+    gbps = d["algo"] / sec / 1e9 if sec > 0 else 0.0
+    return {"ms_per_step": round(run["elapsed"] / steps * 1e3, 3), "batch": B, "steps": steps,
+            "gate_applies_per_s": round(run["n_gates"] * states / run["elapsed"], 1),
+            "statevectors_per_s": round(states / run["elapsed"], 2),
+            "hbm_passes_per_state": len(desc["stages"]),
+            "roofline": {"bound": "hbm", "kernel": "k_direct_1q", "achieved": round(gbps, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "avg_launch_ms": round(d["ms"] / max(1, d["launches"]), 5),
+                         "launches": d["launches"], "passes_per_state": d["passes"],
+                         "algorithmic_bytes_per_launch": round(d["algo"] / max(1, d["launches"])),
+                         "fusion_factor": 1.0,
+                         "note": "every reference gate is its own in-place HBM pass (k_direct_1q); the first "
+                                 "launch of a state also holds the |0..0> initialisation; <Z> is one more "
+                                 "read (k_expval_partial), outside this kernel's time"},
+            "max_abs_diff_vs_headline_expvals": None, "_out": run["out"]}
+
+
+def mw_28q_leg(n=28, reps=10):
+    """BASELINE config 5: Meyer-Wallach of ONE 2^28 statevector (2 GiB, HE layer applied to |0..0>),
+    HIP events around `reps` calls.  frac = the 8 D-byte single read of SURVEY 8-d / time / 8 TB/s;
+    moved_frac = bytes the reads of the call really fetch (reads_per_call x 8 D) / time / 8 TB/s."""
+    from qml_essentials_amd import _native as N
+    from oracle.circuits import bricks  # wire-pair generator only (test infrastructure, no compute)
+
+    ops = [(g, [q], [i * n + q], -1) for i, g in enumerate(("RY", "RZ", "RY")) for q in range(n)]
+    ops += [("CX", [a, b], [], -1) for a, b in bricks(n, mirror=False) +
+            bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
+    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, 3 * n)).astype(np.float32)).cuda()
+    st = N.Plan(ops, n, 3 * n).run(ang, "state")
+    q = N.meyer_wallach(st)
     torch.cuda.synchronize()
-    return {"seconds": round(time.perf_counter() - t0, 5), "kl": float(np.mean(kl)),
-            "n_qubits": n, "pairs": samples}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        q = N.meyer_wallach(st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    D8 = 8.0 * (1 << n)
+    reads = N.mw_reads(n)
+    traffic, source, _, terr = load_traffic(f"meyer_wallach:n{n}")
+    del st
+    torch.cuda.empty_cache()
+    return {"ms": round(ms, 4), "Q": float(q[0]), "n_qubits": n, "state_bytes": int(D8),
+            "reads_of_the_state_per_call": reads,
+            "roofline": {"bound": "hbm", "kernel": "k_mw_tile2", "achieved": round(D8 / ms / 1e6, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                         "moved_GBps": round(reads * D8 / ms / 1e6, 1),
+                         "moved_frac": round(reads * D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "traffic_source": source, "traffic_error": terr,
+                         "note": "frac counts ONE read of the state (8 D bytes, SURVEY 8-d) per call; the call "
+                                 "reads it reads_of_the_state_per_call times (moved_frac); traffic = PMC bytes "
+                                 "fetched per call"}}
 
 
 def cpu_baseline(n, params_rows, budget_s, gpu_rows):
@@ -403,12 +668,47 @@ def adjoint_gradient_wallclock(n=20, layers=4):
             "n_params": int(p.numel()), "finite": bool(torch.isfinite(g).all())}
 
 
-def main():
-    a = parse_args()
+def rank_bookkeeping(a, rank, size):
+    """World checks shared by the full run and --rendezvous-only: the job must have exactly
+    --gpus ranks on the nccl (RCCL) backend -- gloo only when QMLE_DIST_BACKEND asks for a rehearsal
+    -- and every rank must answer the one collective the data path uses (all_gather_into_tensor)."""
+    from qml_essentials_amd import distributed
+
+    if size != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {size} rank(s); launch with "
+                         f"`python bench.py --gpus {a.gpus}` (spawns the ranks) or torch.distributed.run "
+                         f"--nproc-per-node {a.gpus}")
+    backend = torch.distributed.get_backend() if size > 1 else None
+    if size > 1 and backend != "nccl" and os.environ.get("QMLE_DIST_BACKEND") != backend:
+        raise SystemExit(f"bench.py: {size} ranks on backend {backend!r}; the data path needs nccl (RCCL)")
+    token = np.array([[rank, os.getpid()]], dtype=np.float64)
+    if size > 1:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        token = distributed.all_gather_rows(torch.from_numpy(token).to(dev), size).cpu().numpy()
+    seen = [int(r) for r in token[:, 0]]
+    if seen != list(range(size)) or len({int(p) for p in token[:, 1]}) != size:
+        raise SystemExit(f"bench.py: all-gather returned ranks {seen} for world size {size}")
+    return {"ranks_seen": seen, "collective_backend": backend or "none (single rank)",
+            "launched_by": os.environ.get("QMLE_BENCH_LAUNCHED_BY", "torch.distributed.run" if size > 1 else "python")}
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher: this process has not touched the GPU (import torch does not) and never will
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:] if argv is None else list(argv)))
     from qml_essentials_amd import distributed
     import __graft_entry__ as entry
 
     rank, size = distributed.init_from_env()
+    books = rank_bookkeeping(a, rank, size)
+    if a.rendezvous_only:
+        distributed.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": size, **books}), flush=True)
+        if size > 1:
+            torch.distributed.destroy_process_group()
+        return
     if rank == 0:
         with contextlib.redirect_stdout(sys.stderr):  # stdout carries the ONE JSON line only
             entry.build()
@@ -425,9 +725,10 @@ def main():
     head_flags = DENSE | (N.PLAN_NO_FUSION if a.no_fusion else 0)
     head = timed_k2(n, B, size, a.steps, a.warmup, head_flags)
 
-    expr = None
+    c3 = c4 = None
     if not a.skip_aux:  # sharded over all ranks -> every rank takes part
-        expr = expressibility_wallclock()
+        c3 = expressibility_leg()
+        c4 = fourier_grid_leg()
     if rank != 0:
         distributed.barrier()
         return
@@ -449,22 +750,38 @@ def main():
                                f"QMLE_PLAN_NO_ABSORB), batch {B} statevectors per GPU per step",
                    "n_qubits": n, "batch_per_gpu": B, "gates_per_state": n_gates,
                    "gates_applied_to_the_state": n_gates - head["folded"],
+                   "operators_executed_per_state": head["desc"]["n_lowered"],
                    "hbm_passes_per_state": hs["hbm_passes_per_state"], "fusion": not a.no_fusion,
                    "known_zero_tracking": False, "observable_folding": False,
                    "parallelism": f"batch-sharded x{size}"},
+        **books,
+        "elapsed_s_per_rank_min_max": [round(min(head["elapsed_per_rank"]), 6),
+                                       round(max(head["elapsed_per_rank"]), 6)],
         "statevectors_per_s": round(total_states / elapsed, 2),
         "hbm_bytes_moved_per_state": hs["hbm_bytes_moved_per_state"],
         "step_moved_GBps": hs["moved_GBps"], "step_moved_frac_of_8TBps": hs["moved_frac_of_8TBps"],
         "roofline": roofline,
     }
+    if c3 is not None:
+        result["c3_expressibility_12q_1024pairs"] = c3
+        result["c4_fourier_10q_6l_4096grid"] = c4
     if not a.skip_aux and size == 1 and not a.no_fusion:
+        # SURVEY 8-d `achieved_unfused`: one HBM pass per reference gate, no 1-qubit merging
+        try:
+            uf = k2_unfused_leg(n, min(B, 128))
+            out_uf = uf.pop("_out")
+            uf["max_abs_diff_vs_headline_expvals"] = float((out_uf - head["out"][:out_uf.shape[0]]).abs().max())
+            result["k2_unfused"] = uf
+            del out_uf
+        except Exception as e:  # pragma: no cover
+            result["k2_unfused"] = {"error": str(e)}
         # the default engine on the same workload: exact, but specific to what a one-layer circuit
         # from |0..0> leaves untouched (known zeros never read / computed / stored, trailing CX layer
         # folded into Z-parity observables) -- NOT a throughput figure for gate application
         sc = timed_k2(n, B, size, a.steps, a.warmup, 0)
         s2 = summarize(sc, False)
         s2["roofline"] = {k: v for k, v in roofline_of(sc, False, None).items()
-                          if k in ("kernel", "achieved", "frac", "moved_GBps", "moved_frac", "avg_launch_ms")}
+                          if k in ("kernel", "achieved", "frac", "algorithmic_GBps", "fusion_factor", "avg_launch_ms")}
         s2["gates_folded_into_observables"] = sc["folded"]
         s2["max_abs_diff_vs_headline_expvals"] = float((sc["out"] - head["out"]).abs().max())
         s2["note"] = ("default plan flags: known-zero tracking + observable folding; counts all "
@@ -472,26 +789,17 @@ def main():
                       "amplitudes are never touched")
         result["exact_shortcuts"] = s2
         del sc
-        # all amplitudes live, observable folding left to the engine: on live input it now applies
-        # the trailing CX layer (free in the fast tile path) instead of folding it -- the folded
-        # form's last pass (k_reg_measure) was the slower one (112 vs 100 ms per step)
-        fo = timed_k2(n, B, size, max(3, a.steps // 4), 1, N.PLAN_NO_SPARSE)
-        result["k2_all_live_cx_folded"] = summarize(fo, True, count_gates=n_gates - fo["folded"])
-        result["k2_all_live_cx_folded"]["gates_folded_into_observables"] = fo["folded"]
-        result["k2_all_live_cx_folded"]["note"] = (
-            "QMLE_PLAN_NO_SPARSE only: the engine chooses between folding the trailing CX layer into "
-            "the observables and applying it (pass-cost model, DESIGN 4.6); 0 folded = it applied them")
-        del fo
         # a deeper circuit: 4 layers with data re-uploading = 5 ansatz + 4 encoding layers
         try:
             deep = {}
             for label, fl in (("all_live", DENSE), ("default_flags", 0)):
                 d = timed_k2(n, B, size, 3, 1, fl, layers=4, dru=True, x=0.5)
                 deep[label] = summarize(d, fl != 0)
+                deep[label]["operators_executed_per_state"] = d["desc"]["n_lowered"]
                 if fl:
                     deep[label]["roofline"] = {k: v for k, v in roofline_of(d, True, None).items()
-                                               if k in ("kernel", "achieved", "frac", "moved_GBps",
-                                                        "moved_frac", "avg_launch_ms", "launches")}
+                                               if k in ("kernel", "achieved", "frac", "algorithmic_GBps",
+                                                        "fusion_factor", "avg_launch_ms", "launches")}
                 del d
             deep["workload"] = (f"Model({n}, 4, Hardware_Efficient) with data re-uploading, input 0.5: "
                                 f"{deep['all_live']['gates_counted_per_state']} gates/state, batch {B}, 3 timed steps")
@@ -507,17 +815,22 @@ def main():
             result["cpu_baseline"]["other_legs"] = {"error": str(e)}
         del head
         torch.cuda.empty_cache()
+        # LDS-resident regime (n <= 14 is bound by LDS / fp32 VALU, not by HBM)
         try:
-            result["k1_single_gate_28q"] = k1_sweep()
-        except Exception as e:  # pragma: no cover - e.g. not enough free HBM
-            result["k1_single_gate_28q"] = {"error": str(e)}
-    if expr is not None:
-        result["expressibility_12q_1024pairs"] = expr
-        if size == 1:
+            result["lds_regime"] = {
+                "c3_states_12q": lds_regime_leg(12, 3, False, 2048, "state"),
+                "c3_states_12q_saturated": lds_regime_leg(12, 3, False, 32768, "state"),
+                "c4_expval_10q": lds_regime_leg(10, 6, True, 4096, "expval"),
+                "c4_expval_10q_saturated": lds_regime_leg(10, 6, True, 65536, "expval"),
+            }
+        except Exception as e:  # pragma: no cover
+            result["lds_regime"] = {"error": str(e)}
+        for key, fn in (("k1_single_gate_28q", k1_sweep), ("mw_28q", mw_28q_leg),
+                        ("adjoint_gradient_20q", adjoint_gradient_wallclock)):
             try:
-                result["adjoint_gradient_20q"] = adjoint_gradient_wallclock()
-            except Exception as e:  # extras never break the headline line
-                result["adjoint_gradient_20q"] = {"error": str(e)}
+                result[key] = fn()
+            except Exception as e:  # pragma: no cover - e.g. not enough free HBM
+                result[key] = {"error": str(e)}
     distributed.barrier()
     print(json.dumps(result), flush=True)
 

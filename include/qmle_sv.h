@@ -250,6 +250,10 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
                        float *d_purities, void *d_workspace, size_t workspace_bytes,
                        qmle_stream stream);
 size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch);
+/* how many times qmle_meyer_wallach streams the state from HBM at this size (host only;
+ * bench.py's bytes-moved accounting): the passes of the tile scheme from 12 qubits on, one
+ * cache-resident sweep per wire below */
+int qmle_meyer_wallach_reads(int n_qubits);
 /* numpy.histogram(values, bins=linspace(lo,hi,n_bins+1)) counts (last bin
  * right-inclusive) -- expressibility.py:104-108; d_counts int32[n_bins], zeroed
  * by the call */

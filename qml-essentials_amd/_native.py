@@ -120,6 +120,7 @@ SYMBOLS = [
     ("qmle_expval_parity_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
+    ("qmle_meyer_wallach_reads", _I, [_I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
     ("qmle_adjoint_gradient", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
                                    _VP, _I, _VP, _SZ, _VP]),
@@ -544,6 +545,11 @@ def meyer_wallach(states, return_purities: bool = False):
                                    C.c_void_p(ws.data_ptr()), wsb, _stream_ptr()),
           "qmle_meyer_wallach")
     return (out, pur) if return_purities else out
+
+
+def mw_reads(n_qubits: int) -> int:
+    """HBM reads of the state per ``meyer_wallach`` call at this size (host only)."""
+    return int(lib().qmle_meyer_wallach_reads(int(n_qubits)))
 
 
 def histogram(values, n_bins: int, lo: float = 0.0, hi: float = 1.0):

@@ -987,6 +987,24 @@ int expval_kernel_of(const qmle_plan *p, size_t si, bool sparse) {
   return live_bits <= 2 && g.n_ops > 0 ? 2 : 1;
 }
 
+// fp32 flops per state of the operators the plan really applies (after 1-qubit merging): a dense
+// 2x2 costs 4 complex multiplies + 2 complex adds per amplitude pair = 14 per amplitude, a
+// diagonal one 6, a permutation 0; a control halves the amplitudes touched.
+static double plan_flops_per_state(const qmle_plan *p) {
+  const double D = std::ldexp(1.0, p->n);
+  double f = 0;
+  for (const LoweredOp &op : p->lowered) {
+    const double live = D / (double)(1u << op.nc);
+    switch (op.kind) {
+      case LK_1Q: f += (op.flags & LF_PERMX) ? 0.0 : (op.flags & LF_DIAG) ? 6.0 * live : 14.0 * live; break;
+      case LK_2Q: f += 30.0 * live; break;
+      case LK_DIAG_ALL: f += 6.0 * D; break;
+      case LK_4Q: f += 126.0 * D; break;
+    }
+  }
+  return f;
+}
+
 std::string describe_plan(const qmle_plan *p) {
   std::ostringstream os;
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
@@ -994,7 +1012,8 @@ std::string describe_plan(const qmle_plan *p) {
      << ",\"whole_state_lds\":" << (p->whole_state_lds ? "true" : "false")
      << ",\"model_cost\":" << p->model_cost << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
      << ",\"mat_floats\":" << p->mat_floats
-     << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state << ",\"stages\":[";
+     << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state
+     << ",\"flops_per_state\":" << plan_flops_per_state(p) << ",\"stages\":[";
   for (size_t s = 0; s < p->stages.size(); ++s) {
     const Stage &st = p->stages[s];
     if (s) os << ",";

@@ -5538,6 +5538,11 @@ int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint
 
 static int mw_passes(int n) { return n <= kMwT ? 1 : (n - kMwL + (kMwT - kMwL) - 1) / (kMwT - kMwL); }
 
+int qmle_meyer_wallach_reads(int n_qubits) {
+  if (n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS) return 0;
+  return n_qubits >= kMwT ? mw_passes(n_qubits) : n_qubits;  // below the tile size: one (cached) sweep per wire
+}
+
 size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch) {
   if (n_qubits < 1 || batch < 1) return 0;
   if (n_qubits >= kMwT)

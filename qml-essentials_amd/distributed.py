@@ -84,7 +84,13 @@ def check_same_arguments(*arrays) -> None:
             continue
         if hasattr(a, "detach"):
             a = a.detach().cpu().numpy()
-        a = np.ascontiguousarray(a)
+        try:
+            a = np.ascontiguousarray(a)
+            if a.dtype == object:
+                raise TypeError
+        except (TypeError, ValueError):
+            h.update(repr(a).encode())
+            continue
         h.update(str(a.shape).encode() + str(a.dtype).encode() + a.tobytes())
     v = int.from_bytes(h.digest(), "little") >> 1
     dist = _dist()
@@ -142,12 +148,15 @@ def shard_bounds(n: int, rank: int = None, size: int = None) -> Tuple[int, int]:
     return rank * n // size, (rank + 1) * n // size
 
 
-def my_block(n: int) -> Tuple[int, int, bool]:
+def my_block(n: int, *arguments) -> Tuple[int, int, bool]:
     """``(lo, hi, sharded)`` of this rank for a batch of ``n`` rows: the whole range when
     sharding is off or there are fewer rows than ranks (then every rank computes all rows and
     no collective runs).  The one place the four call sites (Script, Model's compiled device
-    path, Expressibility pairs, Meyer-Wallach samples) take their block from."""
+    path, Expressibility pairs, Meyer-Wallach samples) take their block from; they hand over
+    the call's ``arguments`` (params / inputs / ...), which ``QMLE_SHARD_CHECK=1`` verifies to be
+    identical on every rank before any row is split (:func:`check_same_arguments`)."""
     if enabled() and n >= world()[1]:
+        check_same_arguments(n, *arguments)
         lo, hi = shard_bounds(n)
         return lo, hi, True
     return 0, n, False
@@ -166,8 +175,10 @@ def all_gather_rows(local, n_total: int):
     import torch
 
     rank, size = world()
-    if size == 1:
+    if not is_initialized():
         return local
+    # (a one-rank process group still goes through the collective: the product never shards at
+    # world size 1 -- `enabled()` -- but tests/test_gpu_distributed.py exercises RCCL this way)
     is_np = isinstance(local, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
     dist = _dist()

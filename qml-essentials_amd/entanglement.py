@@ -49,7 +49,7 @@ class Entanglement:
         kwargs.pop("execution_type", None)
         params = np.asarray(model.params)
         total = params.shape[0]
-        lo, hi, sharded = distributed.my_block(total)
+        lo, hi, sharded = distributed.my_block(total, params, kwargs.get("inputs"))
         with distributed.local_only():
             states = model._forward(params=params[lo:hi], execution_type="state",
                                     as_tensor=True, **kwargs)

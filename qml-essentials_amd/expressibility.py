@@ -31,7 +31,7 @@ class Expressibility:
         n_samples = int(n_samples)
         model.initialize_params(random_key, repeat=n_samples * 2)
         params = np.asarray(model.params)
-        lo, hi, sharded = distributed.my_block(n_samples)
+        lo, hi, sharded = distributed.my_block(n_samples, params, kwargs.get("inputs"))
         local = np.concatenate([params[lo:hi], params[n_samples + lo: n_samples + hi]])
         kwargs.pop("execution_type", None)
         with distributed.local_only():

@@ -765,7 +765,7 @@ class Model:
             leaves.append(x); divs.append(B_P if cross else 1); mods.append(B_I if B_I > 1 else 1)
         if _want_call:  # (Model.vjp_device) hand the compiled call + its leaves to the caller
             return cc, leaves, divs, mods, B
-        lo, hi, sharded = distributed.my_block(B)
+        lo, hi, sharded = distributed.my_block(B, *leaves)
         result = cc.run(leaves, divs, mods, hi - lo, lo)
         if sharded:
             result = distributed.all_gather_rows(result, B)

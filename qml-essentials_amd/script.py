@@ -265,7 +265,7 @@ class Script:
             use_density = any(isinstance(o, KrausChannel) for o in tape)
         # multi-GPU: this rank simulates one contiguous block of the batch; one
         # all-gather returns the full result everywhere (script.py:443-453)
-        lo, hi, sharded = distributed.my_block(batch_size)
+        lo, hi, sharded = distributed.my_block(batch_size, *args)
         local = hi - lo
         chunk = memory.compute_chunk_size(n_qubits, local, type, use_density, n_obs, n_ops=n_ops)
         if chunk >= local:

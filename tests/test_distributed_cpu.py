@@ -301,3 +301,47 @@ def test_process_group_alone_does_not_switch_sharding_on():
         import importlib
         importlib.reload(d)
         d._opt_in = saved
+
+
+# ---------------------------------------------------------------------------------------------
+# QMLE_SHARD_CHECK=1: the identical-arguments contract is verified at every my_block() call site
+# (check_same_arguments existed but nothing called it)
+# ---------------------------------------------------------------------------------------------
+def _check_worker(rank, size, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(size), LOCAL_RANK=str(rank), QMLE_SHARD_CHECK="1")
+    from qml_essentials_amd import distributed
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+
+    distributed.init_from_env("gloo")
+    calls = []
+    _install_fake_engine(calls)
+    m = Model(2, 1, "Hardware_Efficient")
+    m.host_arrays_via_device = False
+    x = np.linspace(0, 1, 6, dtype=np.float32).reshape(6, 1)
+    same = np.asarray(m(inputs=x))                      # identical arguments: passes
+    report = {"same_shape": same.shape}
+    try:                                                # per-rank minibatch with sharding on: refused
+        m(inputs=x + np.float32(rank))
+        report["script"] = "no error"
+    except RuntimeError as e:
+        report["script"] = str(e)
+    m2 = Model(3, 1, "Hardware_Efficient", data_reupload=False)
+    try:                                                # different sampling key -> different params
+        Entanglement.meyer_wallach(m2, n_samples=4, random_key=100 + rank)
+        report["mw"] = "no error"
+    except RuntimeError as e:
+        report["mw"] = str(e)
+    q.put((rank, report))
+    distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_check_refuses_different_arguments_across_ranks():
+    res = _spawn(_check_worker, 2)
+    for rank, rep in res.items():
+        assert rep["same_shape"] == (6, 2)
+        assert "different arguments" in rep["script"], rep
+        assert "different arguments" in rep["mw"], rep

@@ -3,6 +3,9 @@
 the per-kernel PMC averages that tools/parse_pmc.py wrote.  Usage: update_traffic.py pmc.json n states"""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import source_sha16  # the records are signed with the kernel sources they were collected for
+SHA = source_sha16()
 pm = json.load(open(sys.argv[1])); n = int(sys.argv[2]); states = int(sys.argv[3])
 tag = sys.argv[4] if len(sys.argv) > 4 else "fused"   # "dense": the all-amplitudes-live plan
 source = sys.argv[5] if len(sys.argv) > 5 else None
@@ -22,8 +25,19 @@ for fam, d in pm.items():
         continue
     rd, wr = round(d["hbm_read_bytes_per_launch_x2_corrected"]), round(d["hbm_write_bytes_per_launch"])
     t[f"{fam}:n{n}:{tag}"] = {"read": rd, "write": wr, "hbm_bytes_per_launch": rd + wr,
-                              "states_per_launch": states, "launches_averaged": d.get("launches")}
+                              "states_per_launch": states, "launches_averaged": d.get("launches"),
+                              "source_sha16": SHA}
     if source:
         t[f"{fam}:n{n}:{tag}"]["source"] = source
+# Meyer-Wallach: bytes per qmle_meyer_wallach CALL = every k_mw_* launch of one call (tag "mw": the
+# counters come from tools/mw_bench.py, `states` = calls profiled)
+if tag == "mw":
+    rd = sum(d.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) * d.get("launches", 0)
+             for f, d in pm.items() if f.startswith("k_mw")) / max(1, states)
+    wr = sum(d.get("hbm_write_bytes_per_launch", 0.0) * d.get("launches", 0)
+             for f, d in pm.items() if f.startswith("k_mw")) / max(1, states)
+    t[f"meyer_wallach:n{n}"] = {"read": round(rd), "write": round(wr), "hbm_bytes_per_launch": round(rd + wr),
+                                "states_per_launch": 1, "calls_averaged": states, "source": source,
+                                "source_sha16": SHA}
 json.dump(t, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in t.items() if k != "_how"}, indent=1))
