@@ -357,7 +357,8 @@ def summarize(run, dense, count_gates=None):
             "register_tile_groups_per_pass": [len(st.get("fast_groups") or st.get("groups") or [])
                                               for st in desc["stages"]],
             "hbm_bytes_moved_per_state": moved,
-            "moved_GBps": round(moved * B * steps / el / 1e9, 1),
+            "moved_GBps_per_gpu": round(moved * B * steps / el / 1e9, 1),
+            "moved_GBps": round(moved * B * size * steps / el / 1e9, 1),
             "moved_frac_of_8TBps": round(moved * B * steps / el / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
@@ -759,7 +760,8 @@ def main(argv=None):
                                        round(max(head["elapsed_per_rank"]), 6)],
         "statevectors_per_s": round(total_states / elapsed, 2),
         "hbm_bytes_moved_per_state": hs["hbm_bytes_moved_per_state"],
-        "step_moved_GBps": hs["moved_GBps"], "step_moved_frac_of_8TBps": hs["moved_frac_of_8TBps"],
+        "step_moved_GBps": hs["moved_GBps"], "step_moved_GBps_per_gpu": hs["moved_GBps_per_gpu"],
+        "step_moved_frac_of_8TBps": hs["moved_frac_of_8TBps"],
         "roofline": roofline,
     }
     if c3 is not None:

@@ -54,7 +54,9 @@ typedef enum qmle_status {
   QMLE_ERR_HIP = -8,             /* a HIP runtime call failed                  */
   QMLE_ERR_NO_DEVICE = -9,
   QMLE_ERR_UNSUPPORTED = -10,
-  QMLE_ERR_SLOT_RANGE = -11
+  QMLE_ERR_SLOT_RANGE = -11,
+  QMLE_ERR_INTERNAL = -12        /* a build-time invariant of the kernels does not hold (e.g. a tile
+                                    kernel whose dynamic LDS does not start at offset 0)          */
 } qmle_status;
 
 /* Gate vocabulary = the gate classes of qml_essentials/operations.py that the

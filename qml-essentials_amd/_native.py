@@ -166,7 +166,9 @@ def check(status: int, what: str = "") -> None:
     if status == OK:
         return
     if status == -10:
-        raise Unsupported(f"{what}: {lib().qmle_status_string(status).decode()} (qmle status -10)")
+        raise Unsupported(f"{what}: {lib().qmle_status_string(status).decode()} (qmle status -10; "
+                          "this is also what a plan answers when it is run on another GPU than the "
+                          "one of its first run -- build one Plan per device)")
     msg = lib().qmle_status_string(status).decode()
     raise _STATUS_EXC.get(status, RuntimeError)(f"{what}: {msg} (qmle status {status})")
 

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <utility>
 
@@ -1454,8 +1455,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   const int T = a.T;
   // LDS byte offset of the tile; the XOR addressing needs it aligned to the tile size (it is 0:
   // the kernel has no static LDS)
+  // (launch_tile checks this on the host, once per device: lds_base_is_zero)
   const uint32_t sbo = lds_offset_of(smem4);
-  if (sbo & ((8u << T) - 1u)) __builtin_trap();
   // measuring epilogues: scratch aliases the tile, except the whole-state one (own region)
   float *red = a.meas == TM_EXPVAL ? reinterpret_cast<float *>(s + (1u << T)) : reinterpret_cast<float *>(s);
   const int tid = threadIdx.x, nt = blockDim.x;  // nt = 2^(T-4)
@@ -3824,12 +3825,30 @@ static inline int current_device() {
   return dev;
 }
 static inline bool first_use_on_device(int slot) {
-  static bool done[8][kMaxDevices] = {};
-  bool &d = done[slot][current_device()];
-  const bool first = !d;
-  d = true;
-  return first;
+  static std::atomic<bool> done[8][kMaxDevices] = {};
+  int dev = -1;
+  // a device index beyond the table has no slot of its own: its attributes are simply set on
+  // every call (idempotent) instead of sharing -- and trusting -- slot 0's flag
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;
+  return !done[slot][dev].exchange(true);
 }
+
+// The tile kernels address their LDS tile by XOR (swizzle + gather offsets folded into one
+// `base ^ offset`), which is only an addition while the tile starts at a multiple of its size.
+// The dynamic-LDS window starts right behind a kernel's static __shared__ variables, so the
+// invariant is "these kernels have none": checked here on the host at first use (a static
+// __shared__ added later turns into QMLE_ERR_INTERNAL at the first launch instead of wrong
+// amplitudes or a device-side abort); tests/test_abi_cpu.py checks the build's resource table.
+static int lds_base_is_zero(const void *kernel) {
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, kernel) != hipSuccess) return QMLE_ERR_HIP;
+  return attr.sharedSizeBytes == 0 ? QMLE_OK : QMLE_ERR_INTERNAL;
+}
+#define QMLE_LDS_BASE_CHECK(kernel)                                     \
+  do {                                                                  \
+    const int rc_lds_ = lds_base_is_zero((const void *)(kernel));       \
+    if (rc_lds_ != QMLE_OK) return rc_lds_;                             \
+  } while (0)
 
 int ensure_device_plan(qmle_plan *p) {
   if (p->dev.blob) {
@@ -3970,6 +3989,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
              ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   if (first_use_on_device(0)) {
+    QMLE_LDS_BASE_CHECK(k_tile<false>);
+    QMLE_LDS_BASE_CHECK(k_tile<true>);
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<true>,
@@ -4004,6 +4025,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                      total >= 4ull * n_cu * wg_per_cu;
   if (pf_ok) {
     if (first_use_on_device(1)) {
+      QMLE_LDS_BASE_CHECK(k_tile_pf<false>);
+      QMLE_LDS_BASE_CHECK(k_tile_pf<true>);
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<true>,
@@ -4114,6 +4137,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       (st.T < p->n ? meas != TM_EXPVAL : !no_fast_whole)) {
     if (first_use_on_device(2)) {
 #define QMLE_T2_LDS(NT, ME, MU)                                                   \
+  QMLE_LDS_BASE_CHECK((k_tile2<NT, ME, MU>));                                      \
   HIPCHK(hipFuncSetAttribute((const void *)k_tile2<NT, ME, MU>,                    \
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
       QMLE_T2_LDS(false, false, false); QMLE_T2_LDS(true, false, false);
@@ -4417,6 +4441,7 @@ const char *qmle_status_string(int status) {
     case QMLE_ERR_NO_DEVICE: return "no HIP device";
     case QMLE_ERR_UNSUPPORTED: return "unsupported configuration";
     case QMLE_ERR_SLOT_RANGE: return "angle slot out of range";
+    case QMLE_ERR_INTERNAL: return "internal invariant violated (kernel LDS layout)";
     default: return "unknown status";
   }
 }

@@ -259,9 +259,21 @@ class LoweredTape:
         return table[:, : self.n_slots] if self.n_slots else table[:, :0]
 
 
+def _current_device() -> int:
+    try:
+        import torch
+
+        return int(torch.cuda.current_device()) if torch.cuda.is_available() else -1
+    except Exception:  # pragma: no cover
+        return -1
+
+
 def get_plan(low: LoweredTape, flags: Optional[int] = None) -> N.Plan:
     flags = PLAN_FLAGS if flags is None else flags
-    key = (low.key, flags)
+    # a plan's device image lives on the GPU of its first run (libqmle_sv refuses another one):
+    # the cache is keyed by the current device, so a process that switches torch.cuda devices
+    # gets one plan per device instead of QMLE_ERR_UNSUPPORTED from a cached one
+    key = (low.key, flags, _current_device())
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         plan = N.Plan(low.ops, low.n_qubits, low.n_slots, low.consts, flags)

@@ -150,6 +150,30 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy():
         assert r["Occupancy"] >= 5 and r["VGPRs"] <= (96 if multi else 64), (name, r)
 
 
+def test_xor_addressed_tile_kernels_have_no_static_lds():
+    """The tile kernels address their LDS tile as ``base ^ offset`` (swizzle and gather offsets in
+    one XOR), which needs the dynamic-LDS window to start at offset 0, i.e. NO static __shared__
+    in those kernels (ADVICE r2 / VERDICT r2 item 7).  The library checks it on the host at the
+    first launch (``lds_base_is_zero`` -> QMLE_ERR_INTERNAL, no device-side trap any more); this
+    is the same check on the build's resource table, where it fails without a GPU."""
+    import json
+    import os
+
+    import __graft_entry__ as G
+
+    if not os.path.exists(G.RESOURCES):
+        G.build(force=True)
+    res = json.load(open(G.RESOURCES))
+    xor_kernels = {k: v for k, v in res.items()
+                   if any(t in k for t in ("6k_tileILb", "k_tile2", "k_tile_pf", "k_mw_tile2", "k_mw_read"))}
+    assert len(xor_kernels) >= 14
+    for name, r in xor_kernels.items():
+        assert r["LDS Size"] == 0, (name, r)
+    src = open(os.path.join(G.CSRC, "qmle_sv.hip")).read()
+    assert "__builtin_trap" not in src
+    assert N.lib().qmle_status_string(-12).decode().startswith("internal invariant")
+
+
 def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
     """Plan compiler, host only: the K2 plan (one HE layer at n = 24, <Z> on every wire) after
     observable folding -- ready gates are scheduled low bits first, every stage knows which bit

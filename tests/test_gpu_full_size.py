@@ -80,8 +80,9 @@ def test_n28_single_gates_streaming_path_closed_form_and_tile_path():
             for g, wires, ang in gates:
                 kinds += _apply(st, n, g, wires, ang)
             # control on bit positions 1..3 goes through a single-gate tile pass by design
-            # (qmle_plan.cpp direct_ok); everything else must have streamed
-            low_ctrl = kind in ("CX", "CRX") and 1 <= n - 1 - c2 <= 3
+            # (qmle_plan.cpp direct_ok) unless the target sits on positions 1..6, which the
+            # lane-exchange streaming mode 7 of k_direct_1q serves; everything else must stream
+            low_ctrl = kind in ("CX", "CRX") and 1 <= n - 1 - c2 <= 3 and not 1 <= n - 1 - w <= 6
             assert all(k == ("tile" if low_ctrl else "direct") for k in kinds), (kind, w, kinds)
             got = N.expval_z(st, list(range(n))).cpu().numpy()[0]
             want = c.copy()

@@ -51,6 +51,34 @@ def test_random_circuits_state_parity_all_modes(n):
         assert err < 2e-6, (mode, n, err)  # fp32 state vs fp64 oracle, 40 gates
 
 
+@pytest.mark.parametrize("n", [14, 16])
+def test_low_control_streaming_mode_every_control_target_pair(n):
+    """k_direct_1q mode 7: non-diagonal controlled gates with the control on bit
+    position 0..3 and the target on position 1..6, BOTH sides of the control (per-lane control
+    branch with the target above and below it), one gate per launch, against the oracle."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(70 + n)
+    prefix = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    prefix += [("CX", [q, (q + 1) % n], ()) for q in range(n - 1)]
+    prefix += [("RX", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    flags = N.plan_flags(no_fusion=True, force_global=True)
+    for pc in range(0, 4):
+        for pt in range(1, 7):
+            if pt == pc:
+                continue
+            c, t = n - 1 - pc, n - 1 - pt
+            for gate in (("CX", [c, t], ()), ("CRX", [c, t], (0.9,)), ("CRY", [c, t], (1.3,)),
+                         ("CY", [c, t], ())):
+                tape = prefix + [gate]
+                got, plan = _run(tape, n, "state", flags=flags)
+                kinds = [st["kind"] for st in plan.describe()["stages"]]
+                assert kinds[-1] == "direct", (gate, pc, pt, kinds[-1])  # streamed, not a tile pass
+                want = OE.simulate_pure(tape, n, np.complex128)
+                err = np.abs(got[0] - want).max()
+                assert err < 1e-6, (gate, pc, pt, err)
+
+
 @pytest.mark.parametrize("n", [4, 9, 13, 14])
 def test_every_wire_every_single_gate_kind(n):
     """One gate per circuit on a random state prefix: exercises every target /
