@@ -3365,355 +3365,230 @@ k_parity_final(const float *__restrict__ partial, int n_blocks, int count, int n
 
 
 // ---------------------------------------------------------------------------
-// Meyer-Wallach via LDS-staged tiles: one read of the state covers the cross terms
-// c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) and the signed populations of EVERY
-// tile-local bit (12 per pass) -- entanglement.py:86-101 with Tr rho_j^2 = a^2+d^2+2|c|^2.
-// Pass p stages bits {0..L-1} + the p-th chunk of T-L high bits; ceil((n-L)/(T-L)) passes
-// instead of n.  Row layout per tile: [3 * local bit + {cr, ci, z}], [36] = total.
+// Meyer-Wallach (entanglement.py:69-103 with Tr rho_j^2 = a^2 + d^2 + 2 |c|^2): THREE reads of
+// the state at n = 28 -- ceil((n - 12) / 8) + 1 in general -- instead of n.
+//
+// A read streams the state through 2^12-amplitude LDS tiles: the 4 lowest bits (128-byte rows)
+// + two runs of 4 bit positions, [lo, lo+4) and [lo2, lo2+4), and reports the cross terms
+// c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) of its bits.  The FIRST read's tile is 32 KiB
+// of contiguous memory (bits 0..11); it also reports the signed populations of those 12 bits and
+// the per-row totals from which the populations of EVERY other bit follow (sign of a row = one
+// bit of its index), so the later reads carry cross terms only.
+//
+// Round-3 structure (tools/mw_tune.hip has the stand-alone bench it was tuned with):
+//  * a lane's own 8 float4 span local bits {0, 9, 10, 11}: their cross terms (and, first read,
+//    the 4-bit population butterfly) come straight out of the load registers, before staging;
+//  * then ONE staging round trip and cross-only register gathers: local bits 1..4 and 5..8
+//    (first read: 2 x 16 ds_read_b64) resp. 4..7 and, for bit 8 alone, 8 ds_read_b128 over
+//    {0, 8, 9, 10} (later reads) -- 192 resp. 128 packed fmas per 16 amplitudes, nothing else;
+//  * populations of the thread-mapped local bits 1..8 are the per-thread totals signed by the
+//    thread index, applied once in the reduction at the end of a workgroup's walk;
+//  * no register prefetch: 91 / 108 VGPRs = 5 / 4 workgroups per CU keep more bytes in flight
+//    than a software pipeline at 3 (the round-2 kernel: 128 - 144 VGPRs, 4.1 - 4.85 TB/s);
+//  * which positions share a tile matters: at n = 28 the pairs {12-15, 24-27} and {16-19, 20-23}
+//    stream at 6.9 TB/s, {12-15, 20-23} at 5.7 and {20-27} at 4.5 (same bytes, same code;
+//    profiles/r03_mw_tune.txt) -- mw_plan() pairs the 4-bit chunks outermost with innermost.
+// Measured at n = 28 (MI355X): first read 0.34 ms, later reads 0.31 ms each; round 2: 0.52 +
+// 2 x 0.44.
 // ---------------------------------------------------------------------------
-constexpr int kMwT = 12, kMwL = 4, kMwRow = 40, kMwThreads = 256;
+constexpr int kMwT = 12, kMwThreads = 256;
+constexpr int kMwRowFirst = 48, kMwRowLater = 16;
 
-struct MwArgs {
+struct MwReadArgs {
   const float2 *states;
-  float *partial;  // [batch][tiles][kMwRow] for this pass
-  int n;
-  int8_t tile_bits[kMwT];
-  int8_t outer_bits[QMLE_MAX_QUBITS];
-  // k_mw_tile2: the same positions as contiguous runs (scalar registers instead of indexed
-  // reads of the byte arrays): tile index -> base, lane index -> offset, u = 0..7 -> offset
-  int n_runs;
-  uint32_t run_off[4], run_mask[4], run_pos[4];
-  int n_in_runs;
-  uint32_t in_off[3], in_mask[3], in_pos[3];
-  uint32_t uo8[8];
+  float *rows;  // [batch][rows_per_state][kMwRowFirst | kMwRowLater]
+  int n, lo, lo2, q;  // tile = bits 0..3 + lo..lo+3 + lo2..lo2+3; 2^q tiles per workgroup
 };
 
-// LOW: also the sums of the 4 low bits, which every pass stages but only the first one reports
-template <bool LOW>
-__global__ void __launch_bounds__(kMwThreads) k_mw_tile(const MwArgs a, uint32_t n_tiles) {
-  extern __shared__ float4 smem4[];
-  float2 *s = reinterpret_cast<float2 *>(smem4);
-  uint32_t *lut = reinterpret_cast<uint32_t *>(s + (1u << kMwT));
-  float *red = reinterpret_cast<float *>(lut + (1u << (kMwT - kMwL)));
-  const int tid = threadIdx.x, b = blockIdx.y;
-  for (uint32_t h = tid; h < (1u << (kMwT - kMwL)); h += kMwThreads) {
-    uint32_t v = 0;
-    for (int i = 0; i < kMwT - kMwL; ++i) v |= ((h >> i) & 1u) << a.tile_bits[kMwL + i];
-    lut[h] = v;
-  }
-  const float2 *st = a.states + ((size_t)b << a.n);
-  constexpr uint32_t half = 1u << (kMwT - 1), lowmask = (1u << kMwL) - 1u;
-  static_assert(half == 8u * kMwThreads, "one staging round");
-  float acc[37];
-#pragma unroll
-  for (int k = 0; k < 37; ++k) acc[k] = 0.f;
-
-  // One tile per workgroup.  (A persistent variant that keeps the 37 sums in registers across
-  // tiles was tried: hipcc then needs 256 VGPRs -> 1 wave/SIMD and runs 2x slower.)
-  (void)n_tiles;
-  {
-    const uint32_t tile = blockIdx.x;
-    uint64_t base = 0;
-    for (int i = 0; i < a.n - kMwT; ++i) base |= (uint64_t)((tile >> i) & 1u) << a.outer_bits[i];
-    __syncthreads();  // LUT ready / previous tile fully consumed
-    {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t j = (tid + u * kMwThreads) * 2u;
-        v[u] = *reinterpret_cast<const float4 *>(st + (base | lut[j >> kMwL] | (j & lowmask)));
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        reinterpret_cast<float4 *>(s)[sw((tid + u * kMwThreads) * 2u) >> 1] = v[u];
-    }
-    __syncthreads();
-    const uint32_t tidv = (uint32_t)tid;
-#pragma unroll
-    for (int g = LOW ? 0 : 1; g < 3; ++g) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
-      const uint32_t bs =
-          sw(ins0(ins0(ins0(ins0(tidv, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3));
-      float2 r[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = s[bs ^ sw((uint32_t)c << (4 * g))];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float cr = 0.f, ci = 0.f, z = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c & (1 << t)) continue;
-          const float2 x = r[c], y = r[c | (1 << t)];
-          cr += x.x * y.x + x.y * y.y;
-          ci += x.y * y.x - x.x * y.y;
-          z += (x.x * x.x + x.y * x.y) - (y.x * y.x + y.y * y.y);
-        }
-        acc[3 * (4 * g + t)] += cr;
-        acc[3 * (4 * g + t) + 1] += ci;
-        acc[3 * (4 * g + t) + 2] += z;
-      }
-      if (g == 1) {
-        float tot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) tot += r[c].x * r[c].x + r[c].y * r[c].y;
-        acc[36] += tot;
-      }
-    }
-  }
-  const int lane = tid & (kWave - 1), w = tid / kWave;
-  __syncthreads();
-  const float mine = wave_reduce_scatter<37>(acc);  // lane l: this wave's total of sum l
-  if (lane < 37) red[w * 37 + lane] = mine;
-  __syncthreads();
-  if (tid < 37) {
-    float v = 0.f;
-    for (int i = 0; i < kMwThreads / kWave; ++i) v += red[i * 37 + tid];
-    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = v;
-  }
+// x conj(y) accumulated into (re, im): two packed fmas
+__device__ __forceinline__ void mw_cross(v2f &s, v2f x, v2f y) {
+  s = __builtin_elementwise_fma(x, y.xx, s);
+  s = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, s);
+}
+// cross terms of the 4 bits a 16-amplitude register gather spans
+template <int B0>
+__device__ __forceinline__ void mw_cross16(v2f (&cr)[12], const v2f (&r)[16]) {
+  static_for<4>([&](auto t) {
+    static_for<8>([&](auto pq) {
+      constexpr int lowm = (1 << t) - 1;
+      constexpr int c = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+      mw_cross(cr[B0 + (int)t], r[c], r[c | (1 << t)]);
+    });
+  });
 }
 
-// Round-2 Meyer-Wallach tile kernel: same rows as k_mw_tile, built like k_tile2 -- no lookup
-// table (a lane's 8 float4 differ in wave-uniform high bits), cross terms as packed fp32 (2
-// instructions per amplitude pair), the populations of a gather's 4 bits through a pruned
-// Walsh-Hadamard butterfly (41 additions instead of 64), the 37 per-wave sums on the DPP data
-// path instead of 63 LDS-crossbar exchanges, and 2^q tiles per workgroup with the next tile in
-// flight in registers (one reduction and one 37-float row per 16 tiles at n = 28).
-// Measured (MI355X, n = 28, three reads of 2 GiB): 1.93 ms (k_mw_tile + 2 x k_mw_direct) ->
-// 2.01 ms one tile per workgroup -> 1.80 ms at q = 4 -> 1.41 ms with the bit positions as runs
-// in scalar registers (MwArgs::run_*) instead of indexed byte-array reads; hipcc gives the loop
-// form 180-204 VGPRs (2 waves per SIMD), and capping it at 128 spills (5 ms).  See DESIGN.md section 5 for why two
-// reads are out of reach with 160 KiB of LDS.
-template <bool LOW, bool NT>
-__global__ void __launch_bounds__(kMwThreads) k_mw_tile2(const MwArgs a, int q) {
-  extern __shared__ float4 smem4[];
-  float2 *s = reinterpret_cast<float2 *>(smem4);
-  float *red = reinterpret_cast<float *>(smem4);  // reduction scratch aliases the tile
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const uint32_t jl = 2u * tid;  // local bits 1..8 from tid (bits 0..3 contiguous), 9..11 from u
-  uint32_t goff = 0;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-    if (r < a.n_in_runs) goff |= ((jl >> a.in_off[r]) & a.in_mask[r]) << a.in_pos[r];
-  const uint32_t goff8 = goff << 3;
-  uint32_t uo[8];
-  static_for<8>([&](auto u) { uo[u] = a.uo8[u]; });
-  const uint32_t sl = sw(jl) >> 1;
-  const uint32_t tidv = (uint32_t)tid;
-  // a workgroup walks 2^q tiles: the next tile's 8 float4 per lane are in flight (registers)
-  // while the gathers run on the current one, and the 37 sums stay per work item until the end
-  auto tile_ptr = [&](uint32_t tile) {
-    uint64_t base = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < a.n_runs) base |= (uint64_t)((tile >> a.run_off[r]) & a.run_mask[r]) << a.run_pos[r];
-    return reinterpret_cast<const char *>(a.states + ((size_t)b << a.n) + base);
-  };
-  const uint32_t tile0 = blockIdx.x << q, n_it = 1u << q;
-  float4 v[8];
-  {
-    const char *st = tile_ptr(tile0);
-    static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
-  }
-  float acc[37];
-  static_for<37>([&](auto k) { acc[k] = 0.f; });
-  const uint32_t sbo = lds_offset_of(smem4);
-  const uint32_t slb = (sl << 4) + sbo;  // staging: LDS byte offset of the lane's first float4
-  constexpr bool kMwPrefetch = true;  // (without it: 1.43 - 1.44 instead of 1.39 - 1.41 ms at n = 28)
+template <bool FIRST, bool NT>
+__device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4) {
+  const uint32_t sbo = lds_offset_of(smem4);  // 0: no static LDS (launch side checks lds_base_is_zero)
+  const uint32_t tid = threadIdx.x;
+  const uint32_t jl = 2u * tid;  // local bits 1..8 from tid, 9..11 from u, bit 0 inside the float4
+  const int lo = a.lo, lo2 = a.lo2;
+  const uint64_t goff = ((uint64_t)(jl & 15u) | ((uint64_t)((jl >> 4) & 15u) << lo) | ((uint64_t)(jl >> 8) << lo2)) << 3;
+  const uint64_t ustep = (uint64_t)1 << (lo2 + 1 + 3);  // local bit 9 = second run's bit 1
+  const char *st = reinterpret_cast<const char *>(a.states + ((size_t)blockIdx.y << a.n)) + goff;
+  const uint32_t slb = (sw(jl) << 3) + sbo;  // staging address of u = 0; u adds u << 12
+  const uint32_t tile0 = blockIdx.x << a.q, n_it = 1u << a.q;
+  const uint32_t r0 = lo - 4, r1 = lo2 - lo - 4;  // outer runs [4, lo), [lo+4, lo2), [lo2+4, n)
+
+  // cross terms per reported bit: first read local bit b at cr[b]; later reads new bit k at cr[k]
+  // (k < 4: lo + k, else lo2 + k - 4)
+  v2f cr[12];
+  static_for<12>([&](auto k) { cr[k] = (v2f){0.f, 0.f}; });
+  float zin[4] = {0.f, 0.f, 0.f, 0.f}, tot = 0.f, zw[4] = {0.f, 0.f, 0.f, 0.f};
+
   for (uint32_t it = 0; it < n_it; ++it) {
-    if (it) __syncthreads();  // the previous tile's gathers are done
-    if (!kMwPrefetch && it) {
-      const char *st = tile_ptr(tile0 + it);
-      static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
-    }
-    static_for<8>([&](auto u) { lds_st128(slb ^ (sw((uint32_t)u << (kMwT - 3)) << 3), v[u]); });
-    __syncthreads();
-    if (kMwPrefetch && it + 1 < n_it) {
-      const char *st = tile_ptr(tile0 + it + 1);
-      static_for<8>([&](auto u) { v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uo[u] + goff8)); });
-    }
-    // (opaque per tile: hipcc would hoist the 32 - 48 gather addresses out of the tile loop and
-    // keep them in registers across it)
-    uint32_t tid_i = tidv;
-    asm volatile("" : "+v"(tid_i));
-    static_for<LOW ? 3 : 2>([&](auto gg) {  // local bits 4g .. 4g+3, one 16-amplitude gather each
-      constexpr int g = LOW ? (int)gg : (int)gg + 1;
-      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tid_i, 4 * g), 4 * g + 1), 4 * g + 2), 4 * g + 3)) << 3) + sbo;
-      v2f r[16];
-      static_for<16>([&](auto c) {
-        const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << (4 * g)) << 3));
-        r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
-      });
+    const uint32_t t = tile0 + it;
+    const uint64_t base = ((uint64_t)(t & ((1u << r0) - 1u)) << 4 | (uint64_t)((t >> r0) & ((1u << r1) - 1u)) << (lo + 4) |
+                           (uint64_t)(t >> (r0 + r1)) << (lo2 + 4)) << 3;
+    float4 v4[8];
+    static_for<8>([&](auto u) { v4[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + base + (uint64_t)u * ustep)); });
+    v2f lo_[8], hi_[8];  // the two amplitudes of each float4
+    static_for<8>([&](auto u) { lo_[u] = (v2f){v4[u].x, v4[u].y}; hi_[u] = (v2f){v4[u].z, v4[u].w}; });
+    // ---- bits held by the lane's own 8 float4: local 0 (halves of a float4) and 9, 10, 11 (u) ----
+    if (FIRST) {
+      static_for<8>([&](auto u) { mw_cross(cr[0], lo_[u], hi_[u]); });
       float pr[16];
-      static_for<16>([&](auto c) {
-        const v2f qq = r[c] * r[c];
-        pr[c] = qq.x + qq.y;
+      static_for<8>([&](auto u) {
+        const v2f q0 = lo_[u] * lo_[u], q1 = hi_[u] * hi_[u];
+        pr[2 * u] = q0.x + q0.y;
+        pr[2 * u + 1] = q1.x + q1.y;
       });
-      // populations: signed sums over each of the 4 bits + the total, pruned butterfly
       float h0 = 0.f, h1 = 0.f, h2 = 0.f, s1[8], s2[4], s3[2];
       static_for<8>([&](auto i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; });
       static_for<4>([&](auto i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; });
       static_for<2>([&](auto i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; });
-      acc[3 * (4 * g + 0) + 2] += h0;
-      acc[3 * (4 * g + 1) + 2] += h1;
-      acc[3 * (4 * g + 2) + 2] += h2;
-      acc[3 * (4 * g + 3) + 2] += s3[0] - s3[1];
-      if (g == 1) acc[36] += s3[0] + s3[1];
-      // cross terms x conj(y) over the 8 pairs of each bit: two packed fmas per pair
-      static_for<4>([&](auto t) {
-        v2f sum = {0.f, 0.f};  // (accumulating from zero and adding afterwards keeps the chains short)
-        static_for<8>([&](auto pq) {
-          constexpr int lo = (1 << t) - 1;
-          constexpr int c = ((pq & ~lo) << 1) | (pq & lo);
-          const v2f x = r[c], y = r[c | (1 << t)];
-          sum = __builtin_elementwise_fma(x, y.xx, sum);
-          sum = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, sum);
-        });
-        acc[3 * (4 * g + t)] += sum.x;
-        acc[3 * (4 * g + t) + 1] += sum.y;
+      zin[0] += h0; zin[1] += h1; zin[2] += h2; zin[3] += s3[0] - s3[1];
+      const float tt = s3[0] + s3[1];
+      tot += tt;
+      static_for<4>([&](auto j) { zw[j] += __uint_as_float(__float_as_uint(tt) ^ (((it >> j) & 1u) << 31)); });
+    }
+    static_for<3>([&](auto k) {
+      constexpr int B = FIRST ? 9 + (int)k : 5 + (int)k;
+      static_for<4>([&](auto pq) {
+        constexpr int lowm = (1 << k) - 1;
+        constexpr int u0 = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+        mw_cross(cr[B], lo_[u0], lo_[u0 | (1 << k)]);
+        mw_cross(cr[B], hi_[u0], hi_[u0 | (1 << k)]);
       });
     });
-  }
-  const int lane = tid & (kWave - 1), w = tid / kWave;
-  if (LOW) {
-    wave_sums_dpp63(acc);
-  } else {  // (the first 12 are not used by the later reads)
-    float (&tail)[25] = *reinterpret_cast<float (*)[25]>(&acc[12]);
-    wave_sums_dpp63(tail);
-  }
-  __syncthreads();  // every gather has been read: the tile becomes scratch
-  if (lane == kWave - 1) {
-#pragma unroll
-    for (int k = 0; k < 37; ++k) red[w * 37 + k] = acc[k];
-  }
-  __syncthreads();
-  if (tid < 37) {
-    float vv = 0.f;
-    for (int i = 0; i < kMwThreads / kWave; ++i) vv += red[i * 37 + tid];
-    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = vv;
-  }
-}
-
-// Passes after the first only report 8 high bits: no LDS staging for those.  A workgroup
-// takes a block of 2^14 amplitudes -- the 6 lowest bits (one wave = 512 contiguous bytes per
-// load instruction; the LDS tile kernel's 4 low bits give 128-byte runs) and the pass's 8
-// bits -- and walks it twice: the 16 amplitudes over the first 4 reported bits in registers,
-// then over the other 4 (second read out of L2).  The 25 sums are kept per work item across
-// the 2^q blocks a workgroup walks: one cross-lane reduction per workgroup.  Row layout as
-// k_mw_tile.
-struct MwDirectArgs {
-  const float2 *states;
-  float *partial;
-  int n;
-  int8_t hi[8];                        // reported bit positions, ascending
-  int8_t outer[QMLE_MAX_QUBITS];       // the other positions >= 6, ascending
-};
-
-// (156 VGPRs = 3 waves per SIMD; forcing 4 waves changes nothing: 1.96 vs 1.93 ms at n = 28)
-__global__ void __launch_bounds__(kMwThreads) k_mw_direct(const MwDirectArgs a, int q) {
-  __shared__ float red[(kMwThreads / kWave) * 37];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const float2 *st = a.states + ((size_t)b << a.n);
-  const uint32_t lane_off = (uint32_t)tid & 63u;  // bits 0..5
-  const uint32_t wv = (uint32_t)tid >> 6;          // 2 of the 4 bits a gather leaves to the work items
-  uint32_t hs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) hs[i] = 1u << a.hi[i];
-  // per reported bit: (cr, ci) as one packed pair, z; explicit two-lane arithmetic (left to the
-  // SLP vectoriser the loop-carried sums get paired at random: 180 VGPRs)
-  v2f cri[8];
-  float zz[8], tot = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { cri[k] = (v2f){0.f, 0.f}; zz[k] = 0.f; }
-  const int n_outer = a.n - 14;
-  for (uint32_t it = 0; it < (1u << q); ++it) {
-    const uint32_t blk = (blockIdx.x << q) + it;
-    uint64_t base = 0;
-    for (int i = 0; i < n_outer; ++i) base |= (uint64_t)((blk >> i) & 1u) << a.outer[i];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-#pragma unroll 1
-      for (uint32_t round = 0; round < 4; ++round) {
-        const uint32_t o = wv | (round << 2);  // the 4 bits of the OTHER gather
-        const uint32_t oo = ((o & 1u) ? hs[4 * (1 - g)] : 0u) | ((o & 2u) ? hs[4 * (1 - g) + 1] : 0u) |
-                            ((o & 4u) ? hs[4 * (1 - g) + 2] : 0u) | ((o & 8u) ? hs[4 * (1 - g) + 3] : 0u);
-        const float2 *pu = st + base + oo;
-        v2f r[16];
-        float pr[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const uint32_t go = ((c & 1) ? hs[4 * g] : 0u) | ((c & 2) ? hs[4 * g + 1] : 0u) |
-                              ((c & 4) ? hs[4 * g + 2] : 0u) | ((c & 8) ? hs[4 * g + 3] : 0u);
-          const float2 x = (pu + go)[lane_off];
-          r[c] = (v2f){x.x, x.y};
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) pr[c] = r[c].x * r[c].x + r[c].y * r[c].y;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          v2f sum = {0.f, 0.f};
-          float zt = 0.f;
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (c & (1 << t)) continue;
-            const v2f x = r[c], y = r[c | (1 << t)];
-            // conj(x) * y = (x.x y.x + x.y y.y,  x.x y.y - x.y y.x);  ci below is its negative,
-            // as in k_mw_tile -- only |c|^2 is used
-            sum = __builtin_elementwise_fma(x, y.xx, sum);
-            sum = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, sum);
-            zt += pr[c] - pr[c | (1 << t)];
-          }
-          cri[4 * g + t] += sum;
-          zz[4 * g + t] += zt;
-        }
-        if (g == 0) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) tot += pr[c];
-        }
-      }
+    if (it) __syncthreads();  // the previous tile's gathers are done
+    static_for<8>([&](auto u) { lds_st128(slb + ((uint32_t)u << 12), v4[u]); });
+    __syncthreads();
+    uint32_t tg = tid;
+    asm volatile("" : "+v"(tg));  // keeps the gather addresses out of loop-carried registers
+    {  // gather A: 16 amplitudes over local bits gA .. gA+3 (first read 1..4, later reads 4..7)
+      constexpr int gA = FIRST ? 1 : 4;
+      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, gA), gA + 1), gA + 2), gA + 3)) << 3) + sbo;
+      v2f r[16];
+      static_for<16>([&](auto c) {
+        const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << gA) << 3));
+        r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+      });
+      mw_cross16<FIRST ? gA : 0>(cr, r);
+    }
+    if (FIRST) {  // gather B: local bits 5..8
+      constexpr int gB = 5;
+      const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, gB), gB + 1), gB + 2), gB + 3)) << 3) + sbo;
+      v2f r[16];
+      static_for<16>([&](auto c) {
+        const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << gB) << 3));
+        r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+      });
+      mw_cross16<gB>(cr, r);
+    } else {  // local bit 8 alone: 8 float4 over local bits {0, 8, 9, 10}; thread index -> 1..7, 11
+      const uint32_t e0 = ((tg & 127u) << 1) | ((tg >> 7) << 11);
+      const uint32_t bs = (sw(e0) << 3) + sbo;
+      float4 r[8];
+      static_for<8>([&](auto c) {
+        constexpr uint32_t e = (((uint32_t)c & 1u) << 8) | (((uint32_t)c >> 1) << 9);
+        r[c] = lds_ld128(bs ^ (sw(e) << 3));
+      });
+      static_for<4>([&](auto pq) {
+        mw_cross(cr[4], (v2f){r[2 * pq].x, r[2 * pq].y}, (v2f){r[2 * pq + 1].x, r[2 * pq + 1].y});
+        mw_cross(cr[4], (v2f){r[2 * pq].z, r[2 * pq].w}, (v2f){r[2 * pq + 1].z, r[2 * pq + 1].w});
+      });
     }
   }
-  float full[37];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) full[k] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    full[12 + 3 * k] = cri[k].x;
-    full[12 + 3 * k + 1] = cri[k].y;
-    full[12 + 3 * k + 2] = zz[k];
+  // ---- one reduction and one row per workgroup ----
+  // first read: [0..23] cross terms of local bit b at 2b, 2b+1; [24..35] signed populations of
+  // local bits 0..11; [36] total; [37..40] total signed by bit j of the tile's index in the walk.
+  // later reads: [0..15] cross terms of new bit k at 2k, 2k+1.
+  constexpr int NB = FIRST ? 12 : 8, NV = FIRST ? 41 : 16;
+  float red_v[NV];
+  static_for<NB>([&](auto k) { red_v[2 * k] = cr[k].x; red_v[2 * k + 1] = cr[k].y; });
+  if (FIRST) {
+    red_v[24] = zin[0];
+    static_for<8>([&](auto k) { red_v[25 + k] = ((tid >> k) & 1u) ? -tot : tot; });
+    red_v[33] = zin[1]; red_v[34] = zin[2]; red_v[35] = zin[3];
+    red_v[36] = tot;
+    static_for<4>([&](auto j) { red_v[37 + j] = zw[j]; });
   }
-  full[36] = tot;
-  const int lane = tid & (kWave - 1), w = tid / kWave;
-  const float mine = wave_reduce_scatter<37>(full);
-  if (lane < 37) red[w * 37 + lane] = mine;
+  wave_sums_dpp63(red_v);
+  __syncthreads();  // every gather has been read: the tile becomes scratch
+  float *red = reinterpret_cast<float *>(smem4);
+  const uint32_t lane = tid & (kWave - 1), w = tid / kWave;
+  if (lane == kWave - 1) static_for<NV>([&](auto k) { red[w * NV + k] = red_v[k]; });
   __syncthreads();
-  if (tid < 37) {
-    float v = 0.f;
-    for (int i = 0; i < kMwThreads / kWave; ++i) v += red[i * 37 + tid];
-    a.partial[((size_t)b * gridDim.x + blockIdx.x) * kMwRow + tid] = v;
+  if (tid < NV) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMwThreads / kWave; ++i) s += red[i * NV + tid];
+    a.rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (FIRST ? kMwRowFirst : kMwRowLater) + tid] = s;
   }
 }
+// Two entry points, because the occupancy that suits them differs: the later reads are bound by
+// HBM alone and want every workgroup the LDS admits (5 per CU); the first read carries twice the
+// arithmetic and runs FASTER at 4 workgroups per CU (0.33 vs 0.42 ms at n = 28, same
+// instructions -- five workgroups of it fight over the vector pipe and the LDS between barriers).
+template <bool NT>
+__global__ void __launch_bounds__(kMwThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_mw_read_first(const MwReadArgs a) {
+  extern __shared__ float4 smem4[];
+  mw_read_body<true, NT>(a, smem4);
+}
+template <bool NT>
+__global__ void __launch_bounds__(kMwThreads) k_mw_read_later(const MwReadArgs a) {
+  extern __shared__ float4 smem4[];
+  mw_read_body<false, NT>(a, smem4);
+}
 
-// purity of one wire from the per-tile rows: one block per (state, bit)
+// Where the sums of bit position p come from: which later read (0 = the first read) and column.
+struct MwPlan {
+  int n_later;
+  int lo[8], lo2[8], q[8];   // later reads
+  int q_first;
+  int src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];
+  uint32_t rows_first, rows_later[8];
+};
+
+// purity of one wire from the per-workgroup rows: one block per (state, bit position)
+struct MwPurityArgs {
+  const float *first;       // [batch][rows_first][kMwRowFirst]
+  const float *later[8];    // [batch][rows_later[r]][kMwRowLater]
+  uint32_t rows_first, rows_later[8];
+  int q_first, n;
+  int8_t src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];
+};
 __global__ void __launch_bounds__(1024)
-k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_passes, int batch,
-                 int rows_later /* rows per state of the passes after the first */,
-                 int rows_first /* rows per state of the first pass */,
-                 float *__restrict__ pur_out /* [batch][n] by bit position */) {
+k_mw_purity(const MwPurityArgs a, float *__restrict__ pur_out /* [batch][n] by bit position */) {
   __shared__ double red[16];
   const int b = blockIdx.x, p = blockIdx.y;
-  const size_t pass_stride = (size_t)batch * n_tiles * kMwRow;
-  // chunk k covers bits [L + k*(T-L), ...); the last chunk is shifted down to stay full
-  int pass = 0, local = p;
-  if (p >= kMwL) {
-    pass = (p - kMwL) / (kMwT - kMwL);
-    local = kMwL + (p - kMwL) % (kMwT - kMwL);
-    if (pass == n_passes - 1 && n > kMwT) local = kMwL + (p - (n - (kMwT - kMwL)));
-  }
-  const int rows = pass == 0 ? rows_first : rows_later;
-  const float *pp = partial + pass * pass_stride + (size_t)b * rows * kMwRow;
+  const float *fr = a.first + (size_t)b * a.rows_first * kMwRowFirst;
   double cr = 0, ci = 0, z = 0, tot = 0;
-  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
-    const float *row = pp + (size_t)i * kMwRow;
-    cr += row[3 * local]; ci += row[3 * local + 1]; z += row[3 * local + 2]; tot += row[36];
+  for (uint32_t i = threadIdx.x; i < a.rows_first; i += blockDim.x) {
+    const float *row = fr + (size_t)i * kMwRowFirst;
+    const float t = row[36];
+    tot += t;
+    if (p < kMwT) { cr += row[2 * p]; ci += row[2 * p + 1]; z += row[24 + p]; }
+    else if (p < kMwT + a.q_first) z += row[37 + p - kMwT];
+    else z += ((i >> (p - kMwT - a.q_first)) & 1u) ? -(double)t : (double)t;
+  }
+  if (p >= kMwT) {
+    const int r = a.src_read[p] - 1, col = a.src_col[p];
+    const float *lr = a.later[r] + (size_t)b * a.rows_later[r] * kMwRowLater;
+    for (uint32_t i = threadIdx.x; i < a.rows_later[r]; i += blockDim.x) {
+      cr += lr[(size_t)i * kMwRowLater + 2 * col];
+      ci += lr[(size_t)i * kMwRowLater + 2 * col + 1];
+    }
   }
   cr = block_sum_d(cr, red);
   ci = block_sum_d(ci, red);
@@ -3721,7 +3596,7 @@ k_mw_tile_purity(const float *__restrict__ partial, int n, int n_tiles, int n_pa
   tot = block_sum_d(tot, red);
   if (threadIdx.x == 0) {
     const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
-    pur_out[(size_t)b * n + p] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
+    pur_out[(size_t)b * a.n + p] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
   }
 }
 
@@ -5561,18 +5436,71 @@ int qmle_expval_parity(const void *d_states, int n_qubits, int batch, const uint
   return QMLE_OK;
 }
 
-static int mw_passes(int n) { return n <= kMwT ? 1 : (n - kMwL + (kMwT - kMwL) - 1) / (kMwT - kMwL); }
+// Plan of the reads for an n-qubit state (host only).  Positions >= 12 are cut into 4-bit chunks
+// [12,16), [16,20), ... with the last one aligned to the top [n-4, n); a later read takes two
+// chunks, paired outermost with innermost -- at n = 28: {12-15, 24-27} and {16-19, 20-23}, the
+// pairs that stream fastest (see the note above k_mw_read).  An odd chunk is paired with a
+// lower, already reported one.  A chunk may overlap its neighbour (n not a multiple of 4): every
+// position takes its sums from the first read that reports it.
+static MwPlan mw_plan(int n, int batch) {
+  MwPlan pl;
+  std::memset(&pl, 0, sizeof(pl));
+  for (int p = 0; p < n; ++p) pl.src_read[p] = -1;
+  for (int p = 0; p < kMwT && p < n; ++p) { pl.src_read[p] = 0; pl.src_col[p] = p; }
+  const uint32_t tiles = 1u << (n - kMwT);
+  // tiles per workgroup: the first read keeps ~40 sums per work item, a long walk amortises its
+  // reduction (2^4); the later reads stream best at 2^2 (tools/mw_tune.hip); never fewer than
+  // ~2048 workgroups per launch
+  auto pick_q = [&](int want) {
+    int q = 0;
+    while (q < want && (((uint64_t)batch * tiles) >> (q + 1)) >= 2048) ++q;
+    return q;
+  };
+  static const int q_env = std::getenv("QMLE_MW_Q") ? atoi(std::getenv("QMLE_MW_Q")) : -1;
+  pl.q_first = pick_q(4);
+  if (q_env >= 0 && q_env <= 4 && (tiles >> q_env) >= 1) pl.q_first = q_env;
+  pl.rows_first = tiles >> pl.q_first;
+  int chunks[8], nc = 0;
+  for (int c = kMwT; c < n; c += 4) chunks[nc++] = c + 4 <= n ? c : n - 4;
+  int i = 0, j = nc - 1;
+  while (i <= j) {
+    int a = chunks[i], b = i < j ? chunks[j] : -1;
+    if (b < 0) {  // odd one out: pair it with a lower, already reported chunk
+      b = a;
+      a = b >= 16 ? 8 : b - 4;
+    }
+    if (a > b) std::swap(a, b);
+    if (b < a + 4) a = b - 4;  // overlapping chunks (n not a multiple of 4): shift the lower one down
+    const int r = pl.n_later++;
+    pl.lo[r] = a;
+    pl.lo2[r] = b;
+    pl.q[r] = pick_q(2);
+    if (q_env >= 0 && q_env <= 4 && (tiles >> q_env) >= 1) pl.q[r] = q_env < 2 ? q_env : 2;
+    pl.rows_later[r] = tiles >> pl.q[r];
+    for (int k = 0; k < 8; ++k) {
+      const int p = k < 4 ? a + k : b + k - 4;
+      if (p < n && pl.src_read[p] < 0) { pl.src_read[p] = r + 1; pl.src_col[p] = k; }
+    }
+    ++i;
+    --j;
+  }
+  return pl;
+}
 
 int qmle_meyer_wallach_reads(int n_qubits) {
   if (n_qubits < 1 || n_qubits > QMLE_MAX_QUBITS) return 0;
-  return n_qubits >= kMwT ? mw_passes(n_qubits) : n_qubits;  // below the tile size: one (cached) sweep per wire
+  // below the tile size: one (cache-resident) sweep per wire
+  return n_qubits >= kMwT ? 1 + mw_plan(n_qubits, 1).n_later : n_qubits;
 }
 
 size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch) {
   if (n_qubits < 1 || batch < 1) return 0;
-  if (n_qubits >= kMwT)
-    return ((size_t)mw_passes(n_qubits) * batch * ((size_t)1 << (n_qubits - kMwT)) * kMwRow +
-            (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) + 256;
+  if (n_qubits >= kMwT) {
+    const MwPlan pl = mw_plan(n_qubits, batch);
+    size_t fl = (size_t)pl.rows_first * kMwRowFirst;
+    for (int r = 0; r < pl.n_later; ++r) fl += (size_t)pl.rows_later[r] * kMwRowLater;
+    return ((size_t)batch * fl + (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) + 512;
+  }
   return (size_t)batch * n_qubits * overlap_blocks(n_qubits) * sizeof(float4) + 256;
 }
 
@@ -5586,108 +5514,68 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
     return QMLE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int n = n_qubits;
-  if (n >= kMwT) {  // LDS-staged tiles: ceil((n-4)/8) reads of the state
-    const int passes = mw_passes(n);
-    const uint32_t n_tiles = 1u << (n - kMwT);
-    const int tiles = (int)n_tiles;
-    const size_t lds = ((size_t)8 << kMwT) + ((size_t)4 << (kMwT - kMwL)) + 160 * sizeof(float);
-    // later passes: register-direct kernel, 2^mw_q tiles per workgroup (>= 2048 workgroups)
-    static const bool no_direct = std::getenv("QMLE_MW_NO_DIRECT") != nullptr;
-    int mw_rows = -1;        // k_mw_tile2: rows per pass (tiles >> q2)
-    int mw_q = -1;           // blocks of 2^14 amplitudes per workgroup = 2^mw_q; rows = blocks >> mw_q
-    const int blocks = n >= 14 ? 1 << (n - 14) : 0;
-    if (!no_direct && n >= 18) {
-      mw_q = 0;
-      while (mw_q < 3 && (((uint64_t)batch * blocks) >> (mw_q + 1)) >= 2048) ++mw_q;
+  if (n >= kMwT) {  // LDS-staged tiles: 1 + ceil((n - 12) / 8) reads of the state
+    if (first_use_on_device(5)) {
+      QMLE_LDS_BASE_CHECK(k_mw_read_first<true>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_first<false>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_later<true>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_later<false>);
     }
-    for (int p = 0; p < passes; ++p) {
-      MwArgs a;
-      std::memset(&a, 0, sizeof(a));
-      a.states = (const float2 *)d_states;
-      a.partial = (float *)d_workspace + (size_t)p * batch * tiles * kMwRow;
-      a.n = n;
-      uint32_t mask = (1u << kMwL) - 1u;
-      // high chunk p; the last chunk is shifted down so that it still holds T-L bits
-      int lo = kMwL + p * (kMwT - kMwL);
-      if (lo + (kMwT - kMwL) > n) lo = n - (kMwT - kMwL);
-      for (int i = 0; i < kMwT - kMwL; ++i) mask |= 1u << (lo + i);
-      int nt = 0, no = 0;
-      for (int bit = 0; bit < n; ++bit) {
-        if (mask & (1u << bit)) a.tile_bits[nt++] = (int8_t)bit;
-        else a.outer_bits[no++] = (int8_t)bit;
-      }
-      static const bool mw_old = std::getenv("QMLE_MW_OLD") != nullptr;
-      {  // position arrays as runs (tile = 4 low bits + one run of 8: <= 2 outer runs, <= 2 inner)
-        int r = 0;
-        for (int i = 0; i < no;) {
-          int len = 1;
-          while (i + len < no && a.outer_bits[i + len] == a.outer_bits[i] + len) ++len;
-          if (r < 4) { a.run_off[r] = (uint32_t)i; a.run_mask[r] = (1u << len) - 1u; a.run_pos[r] = (uint32_t)a.outer_bits[i]; }
-          ++r;
-          i += len;
-        }
-        a.n_runs = r;
-        int q = 0;
-        for (int j = 0; j <= kMwT - 4;) {
-          int len = 1;
-          while (j + len <= kMwT - 4 && a.tile_bits[j + len] == a.tile_bits[j] + len) ++len;
-          if (q < 3) { a.in_off[q] = (uint32_t)j; a.in_mask[q] = (1u << len) - 1u; a.in_pos[q] = (uint32_t)a.tile_bits[j]; }
-          ++q;
-          j += len;
-        }
-        a.n_in_runs = q;
-        for (unsigned u = 0; u < 8; ++u)
-          a.uo8[u] = (((u & 1u) << a.tile_bits[kMwT - 3]) | (((u >> 1) & 1u) << a.tile_bits[kMwT - 2]) |
-                      (((u >> 2) & 1u) << a.tile_bits[kMwT - 1])) << 3;
-        if (r > 4 || q > 3) return QMLE_ERR_UNSUPPORTED;  // cannot happen with this tile shape
-      }
-      if (!mw_old && n <= 28) {  // k_mw_tile2: 32-bit byte offsets inside one state
-        // >= 1 GiB per launch: stream past the caches
-        const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
-        const size_t lds2 = (size_t)8 << kMwT;
-        // 2^q2 tiles per workgroup: >= ~4 workgroups per CU-slot left (at n = 28: 16 tiles each)
-        int q2 = 0;
-        while (q2 < 4 && (((uint64_t)batch * tiles) >> (q2 + 1)) >= 4096) ++q2;
-        static const int q_env = std::getenv("QMLE_MW_Q") ? atoi(std::getenv("QMLE_MW_Q")) : -1;
-        if (q_env >= 0 && (tiles >> q_env) >= 1) q2 = q_env;
-        mw_q = -1;
-        mw_rows = tiles >> q2;
-        const dim3 grid2(tiles >> q2, batch);
-        if (p == 0) {
-          if (nt) hipLaunchKernelGGL((k_mw_tile2<true, true>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
-          else hipLaunchKernelGGL((k_mw_tile2<true, false>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
-        } else {
-          if (nt) hipLaunchKernelGGL((k_mw_tile2<false, true>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
-          else hipLaunchKernelGGL((k_mw_tile2<false, false>), grid2, dim3(kMwThreads), lds2, stream, a, q2);
-        }
-        continue;
-      }
-      if (p == 0)
-        hipLaunchKernelGGL(k_mw_tile<true>, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
-      else if (mw_q >= 0) {
-        MwDirectArgs da;
-        std::memset(&da, 0, sizeof(da));
-        da.states = a.states;
-        da.partial = a.partial;
-        da.n = n;
-        uint32_t used = 63u;
-        for (int i = 0; i < 8; ++i) {
-          da.hi[i] = a.tile_bits[kMwL + i];
-          used |= 1u << da.hi[i];
-        }
-        int no2 = 0;
-        for (int bit = 6; bit < n; ++bit)
-          if (!(used & (1u << bit))) da.outer[no2++] = (int8_t)bit;
-        hipLaunchKernelGGL(k_mw_direct, dim3(blocks >> mw_q, batch), dim3(kMwThreads), 0, stream, da, mw_q);
-      }
-      else
-        hipLaunchKernelGGL(k_mw_tile<false>, dim3(tiles, batch), dim3(kMwThreads), lds, stream, a, n_tiles);
+    const MwPlan pl = mw_plan(n, batch);
+    for (int p = 0; p < n; ++p)
+      if (pl.src_read[p] < 0) return QMLE_ERR_INTERNAL;
+    const uint32_t tiles = 1u << (n - kMwT);
+    // >= 1 GiB per launch: stream past the caches
+    const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
+    const size_t lds = (size_t)8 << kMwT;
+    MwPurityArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    float *ws = (float *)d_workspace;
+    MwReadArgs a;
+    a.states = (const float2 *)d_states;
+    a.n = n;
+    a.rows = ws;
+    a.lo = 4;
+    a.lo2 = 8;
+    a.q = pl.q_first;
+    pa.first = ws;
+    pa.rows_first = pl.rows_first;
+    pa.q_first = pl.q_first;
+    pa.n = n;
+    ws += (size_t)batch * pl.rows_first * kMwRowFirst;
+    // The reads are independent of each other.  The first read is the arithmetic-heavy one (192
+    // packed fmas + the population butterfly per 16 amplitudes) and is the one that suffers when
+    // it starts on a chip that has just idled through the tiny reduction kernels of a previous
+    // call (0.33 ms warm, 0.42 - 0.47 ms cold at n = 28); the later reads are bound by HBM
+    // alone.  So it runs LAST (QMLE_MW_FIRST_FIRST=1 for the A/B).
+    static const bool first_first = std::getenv("QMLE_MW_FIRST_FIRST") != nullptr;
+    auto launch_first = [&]() {
+      const dim3 grid(tiles >> a.q, batch);
+      if (nt) hipLaunchKernelGGL(k_mw_read_first<true>, grid, dim3(kMwThreads), lds, stream, a);
+      else hipLaunchKernelGGL(k_mw_read_first<false>, grid, dim3(kMwThreads), lds, stream, a);
+    };
+    const MwReadArgs a_first = a;
+    if (first_first || pl.n_later == 0) launch_first();
+    for (int r = 0; r < pl.n_later; ++r) {
+      a.rows = ws;
+      a.lo = pl.lo[r];
+      a.lo2 = pl.lo2[r];
+      a.q = pl.q[r];
+      pa.later[r] = ws;
+      pa.rows_later[r] = pl.rows_later[r];
+      ws += (size_t)batch * pl.rows_later[r] * kMwRowLater;
+      const dim3 grid(tiles >> a.q, batch);
+      if (nt) hipLaunchKernelGGL(k_mw_read_later<true>, grid, dim3(kMwThreads), lds, stream, a);
+      else hipLaunchKernelGGL(k_mw_read_later<false>, grid, dim3(kMwThreads), lds, stream, a);
     }
-    float *d_pur = (float *)d_workspace + (size_t)passes * batch * tiles * kMwRow;
-    hipLaunchKernelGGL(k_mw_tile_purity, dim3(batch, n), dim3(tiles >= 1024 ? 1024 : 64), 0,
-                       stream, (const float *)d_workspace, n, tiles, passes, batch,
-                       mw_rows >= 0 ? mw_rows : mw_q >= 0 ? blocks >> mw_q : tiles,
-                       mw_rows >= 0 ? mw_rows : tiles, d_pur);
+    if (!first_first && pl.n_later > 0) {
+      a = a_first;
+      launch_first();
+    }
+    for (int p = 0; p < n; ++p) { pa.src_read[p] = (int8_t)pl.src_read[p]; pa.src_col[p] = (int8_t)pl.src_col[p]; }
+    float *d_pur = ws;
+    hipLaunchKernelGGL(k_mw_purity, dim3(batch, n), dim3(pl.rows_first >= 1024 ? 1024 : pl.rows_first >= 256 ? 256 : 64),
+                       0, stream, pa, d_pur);
     hipLaunchKernelGGL(k_mw_tile_q, dim3((batch + 63) / 64), dim3(64), 0, stream,
                        (const float *)d_pur, n, batch, d_out, d_purities);
     HIPCHK(hipGetLastError());

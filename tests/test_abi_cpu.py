@@ -174,6 +174,18 @@ def test_xor_addressed_tile_kernels_have_no_static_lds():
     assert N.lib().qmle_status_string(-12).decode().startswith("internal invariant")
 
 
+def test_meyer_wallach_read_count():
+    """Host only: reads of the state per Meyer-Wallach call (bench.py's bytes-moved accounting):
+    one cache-resident sweep per wire below the tile size, then 1 + ceil((n - 12) / 8)."""
+    lib = N.lib()
+    assert [lib.qmle_meyer_wallach_reads(n) for n in (1, 4, 11)] == [1, 4, 11]
+    assert [lib.qmle_meyer_wallach_reads(n) for n in (12, 13, 16, 20, 21, 24, 28, 29, 32)] == \
+        [1, 2, 2, 2, 3, 3, 3, 4, 4]
+    assert lib.qmle_meyer_wallach_reads(0) == 0 and lib.qmle_meyer_wallach_reads(33) == 0
+    for n in range(12, 33):   # rows of every read + the purities fit the advertised workspace
+        assert lib.qmle_meyer_wallach_workspace_bytes(n, 1) >= (1 << (n - 12)) // 16 * 48 * 4
+
+
 def test_known_zero_tracking_and_kernel_choice_of_the_k2_plan():
     """Plan compiler, host only: the K2 plan (one HE layer at n = 24, <Z> on every wire) after
     observable folding -- ready gates are scheduled low bits first, every stage knows which bit

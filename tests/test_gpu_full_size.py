@@ -307,8 +307,10 @@ def test_fast_tile_kernel_equals_generic_kernel_on_cx_rich_tapes():
 
 
 def test_n29_falls_back_to_64_bit_addressing():
-    """n = 29 (4 GiB per state): the fast tile kernel and k_mw_tile2 address a tile with 32-bit
-    byte offsets, valid up to n = 28; beyond that the generic kernels must take over.  Product
+    """n = 29 (4 GiB per state): the fast tile kernel addresses a tile with 32-bit byte
+    offsets, valid up to n = 28; beyond that the generic kernels must take over (the Meyer-Wallach
+    read kernels use 64-bit offsets and take a fourth read: chunks {12-15, 25-28}, {16-19, 24-27},
+    {8-11, 20-23}).  Product
     state through the fused tile passes: <Z_w> = cos(theta_w) on every wire, Meyer-Wallach 0."""
     N = _N()
     n = 29

@@ -217,18 +217,25 @@ def test_large_state_direct_and_tiled_agree_n22():
     assert float((e1 - e2).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("n", [12, 13, 17, 21])
+@pytest.mark.parametrize("n", list(range(12, 25)))
 def test_meyer_wallach_lds_tile_path(n):
-    """n >= 12 takes the LDS-staged tile kernel (ceil((n-4)/8) reads): every wire's purity
-    against the oracle, including the shifted last chunk (n = 13, 17, 21)."""
+    """n >= 12 takes the LDS-staged read kernels (1 + ceil((n-12)/8) reads): every wire's purity
+    against the oracle for EVERY size from 12 to 24 -- one read (12), one later read with an
+    already reported lower chunk (13..16), overlapping chunks (17..19, 21..23), the outermost /
+    innermost pairing and the odd chunk (21..24)."""
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n)
-    B = 3
+    B = 3 if n <= 18 else 1
+    assert N.mw_reads(n) == 1 + (n - 12 + 7) // 8
     st = rng.normal(size=(B, 2**n)) + 1j * rng.normal(size=(B, 2**n))
     st /= np.linalg.norm(st, axis=1, keepdims=True)
     # make it less uniform: entangle-ish structure via a phase ramp and amplitude decay
     st *= np.exp(-np.arange(2**n) / 2**n)[None, :]
+    # ... and wire-dependent: a few controlled sign flips / swaps of halves
+    idx = np.arange(2**n)
+    for k in range(0, n, 3):
+        st[:, (idx >> k) & 1 == 1] *= (1.0 + 0.15 * k)
     st /= np.linalg.norm(st, axis=1, keepdims=True)
     dev = torch.from_numpy(st.astype(np.complex64)).cuda()
     q, pur = N.meyer_wallach(dev, return_purities=True)

@@ -1,0 +1,463 @@
+// Meyer-Wallach read kernels, stand-alone tuning bench (round 3).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -structurizecfg-skip-uniform-regions=true \
+//         tools/mw_tune.hip -o tools/mw_tune && tools/mw_tune 28
+// One "read" streams the whole 2^n state once through 2^12-amplitude LDS tiles (4 contiguous low
+// bits + 8 bits starting at `lo`) and reports the cross terms c_j = sum_{bit_j = 0} psi_i
+// conj(psi_{i + 2^j}) of the tile's NEW bits; the first read (lo = 4: the tile is 32 KiB of
+// contiguous memory) also reports the signed populations of its 12 bits and the per-row totals
+// from which the populations of every other bit follow.  Variants are timed against a bare
+// tile walk of the same access pattern; results are checked against a CPU sum at n = 20.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef u64 __attribute__((address_space(3))) lds_u64_t;
+typedef vf4 __attribute__((address_space(3))) lds_f4_t;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+template <bool NT> __device__ __forceinline__ vf4 ld4(const void *p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+  return *reinterpret_cast<const vf4 *>(p);
+}
+__device__ __forceinline__ void lds_st128(uint32_t byte, vf4 v) { *(lds_f4_t *)(uintptr_t)byte = v; }
+__device__ __forceinline__ vf4 lds_ld128(uint32_t byte) { return *(const lds_f4_t *)(uintptr_t)byte; }
+__device__ __forceinline__ v2f lds_ld64(uint32_t byte) {
+  const u64 x = *(const lds_u64_t *)(uintptr_t)byte;
+  return (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+}
+__device__ __host__ __forceinline__ constexpr uint32_t sw(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }
+__device__ __forceinline__ uint32_t ins0(uint32_t i, int p) { return ((i >> p) << (p + 1)) | (i & ((1u << p) - 1u)); }
+
+__device__ __forceinline__ void wave_sum4_dpp63(float &a, float &b, float &c, float &d) {
+#define DPP4(ctrl)                                                                     \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\t"          \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+  asm volatile("s_nop 1\n\t" DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                   DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                       DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                           DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                               DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                                   DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef DPP4
+}
+template <int N> __device__ __forceinline__ void wave_sums_dpp63(float (&v)[N]) {
+  float pad = 0.f;
+  static_for<(N + 3) / 4>([&](auto jj) {
+    constexpr int j = 4 * (int)jj;
+    wave_sum4_dpp63(v[j], j + 1 < N ? v[j + 1] : pad, j + 2 < N ? v[j + 2] : pad, j + 3 < N ? v[j + 3] : pad);
+  });
+}
+
+// x * conj(y) accumulated into (re, im): two packed fmas
+__device__ __forceinline__ void cross_acc(v2f &s, v2f x, v2f y) {
+  s = __builtin_elementwise_fma(x, y.xx, s);
+  s = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, s);
+}
+
+constexpr int kT = 12, kThreads = 256;
+constexpr int kRowFirst = 48, kRowLater = 16;
+
+struct ReadArgs {
+  const float2 *state;
+  float *rows;   // [n_rows][kRowFirst | kRowLater]
+  int n, lo, q;  // tile = bits 0..3 + lo..lo+3 + lo2..lo2+3; 2^q tiles per workgroup
+  int lo2;       // lo + 4 for one run of 8 bits
+  int hiwalk;    // 1: a workgroup walks tiles 2^(n-12-q) apart (neighbouring workgroups read neighbouring tiles)
+};
+
+// byte offset of tile `t`: outer bits [4, lo) from the low bits of t, then [lo+4, lo2), then [lo2+4, n)
+__device__ __forceinline__ uint64_t tile_base_bytes(uint32_t t, int lo, int lo2) {
+  const uint32_t r0 = lo - 4, r1 = lo2 - lo - 4;
+  const uint64_t a = (uint64_t)(t & ((1u << r0) - 1u)) << 4 |
+                     (uint64_t)((t >> r0) & ((1u << r1) - 1u)) << (lo + 4) |
+                     (uint64_t)(t >> (r0 + r1)) << (lo2 + 4);
+  return a << 3;
+}
+
+// WORK: 0 = loads + one add per float4 (bare walk), 1 = + LDS staging and barriers, 2 = everything,
+// 3 = everything but the population butterfly, 4 = everything but gather B (timing only)
+template <bool FIRST, bool PREFETCH, bool NT, int WORK>
+__global__ void __launch_bounds__(kThreads) k_mw_read(const ReadArgs a) {
+  extern __shared__ float4 smem4[];
+  const uint32_t sbo = (uint32_t)(uintptr_t)smem4;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t jl = 2u * tid;  // local bits 1..8 from tid; 9..11 from u; bit 0 inside the float4
+  const int lo = a.lo, lo2 = a.lo2;
+  // in-tile byte offset of the lane's first float4 and of step u (wave-uniform)
+  const uint32_t goff = ((jl & 15u) | (((jl >> 4) & 15u) << lo) | ((jl >> 8) << lo2)) << 3;
+  const uint32_t ustep = 1u << (lo2 + 1 + 3);  // local bit 9 = second run's bit 1
+  const char *st = reinterpret_cast<const char *>(a.state);
+  const uint32_t slb = (sw(jl) << 3) + sbo;   // staging address of u = 0; u adds u << 12
+  const uint32_t n_it = 1u << a.q;
+  const uint32_t tile0 = a.hiwalk ? blockIdx.x : blockIdx.x << a.q;
+  const uint32_t tstep = a.hiwalk ? gridDim.x : 1u;
+
+  constexpr int NB = FIRST ? 12 : 8;           // reported bits
+  v2f cr[NB];
+  static_for<NB>([&](auto k) { cr[k] = (v2f){0.f, 0.f}; });
+  float zin[4] = {0.f, 0.f, 0.f, 0.f}, tot = 0.f, zw[4] = {0.f, 0.f, 0.f, 0.f};
+  float dummy = 0.f;
+
+  vf4 v[8];
+  auto issue = [&](uint32_t t) {
+    const char *p = st + tile_base_bytes(t, lo, lo2) + goff;
+    static_for<8>([&](auto u) { v[u] = ld4<NT>(p + (size_t)u * ustep); });
+  };
+  issue(tile0);
+  for (uint32_t it = 0; it < n_it; ++it) {
+    if (!PREFETCH && it) issue(tile0 + it * tstep);
+    if (WORK == 0) {
+      static_for<8>([&](auto u) { dummy += v[u].x + v[u].w; });
+      if (PREFETCH && it + 1 < n_it) issue(tile0 + (it + 1) * tstep);
+      continue;
+    }
+    // ---- bits held by the lane's own 8 float4: local 0 (halves of a float4) and 9, 10, 11 (u) ----
+    if (WORK >= 2) {
+      if (FIRST) {
+        static_for<8>([&](auto u) { cross_acc(cr[0], v[u].xy, v[u].zw); });
+        if (WORK != 3) {
+        float pr[16];
+        static_for<8>([&](auto u) {
+          const v2f q0 = v[u].xy * v[u].xy, q1 = v[u].zw * v[u].zw;
+          pr[2 * u] = q0.x + q0.y;
+          pr[2 * u + 1] = q1.x + q1.y;
+        });
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, s1[8], s2[4], s3[2];
+        static_for<8>([&](auto i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; });
+        static_for<4>([&](auto i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; });
+        static_for<2>([&](auto i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; });
+        zin[0] += h0; zin[1] += h1; zin[2] += h2; zin[3] += s3[0] - s3[1];
+        const float tt = s3[0] + s3[1];
+        tot += tt;
+        static_for<4>([&](auto j) {
+          zw[j] += __uint_as_float(__float_as_uint(tt) ^ (((it >> j) & 1u) << 31));
+        });
+        }
+      }
+      static_for<3>([&](auto k) {
+        constexpr int B = FIRST ? 9 + (int)k : 5 + (int)k;  // index into cr[]: local bit 9+k (later reads: new bit 5+k)
+        static_for<4>([&](auto pq) {
+          constexpr int lowm = (1 << k) - 1;
+          constexpr int u0 = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+          cross_acc(cr[B], v[u0].xy, v[u0 | (1 << k)].xy);
+          cross_acc(cr[B], v[u0].zw, v[u0 | (1 << k)].zw);
+        });
+      });
+    }
+    if (it) __syncthreads();  // previous tile's gathers done
+    static_for<8>([&](auto u) { lds_st128(slb + ((uint32_t)u << 12), v[u]); });
+    __syncthreads();
+    if (PREFETCH && it + 1 < n_it) issue(tile0 + (it + 1) * tstep);
+    if (WORK >= 2) {
+      uint32_t tg = tid;
+      asm volatile("" : "+v"(tg));  // keep the gather addresses out of loop-carried registers
+      // gather A: 16 amplitudes over local bits gA .. gA+3 (first read: 1..4, later: 4..7)
+      constexpr int gA = FIRST ? 1 : 4;
+      {
+        const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, gA), gA + 1), gA + 2), gA + 3)) << 3) + sbo;
+        v2f r[16];
+        static_for<16>([&](auto c) { r[c] = lds_ld64(bs ^ (sw((uint32_t)c << gA) << 3)); });
+        static_for<4>([&](auto t) {
+          constexpr int B = FIRST ? gA + (int)t : (int)t;
+          static_for<8>([&](auto pq) {
+            constexpr int lowm = (1 << t) - 1;
+            constexpr int c = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+            cross_acc(cr[B], r[c], r[c | (1 << t)]);
+          });
+        });
+      }
+      if (FIRST && WORK == 4) {
+      } else if (FIRST) {  // gather B: local bits 5..8
+        constexpr int gB = 5;
+        const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, gB), gB + 1), gB + 2), gB + 3)) << 3) + sbo;
+        v2f r[16];
+        static_for<16>([&](auto c) { r[c] = lds_ld64(bs ^ (sw((uint32_t)c << gB) << 3)); });
+        static_for<4>([&](auto t) {
+          constexpr int B = gB + (int)t;
+          static_for<8>([&](auto pq) {
+            constexpr int lowm = (1 << t) - 1;
+            constexpr int c = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+            cross_acc(cr[B], r[c], r[c | (1 << t)]);
+          });
+        });
+      } else {  // local bit 8 alone: 8 float4 over local bits {0, 8, 9, 10}; thread index -> 1..7, 11
+        const uint32_t e0 = ((tg & 127u) << 1) | ((tg >> 7) << 11);
+        const uint32_t bs = (sw(e0) << 3) + sbo;
+        vf4 r[8];
+        static_for<8>([&](auto c) {
+          constexpr uint32_t e = (((uint32_t)c & 1u) << 8) | (((uint32_t)c >> 1) << 9);
+          r[c] = lds_ld128(bs ^ (sw(e) << 3));
+        });
+        static_for<4>([&](auto pq) {
+          cross_acc(cr[4], r[2 * pq].xy, r[2 * pq + 1].xy);
+          cross_acc(cr[4], r[2 * pq].zw, r[2 * pq + 1].zw);
+        });
+      }
+    }
+  }
+  if (WORK == 0) {
+    if (dummy == 123.456f) a.rows[0] = dummy;
+    return;
+  }
+  // ---- one reduction per workgroup ----
+  constexpr int NV = FIRST ? 41 : 16;
+  float red_v[NV];
+  static_for<NB>([&](auto k) { red_v[2 * k] = cr[k].x; red_v[2 * k + 1] = cr[k].y; });
+  if (FIRST) {
+    // row: [0..23] cross terms of local bit b at 2b, 2b+1; [24..35] signed populations of local
+    // bits 0..11; [36] total; [37..40] total signed by bit j of the tile's index in the walk
+    red_v[24] = zin[0];
+    static_for<8>([&](auto k) { red_v[25 + k] = ((tid >> k) & 1u) ? -tot : tot; });
+    red_v[33] = zin[1]; red_v[34] = zin[2]; red_v[35] = zin[3];
+    red_v[36] = tot;
+    static_for<4>([&](auto j) { red_v[37 + j] = zw[j]; });
+  }
+  wave_sums_dpp63(red_v);
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem4);
+  const uint32_t lane = tid & 63u, w = tid >> 6;
+  if (lane == 63) static_for<NV>([&](auto k) { red[w * NV + k] = red_v[k]; });
+  __syncthreads();
+  if (tid < NV) {
+    const float s = red[tid] + red[NV + tid] + red[2 * NV + tid] + red[3 * NV + tid];
+    a.rows[(size_t)blockIdx.x * (FIRST ? kRowFirst : kRowLater) + tid] = s;
+  }
+}
+
+__global__ void k_init(float2 *s, uint64_t count, float scale) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint64_t x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+  const float re = ((int)(x & 0xffff) - 32768) / 32768.f, im = ((int)((x >> 16) & 0xffff) - 32768) / 32768.f;
+  // a smooth envelope so that populations and cross terms differ from bit to bit
+  const float env = 1.f + 0.5f * __sinf((float)(i & 0xfffff) * 1e-5f) + 0.25f * ((i >> 7) & 1) + 0.125f * ((i >> 19) & 1);
+  s[i] = make_float2(re * env * scale, (0.3f + im) * env * scale);
+}
+
+template <bool FIRST, bool PF, bool NT, int WORK>
+static float run(const ReadArgs &a, int reps, const char *label) {
+  const uint32_t tiles = 1u << (a.n - kT);
+  const dim3 grid(tiles >> a.q);
+  const size_t lds = (size_t)8 << kT;
+  CK(hipFuncSetAttribute((const void *)k_mw_read<FIRST, PF, NT, WORK>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_mw_read<FIRST, PF, NT, WORK>), grid, dim3(kThreads), lds, 0, a);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_mw_read<FIRST, PF, NT, WORK>), grid, dim3(kThreads), lds, 0, a);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double gb = 8.0 * std::ldexp(1.0, a.n) / 1e9;
+  if (label)
+    printf("%-36s bits %2d-%2d,%2d-%2d q=%d hw=%d %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s\n", label, a.lo, a.lo + 3, a.lo2,
+           a.lo2 + 3, a.q, a.hiwalk, ms, gb / (ms * 1e-3), gb / (ms * 1e-3) / 8000.0);
+  fflush(stdout);
+  return ms;
+}
+
+static int check(int n) {
+  const uint64_t D = 1ull << n;
+  float2 *d;
+  CK(hipMalloc(&d, D * sizeof(float2)));
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, 0, d, D, 1.0f / std::sqrt((float)D));
+  std::vector<float2> h(D);
+  CK(hipMemcpy(h.data(), d, D * sizeof(float2), hipMemcpyDeviceToHost));
+  std::vector<double> cr(n), ci(n), z(n);
+  double tot = 0;
+  for (uint64_t i = 0; i < D; ++i) {
+    const double p = (double)h[i].x * h[i].x + (double)h[i].y * h[i].y;
+    tot += p;
+    for (int j = 0; j < n; ++j) {
+      if (i >> j & 1) { z[j] -= p; continue; }
+      z[j] += p;
+      const float2 y = h[i | (1ull << j)];
+      cr[j] += (double)h[i].x * y.x + (double)h[i].y * y.y;
+      ci[j] += (double)h[i].y * y.x - (double)h[i].x * y.y;
+    }
+  }
+  int bad = 0;
+  const int q = 2;
+  const uint32_t tiles = 1u << (n - kT), n_rows = tiles >> q;
+  float *rows;
+  CK(hipMalloc(&rows, (size_t)n_rows * kRowFirst * sizeof(float)));
+  std::vector<float> hr((size_t)n_rows * kRowFirst);
+  // first read
+  for (int pf = 0; pf < 2; ++pf) {
+    ReadArgs a{d, rows, n, 4, q, 8, 0};
+    if (pf) run<true, true, false, 2>(a, 1, nullptr); else run<true, false, false, 2>(a, 1, nullptr);
+    CK(hipMemcpy(hr.data(), rows, hr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<double> gcr(n), gci(n), gz(n);
+    double gtot = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) {
+      const float *row = &hr[(size_t)r * kRowFirst];
+      for (int b = 0; b < 12; ++b) { gcr[b] += row[2 * b]; gci[b] += row[2 * b + 1]; gz[b] += row[24 + b]; }
+      gtot += row[36];
+      for (int j = 0; j < q; ++j) gz[12 + j] += row[37 + j];
+      for (int j = 12 + q; j < n; ++j) gz[j] += ((r >> (j - 12 - q)) & 1) ? -row[36] : row[36];
+    }
+    for (int b = 0; b < n; ++b) {
+      if (std::fabs(gz[b] - z[b]) > 5e-6) { printf("first pf=%d z[%d] %g vs %g\n", pf, b, gz[b], z[b]); ++bad; }
+      if (b < 12 && (std::fabs(gcr[b] - cr[b]) > 5e-6 || std::fabs(gci[b] - ci[b]) > 5e-6)) {
+        printf("first pf=%d c[%d] (%g, %g) vs (%g, %g)\n", pf, b, gcr[b], gci[b], cr[b], ci[b]); ++bad;
+      }
+    }
+    if (std::fabs(gtot - tot) > 5e-6) { printf("first tot %g vs %g\n", gtot, tot); ++bad; }
+  }
+  // later reads: one run of 8 bits, and two runs of 4
+  const int pairs[][2] = {{12, 16}, {n - 8, n - 4}, {12, n - 4}, {13, n - 5}};
+  for (auto &pr : pairs) {
+    const int lo = pr[0], lo2 = pr[1];
+    if (lo < 12 || lo2 < lo + 4 || lo2 + 4 > n) continue;
+    for (int pf = 0; pf < 4; ++pf) {
+      ReadArgs a{d, rows, n, lo, q, lo2, pf >> 1};
+      if (pf & 1) run<false, true, false, 2>(a, 1, nullptr); else run<false, false, false, 2>(a, 1, nullptr);
+      CK(hipMemcpy(hr.data(), rows, (size_t)n_rows * kRowLater * sizeof(float), hipMemcpyDeviceToHost));
+      for (int k = 0; k < 8; ++k) {
+        const int bit = k < 4 ? lo + k : lo2 + k - 4;
+        double r0 = 0, r1 = 0;
+        for (uint32_t r = 0; r < n_rows; ++r) { r0 += hr[(size_t)r * kRowLater + 2 * k]; r1 += hr[(size_t)r * kRowLater + 2 * k + 1]; }
+        if (std::fabs(r0 - cr[bit]) > 5e-6 || std::fabs(r1 - ci[bit]) > 5e-6) {
+          printf("later bits %d,%d variant %d c[%d] (%g, %g) vs (%g, %g)\n", lo, lo2, pf, bit, r0, r1, cr[bit], ci[bit]); ++bad;
+        }
+      }
+    }
+  }
+  printf("check n=%d: %s (tot %.9f, c[5] = %.6g %+.6gi, c[%d] = %.6g %+.6gi)\n", n, bad ? "MISMATCH" : "ok", tot, cr[5], ci[5],
+         n - 1, cr[n - 1], ci[n - 1]);
+  CK(hipFree(rows)); CK(hipFree(d));
+  return bad;
+}
+
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 28;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  if (check(20) || check(23)) return 1;
+  const uint64_t D = 1ull << n;
+  float2 *d;
+  CK(hipMalloc(&d, D * sizeof(float2)));
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, 0, d, D, 1.0f / std::sqrt((float)D));
+  float *rows;
+  CK(hipMalloc(&rows, ((size_t)1 << (n - kT)) * kRowFirst * sizeof(float)));
+  CK(hipDeviceSynchronize());
+  const int sweep = argc > 3 ? atoi(argv[3]) : 0;
+  if (sweep == 2) {  // the product's sequence: later, later, first -- per-kernel HIP-event times over `reps` rounds
+    const size_t lds = (size_t)8 << kT;
+    ReadArgs a{d, rows, n, 4, 4, 8, 0}, b{d, rows, n, 12, 2, 24, 0}, c{d, rows, n, 16, 2, 20, 0};
+    CK(hipFuncSetAttribute((const void *)k_mw_read<true, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CK(hipFuncSetAttribute((const void *)k_mw_read<false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    std::vector<hipEvent_t> ev(4 * reps);
+    for (auto &e : ev) CK(hipEventCreate(&e));
+    const uint32_t tiles = 1u << (n - kT);
+    for (int order = 0; order < 2; ++order) {
+      for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(ev[4 * r]));
+        if (order == 0) hipLaunchKernelGGL((k_mw_read<true, false, true, 2>), dim3(tiles >> a.q), dim3(kThreads), lds, 0, a);
+        else hipLaunchKernelGGL((k_mw_read<false, false, true, 2>), dim3(tiles >> b.q), dim3(kThreads), lds, 0, b);
+        CK(hipEventRecord(ev[4 * r + 1]));
+        hipLaunchKernelGGL((k_mw_read<false, false, true, 2>), dim3(tiles >> c.q), dim3(kThreads), lds, 0, c);
+        CK(hipEventRecord(ev[4 * r + 2]));
+        if (order == 0) hipLaunchKernelGGL((k_mw_read<false, false, true, 2>), dim3(tiles >> b.q), dim3(kThreads), lds, 0, b);
+        else hipLaunchKernelGGL((k_mw_read<true, false, true, 2>), dim3(tiles >> a.q), dim3(kThreads), lds, 0, a);
+        CK(hipEventRecord(ev[4 * r + 3]));
+      }
+      CK(hipDeviceSynchronize());
+      double t[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+      for (int r = 0; r < reps; ++r)
+        for (int k = 0; k < 3; ++k) {
+          float ms;
+          CK(hipEventElapsedTime(&ms, ev[4 * r + k], ev[4 * r + k + 1]));
+          t[k] += ms; if (ms > mx[k]) mx[k] = ms;
+        }
+      printf("sequence %s: %.4f / %.4f / %.4f ms avg (max %.4f / %.4f / %.4f), sum %.4f\n",
+             order == 0 ? "first, later(16,20), later(12,24)" : "later(12,24), later(16,20), first", t[0] / reps, t[1] / reps,
+             t[2] / reps, mx[0], mx[1], mx[2], (t[0] + t[1] + t[2]) / reps);
+    }
+  }
+  if (sweep == 3) {  // the product library's qmle_meyer_wallach on THIS process's buffer
+    void *h = dlopen(argc > 4 ? argv[4] : "qml-essentials_amd/libqmle_sv.so", RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    auto wsb = (size_t (*)(int, int))dlsym(h, "qmle_meyer_wallach_workspace_bytes");
+    auto mw = (int (*)(const void *, int, int, float *, float *, void *, size_t, void *))dlsym(h, "qmle_meyer_wallach");
+    const size_t wb = wsb(n, 1);
+    void *ws; float *out;
+    CK(hipMalloc(&ws, wb)); CK(hipMalloc(&out, 256));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int round = 0; round < 3; ++round) {
+      int rc = mw(d, n, 1, out, nullptr, ws, wb, nullptr);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) rc |= mw(d, n, 1, out, nullptr, ws, wb, nullptr);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      float q; CK(hipMemcpy(&q, out, 4, hipMemcpyDeviceToHost));
+      printf("libqmle_sv qmle_meyer_wallach: rc %d  Q %.6f  %.4f ms per call over %d calls\n", rc, q, ms / reps, reps);
+    }
+  }
+  if (sweep == 1) {  // sustained (thermal steady state): `reps` launches per line, the set run twice
+    for (int rep = 0; rep < 2; ++rep) {
+      ReadArgs a{d, rows, n, 4, 4, 8, 0};
+      run<true, false, true, 0>(a, reps, "first  bare loads        nt");
+      run<true, false, true, 1>(a, reps, "first  + staging         nt");
+      run<true, false, true, 4>(a, reps, "first  no gather B       nt");
+      run<true, false, true, 3>(a, reps, "first  no populations    nt");
+      run<true, false, true, 2>(a, reps, "first  full              nt");
+      ReadArgs b{d, rows, n, 12, 2, 24, 0};
+      run<false, false, true, 0>(b, reps, "later  bare loads        nt");
+      run<false, false, true, 1>(b, reps, "later  + staging         nt");
+      run<false, false, true, 2>(b, reps, "later  full              nt");
+      ReadArgs c{d, rows, n, 16, 2, 20, 0};
+      run<false, false, true, 2>(c, reps, "later  full              nt");
+    }
+  }
+  if (sweep == 0) {
+    for (int q : {2, 4}) {
+      ReadArgs a{d, rows, n, 4, q, 8, 0};
+      run<true, false, true, 0>(a, reps, "first  bare loads        nt");
+      run<true, false, true, 2>(a, reps, "first  full              nt");
+      // second-run position sweep: bits 12-15 + loB..loB+3, then pairs without 12-15
+      const int pairs[][2] = {{12, 16}, {12, 20}, {12, 24}, {16, 20}, {16, 24}, {20, 24}, {14, 18}, {18, 22}};
+      for (auto &pr : pairs) {
+        if (pr[1] + 4 > n) continue;
+        for (int hw = 0; hw < 2; ++hw) {
+          ReadArgs b{d, rows, n, pr[0], q, pr[1], hw};
+          run<false, false, true, 0>(b, reps, "later  bare loads        nt");
+          run<false, false, true, 2>(b, reps, "later  full              nt");
+          run<false, true, true, 2>(b, reps, "later  full        pf    nt");
+        }
+      }
+    }
+  }
+  return 0;
+}

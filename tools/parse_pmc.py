@@ -14,7 +14,7 @@ import sys
 
 
 def family(name):
-    for k in ("k_tile2", "k_mw_tile2", "k_mw_tile_purity", "k_mw_direct", "k_mw_tile", "k_reg_measure_mono", "k_reg_measure", "k_product_stream", "k_tile_product", "k_fold_columns", "k_mono_coef", "k_tile", "k_direct_1q", "k_expval_partial", "k_expval_final", "k_build_matrices",
+    for k in ("k_tile2", "k_mw_read", "k_mw_purity", "k_reg_measure_mono", "k_reg_measure", "k_product_stream", "k_tile_product", "k_fold_columns", "k_mono_coef", "k_tile", "k_direct_1q", "k_expval_partial", "k_expval_final", "k_build_matrices",
               "k_probs", "k_overlap", "k_cross", "k_init_zero", "k_fill_zero"):
         if k in name:
             return k
