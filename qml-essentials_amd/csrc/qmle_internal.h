@@ -175,6 +175,11 @@ struct qmle_plan {
   uint32_t mat_floats = 0;                // per-sample matrix row length
   int fold_groups = 0;                    // most gate groups of any Stage::product_ok stage
   double model_cost = 0.0;                // pass-cost model of the chosen schedule (us per state at n = 24 scale)
+  int chosen_candidate = -1;              // index of the schedule candidate the model picked (compile_plan)
+  // The same tape compiled for runs from |0..0> only (qmle_run_batch): its first stage may stage a
+  // wider tile (it computes one tile per state whatever the size).  Owned; used by run_batch_masks
+  // in place of this plan; qmle_apply_inplace / the adjoint sweep keep using this plan's stages.
+  qmle_plan *zero_variant = nullptr;
   bool whole_state_lds = false;
   int tile_T = 0, tile_L = 0;
   double algo_bytes_per_state = 0;
@@ -196,6 +201,9 @@ struct qmle_plan {
   void *adjf_blob = nullptr;
   uint64_t adjf_hash = 0;
 };
+
+// internal plan flag (bit 25; not part of the ABI): the plan is executed by qmle_run_batch only
+#define QMLE_PLAN_INTERNAL_ZERO_RUN (1u << 25)
 
 namespace qmle {
 int compile_plan(qmle_plan *p);  // qmle_plan.cpp

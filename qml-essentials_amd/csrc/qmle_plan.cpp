@@ -696,7 +696,13 @@ int compile_plan(qmle_plan *p) {
   // whatever room is left after the first sweep is filled by a second, plain greedy sweep.
   // HE layer at n = 24: dense gates per pass 12/7/5 -> 12/8/4, the measuring pass drops from
   // two register-tile groups to one.
-  auto schedule = [&](int T, int L, bool lazy = false) {
+  // carry >= 0: every tile after the first also holds bit position `carry` (position 6 = byte
+  // address bit 9: a read+write pass whose tile holds it moves two 128-byte rows 512 B apart with
+  // every load / store instruction and runs 12-15 % faster -- 51 -> 44 us per state at n = 24,
+  // profiles/r03_rw_tile_bits.txt; the price is one of the tile's 8 free positions).
+  // T_first > T: the first stage of a run from |0..0> computes ONE tile per state (everything else
+  // is zeros whatever the tile size), so it may stage up to 2^14 amplitudes at no cost in traffic.
+  auto schedule = [&](int T, int L, bool lazy = false, int carry = -1, int T_first = 0) {
     if (p->whole_state_lds) T = n;
     if (T > kLdsMaxQubits) T = kLdsMaxQubits;
     if (T > n) T = n;
@@ -722,10 +728,18 @@ int compile_plan(qmle_plan *p) {
 
     auto popc = [](uint64_t x) { return __builtin_popcountll(x); };
 
+    const int T_plan = T;
     while (n_done < nl) {
       std::vector<int> members;
       uint64_t Q = 0;
       int stageL = L;
+      T = T_plan;
+      if (!p->whole_state_lds && p->stages.empty() && T_first > T_plan) {
+        T = T_first;
+        if (T > kLdsMaxQubits) T = kLdsMaxQubits;
+        if (T > n - 1) T = n - 1;
+        if (T < T_plan) T = T_plan;
+      }
       if (p->whole_state_lds) {
         for (size_t i = 0; i < nl; ++i) members.push_back((int)i);
         Q = all_mask;
@@ -750,6 +764,7 @@ int compile_plan(qmle_plan *p) {
         const uint64_t fm = op_mask(fo, n);
         while (stageL > 1 && popc((bit(stageL) - 1) | fm) > T) --stageL;
         Q = bit(stageL) - 1;
+        if (carry >= stageL && carry < n && !p->stages.empty() && popc(Q | fm | bit(carry)) <= T) Q |= bit(carry);
         std::vector<char> taken;
         if (lazy) taken.assign(nl, 0);
         for (int sweep = lazy ? 0 : 1; sweep < 2; ++sweep) {
@@ -899,6 +914,9 @@ int compile_plan(qmle_plan *p) {
   // Known zeros scale both parts: a stage reads 2^-|zero_in| of the state, computes and (when
   // the next stage is a tile stage) stores only the tiles whose outer bits are live.
   const bool sparse_model = !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
+  // the plan is only ever run from |0..0> (qmle_run_batch): set on the variants / children that
+  // qmle_plan_create compiles for that purpose, never on a plan handed to qmle_apply_inplace
+  const bool zero_run = (p->flags & QMLE_PLAN_INTERNAL_ZERO_RUN) != 0;
   auto cost = [&]() {
     double c = 0;
     for (size_t si = 0; si < p->stages.size(); ++si) {
@@ -912,38 +930,87 @@ int compile_plan(qmle_plan *p) {
         if (si > 0) rd = std::ldexp(1.0, -__builtin_popcount(st.zero_in));
         if (st.next_tile) wr = tiles;
       }
-      // + a part that does not shrink with the state (launch, first / last wave): at n = 20 a
-      // pass costs ~1.2 us per state before its first group, a group ~1.35 us
+      // the first stage of a run from |0..0> runs its gates on one tile per state (the rest is a fill)
+      if (si == 0 && zero_run && !sparse_model) tiles = std::ldexp(1.0, st.T - n);
+      const bool last = si + 1 == p->stages.size();
       if (st.fast_ok) {
-        // fast kernel (k_tile2; MI355X, round 2): ~47 us for the HBM round trip of an all-live
-        // stage with one group hidden behind it, ~9 per further group (51 with 2, 106 with 9);
-        // known zeros scale the traffic and the share of tiles that run their groups
-        c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 18.0 * (rd + wr) +
-             9.0 * ((st.fast_end - st.fast_begin) - 0.5) * tiles;
+        // Fast kernel (k_tile2), round-3 model, fitted to per-pass HIP-event times of 1- and 4-layer
+        // circuits at n = 24 with and without their gate groups (tools/deep_anatomy.py,
+        // QMLE_DBG_T2=1; profiles/r03_pass_model.txt): a pass takes the LONGER of its memory time
+        // and its compute time plus a sixth of the shorter one.
+        //   memory: 19.5 us write-only, 21 read-only, 50 read+write (5.4 TB/s: the mix costs);
+        //   a read+write pass whose every load / store instruction spans positions 6 and 13 (byte
+        //   address bits 9 and 16) and no other position below 8 -- a wave's 8 rows of 128 B are
+        //   the tile's three lowest high positions -- runs 15 % faster (51.3 -> 43.3 us, K2 pass
+        //   2; 54 -> 45 in the bare pass for every tile {6, 13, x >= 8, ...} and for no other pair
+        //   tried); every pair of high positions 8 apart costs ~4.5 us (54 -> 71 for {12-15,
+        //   20-23}).  The HBM channel hash behind both is not documented: modelled as measured.
+        //   compute: 5 + 9.5 per register-tile group, + 10 for the <Z> sums of a measuring pass.
+        double rw = (si == 0 ? 0.0 : 21.0 * rd) + (last ? 0.0 : 19.5 * wr);
+        if (si > 0 && !last) {
+          rw += 9.5 * (rd < wr ? rd : wr);
+          double shape = 0.0;
+          if (st.L == 4 && st.T >= 12) {
+            const int h0 = st.tile_bits[4], h1 = st.tile_bits[5], h2 = st.tile_bits[6];
+            if (h0 == 6 && h1 >= 8 && (h1 == 13 || h2 == 13)) shape -= 7.5;
+          }
+          uint32_t hi = 0;
+          for (int j = st.L; j < st.T; ++j) hi |= 1u << st.tile_bits[j];
+          shape += 4.5 * __builtin_popcount(hi & (hi >> 8));
+          rw += shape * (rd < wr ? rd : wr);
+        }
+        const double cmp = (5.0 + 9.5 * (st.fast_end - st.fast_begin) + (last ? 10.0 : 0.0)) * tiles;
+        c += 1.5 + 0.8 * std::ldexp(1.0, 24 - n) + (rw > cmp ? rw + cmp / 6.0 : cmp + rw / 6.0);
         continue;
       }
-      c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 6.0 * (rd + wr) +
+      const double mem = rd + (last ? 0.0 : wr);
+      c += 2.0 + 0.8 * std::ldexp(1.0, 24 - n) + 6.0 * mem +
            25.0 * (st.grp_end - st.grp_begin) * tiles;
     }
+    // a schedule that ends in a streaming pass leaves the measurement to a pass of its own (one
+    // more read of the state), where a tile pass measures on the fly
+    if (!p->stages.empty() && p->stages.back().kind != ST_TILE) c += 21.0;
     return c;
   };
   if (p->whole_state_lds || forced_T != 0 || forced_L != 0 || no_fusion_flag) {
     schedule(forced_T ? forced_T : kDefaultTileBits, forced_L ? forced_L : kDefaultLowBits);
   } else {
     static const int cand[][2] = {{13, 7}, {13, 5}, {12, 4}, {13, 4}, {12, 5}, {13, 6}};
+    // k = geometry (6) x [eager, lazy CX] (2) x variant (4): 0 plain, 1 wide first stage, 2 position 6
+    // carried + wide first stage, 3 position 6 carried.  Ties keep the lower index (round-2 schedules).
     int best = 0;
     double best_cost = 1e300;
     static const bool no_lazy = std::getenv("QMLE_NO_LAZY_CX") != nullptr;
-    for (int k = 0; k < (no_lazy ? 6 : 12); ++k) {  // 0..5 eager (ties keep the eager schedule), 6..11 lazy
-      if (cand[k % 6][0] >= n) continue;
-      schedule(cand[k % 6][0], cand[k % 6][1], k >= 6);
+    static const bool no_carry = std::getenv("QMLE_NO_CARRY6") != nullptr;
+    static const bool no_wide = std::getenv("QMLE_NO_WIDE_FIRST") != nullptr;
+    auto run_cand = [&](int k) {
+      const int g = k % 6, lazy = (k / 6) % 2, v = k / 12;
+      const bool wide = v == 1 || v == 2, carry6 = v >= 2;
+      schedule(cand[g][0], cand[g][1], lazy != 0, carry6 ? 6 : -1, wide ? kLdsMaxQubits : 0);
+    };
+    auto allowed = [&](int k) {
+      const int g = k % 6, lazy = (k / 6) % 2, v = k / 12;
+      if (cand[g][0] >= n) return false;
+      if (lazy && no_lazy) return false;
+      // (known-zero runs keep the round-2 schedules: their first passes are launch-bound special
+      // kernels tuned for the (12, 4) geometry, and the wide first tile cost them 4-8 % at n = 24)
+      if (v >= 1 && sparse_model && std::getenv("QMLE_SPARSE_VARIANTS") == nullptr) return false;
+      if ((v == 1 || v == 2) && (!zero_run || no_wide)) return false;
+      if (v >= 2 && (no_carry || cand[g][1] != 4 || n < 16)) return false;
+      return true;
+    };
+    for (int k = 0; k < 48; ++k) {
+      if (!allowed(k)) continue;
+      run_cand(k);
       const double c = cost();
-      if (c < best_cost) { best_cost = c; best = k; }
+      // (the round-3 variants must win by 2 %: the model knows their effect from two circuits)
+      if (c < best_cost * (k >= 12 && best < 12 ? 0.98 : 1.0) - 1e-9) { best_cost = c; best = k; }
     }
-    // (tuning only: force one of the 12 candidates to measure it against the model's choice)
+    // (tuning only: force one of the candidates to measure it against the model's choice)
     static const int force = std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;
-    if (force >= 0 && force < 12 && cand[force % 6][0] < n) best = force;
-    schedule(cand[best % 6][0], cand[best % 6][1], best >= 6);
+    if (force >= 0 && force < 48 && cand[force % 6][0] < n && (force < 12 || zero_run)) best = force;
+    run_cand(best);
+    p->chosen_candidate = best;
   }
   p->model_cost = cost();
   return QMLE_OK;
@@ -1010,7 +1077,8 @@ std::string describe_plan(const qmle_plan *p) {
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
      << ",\"n_lowered\":" << p->lowered.size()
      << ",\"whole_state_lds\":" << (p->whole_state_lds ? "true" : "false")
-     << ",\"model_cost\":" << p->model_cost << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
+     << ",\"model_cost\":" << p->model_cost << ",\"candidate\":" << p->chosen_candidate
+     << ",\"zero_run\":" << ((p->flags & QMLE_PLAN_INTERNAL_ZERO_RUN) ? "true" : "false") << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
      << ",\"mat_floats\":" << p->mat_floats
      << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state
      << ",\"flops_per_state\":" << plan_flops_per_state(p) << ",\"stages\":[";

@@ -1242,7 +1242,7 @@ struct Tile2Args {
   const uint32_t *tbl;      // qmle_plan::tbl2 on the device
   int n_groups;
   int n_ops_stage;          // ops of all the stage's groups (one contiguous stream in `ops`)
-  int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue
+  int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue, 4 / 8: see tile2_groups
   uint32_t gtab;            // index into tbl: per-lane global byte offset inside the tile
   uint32_t uoff8[8];        // byte offsets of the lane's 8 float4 (the tile's top three bits)
   // tile index -> amplitude offset of the tile: the outer bit positions as <= 6 contiguous runs
@@ -1340,6 +1340,13 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
       // scalar loads return out of order, so only lgkmcnt(0) can cover them: touching this
       // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
       asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
+      if (f.dbg & 12) {  // timing anatomy only (wrong results): 4 = no per-gate scalar loads, 8 = + no dispatch
+        if (busy) {
+          if (f.dbg & 8) f_dense<1>(r, M0);
+          else fast_dispatch(r, (int)(w0.y >> 24), M0);
+        }
+        continue;
+      }
       const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
       const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
       const v4u w2 = op[k + 2 < last ? k + 2 : last];
@@ -3925,7 +3932,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   // the tile kernel behind it (15 us per 32 states) -- 22.4 -> 20.2 us per 2^24-amplitude state.
   static const bool no_fill = std::getenv("QMLE_NO_INIT_FILL") != nullptr;
   if (init_zero && !from_zero && meas == TM_STORE && st.T < p->n && !no_fill && tiles > 1 &&
-      st.fast_ok && p->n <= 28 && threads == (1 << (st.T - 4)) && !(p->flags & QMLE_PLAN_PREFETCH)) {
+      (st.fast_ok || st.T == kLdsMaxQubits) && p->n <= 28 && threads == (1 << (st.T - 4)) &&
+      !(p->flags & QMLE_PLAN_PREFETCH)) {
     const uint64_t count = ((uint64_t)batch << p->n) / 2u;  // float4 = two amplitudes
     for (uint64_t done = 0; done < count;) {  // (grid.x < 2^31 workgroups per launch)
       const uint64_t part = std::min<uint64_t>(count - done, (uint64_t)1 << 38);
@@ -4334,6 +4342,7 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
   *out = nullptr;
   qmle_plan *p = new (std::nothrow) qmle_plan();
   if (!p) return QMLE_ERR_INVALID_ARG;
+  flags &= ~QMLE_PLAN_INTERNAL_ZERO_RUN;  // internal: set below on the plans only qmle_run_batch executes
   p->n = n_qubits;
   p->n_slots = n_slots;
   p->flags = flags;
@@ -4343,6 +4352,25 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
   if (rc != QMLE_OK) {
     delete p;
     return rc;
+  }
+  // The same tape scheduled for runs from |0..0> only (wider first tile): what qmle_run_batch
+  // executes in place of `p` when the pass-cost model prefers it.  qmle_apply_inplace and the
+  // adjoint sweep apply stages to LIVE states and keep `p`'s own schedule.
+  static const bool no_wide = std::getenv("QMLE_NO_WIDE_FIRST") != nullptr;
+  if (!no_wide && !p->whole_state_lds && !(flags & (QMLE_PLAN_NO_FUSION | QMLE_PLAN_PREFETCH)) &&
+      !((flags >> 8) & 0xffffu) && p->stages.size() >= 2 && p->stages[0].kind == ST_TILE) {
+    qmle_plan *v = new (std::nothrow) qmle_plan();
+    if (v) {
+      v->n = n_qubits;
+      v->n_slots = n_slots;
+      v->flags = flags | QMLE_PLAN_INTERNAL_ZERO_RUN;
+      v->ops = p->ops;
+      v->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
+      if (compile_plan(v) == QMLE_OK && v->mat_floats == p->mat_floats && v->model_cost < p->model_cost - 0.5)
+        p->zero_variant = v;
+      else
+        delete v;
+    }
   }
   // <Z> measurements run a second plan without the trailing gates that only relabel basis
   // states or add phases (they are folded into the observables at run time)
@@ -4354,7 +4382,7 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
       if (c) {
         c->n = n_qubits;
         c->n_slots = n_slots;
-        c->flags = flags | QMLE_PLAN_NO_ABSORB;
+        c->flags = flags | QMLE_PLAN_NO_ABSORB | QMLE_PLAN_INTERNAL_ZERO_RUN;  // a child only ever runs from |0..0>
         c->ops = kept;
         c->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
         for (const qmle_op &o : p->absorbed) p->absorbed_algo_bytes += algo_bytes(o, p->n);
@@ -4386,7 +4414,8 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
             if (kind == 0) penalty = 17.0;
             else if (kind == 1 && (!plan_sparse(c) || ls.zero_in == 0)) penalty = 12.0;
           }
-          if (penalty > 0.0 && c->model_cost + penalty > p->model_cost) {
+          const double applied_cost = p->zero_variant ? p->zero_variant->model_cost : p->model_cost;
+          if (penalty > 0.0 && c->model_cost + penalty > applied_cost) {
             delete c;
             p->expval_child = nullptr;
           }
@@ -4398,11 +4427,16 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
   *out = p;
   return QMLE_OK;
 }
-qmle_plan *qmle_plan_expval_child(qmle_plan *plan) { return plan ? plan->expval_child : nullptr; }
+// (the plan QMLE_MEAS_EXPVAL_Z executes: the child when trailing gates were folded into the
+// observables, else the from-|0..0> variant of the plan when there is one)
+qmle_plan *qmle_plan_expval_child(qmle_plan *plan) {
+  return !plan ? nullptr : plan->expval_child ? plan->expval_child : plan->zero_variant;
+}
 
 int qmle_plan_destroy(qmle_plan *plan) {
   if (!plan) return QMLE_OK;
   if (plan->expval_child) (void)qmle_plan_destroy(plan->expval_child);
+  if (plan->zero_variant) (void)qmle_plan_destroy(plan->zero_variant);
   if (plan->adj_blob) (void)hipFree(plan->adj_blob);
   if (plan->adjf_blob) (void)hipFree(plan->adjf_blob);
   if (plan->dev.blob) (void)hipFree(plan->dev.blob);
@@ -4511,6 +4545,10 @@ size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int
   (void)n_obs;
   if (!plan || batch < 1) return 0;
   size_t total = workspace_bytes_one(plan, batch, meas_type, states_in_flight);
+  if (plan->zero_variant) {
+    const size_t c = workspace_bytes_one(plan->zero_variant, batch, meas_type, states_in_flight);
+    if (c > total) total = c;
+  }
   if (meas_type == QMLE_MEAS_EXPVAL_Z && plan->expval_child) {
     const size_t c = workspace_bytes_one(plan->expval_child, batch, meas_type, states_in_flight);
     if (c > total) total = c;
@@ -4601,6 +4639,7 @@ int qmle_run_batch_parity(qmle_plan *plan, const float *d_angles, int batch,
 static int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
                            const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
                            size_t workspace_bytes, hipStream_t stream) {
+  if (plan->zero_variant) plan = plan->zero_variant;  // every run_batch starts from |0..0>
   const int n = plan->n;
   bool single_bits = true;  // plain Z observables: the 33-sums epilogue serves them all
   int8_t obs_bits[QMLE_MAX_QUBITS];

@@ -174,6 +174,40 @@ def test_xor_addressed_tile_kernels_have_no_static_lds():
     assert N.lib().qmle_status_string(-12).decode().startswith("internal invariant")
 
 
+def test_from_zero_variant_of_the_all_live_k2_plan():
+    """Plan compiler, host only (round 3).  qmle_run_batch always starts from |0..0>, where the
+    first stage computes ONE tile per state whatever the tile size: the plan it executes (the
+    from-zero variant, reported by expval_child() when nothing was folded) may stage 2^14
+    amplitudes first, and carries bit position 6 so that the read+write pass's tile is {0-3, 6,
+    13-19} -- the shape that streams 15 % faster.  The plan's own stages, which
+    qmle_apply_inplace and the adjoint sweep apply to LIVE states, keep the round-2 schedule."""
+    ops, slots = he_layer_ops(24)
+    top = N.Plan(ops, 24, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+    own = top.describe()
+    assert own["zero_run"] is False and [s["T"] for s in own["stages"]] == [12, 12, 12]
+    assert [sum(g["n_ops"] for g in s["fast_groups"]) for s in own["stages"]] == [12, 8, 4]
+    var = top.expval_child()
+    assert var is not None
+    d = var.describe()
+    assert d["zero_run"] is True and d["model_cost"] < own["model_cost"]
+    st = d["stages"]
+    assert len(st) == 3 and [s["T"] for s in st] == [14, 12, 12]
+    assert st[0]["bits"] == list(range(14)) and not st[0]["fast"]      # 2^14 amplitudes: generic kernel, one tile per state
+    assert st[1]["bits"] == [0, 1, 2, 3, 6] + list(range(13, 20)) and st[1]["fast"]
+    assert [len(s["fast_groups"]) for s in st[1:]] == [2, 1]           # 6 + 4 dense gates: the measuring pass is ONE group
+    assert sum(s["n_lowered"] for s in st) == 48
+    # every gate exactly once, in an order that respects wires (the generic checker of the fused schedule)
+    seen = sorted(o for s in st for o in s["src_ops"])
+    assert seen == list(range(96))
+    # known-zero runs keep the round-2 geometry (their first passes are launch-bound special kernels)
+    dflt = N.Plan(ops, 24, slots).expval_child().describe()
+    assert [s["T"] for s in dflt["stages"]] == [12, 12, 12] and dflt["stages"][1]["product"]
+    # forced geometries, one-pass-per-gate plans and whole-state plans have no variant
+    assert N.Plan(ops, 24, slots, flags=N.PLAN_NO_ABSORB | N.PLAN_NO_FUSION).expval_child() is None
+    ops12, slots12 = he_layer_ops(12)
+    assert N.Plan(ops12, 12, slots12, flags=N.PLAN_NO_ABSORB).expval_child() is None
+
+
 def test_meyer_wallach_read_count():
     """Host only: reads of the state per Meyer-Wallach call (bench.py's bytes-moved accounting):
     one cache-resident sweep per wire below the tile size, then 1 + ceil((n - 12) / 8)."""

@@ -51,6 +51,43 @@ def test_random_circuits_state_parity_all_modes(n):
         assert err < 2e-6, (mode, n, err)  # fp32 state vs fp64 oracle, 40 gates
 
 
+@pytest.mark.parametrize("n,layers", [(15, 1), (16, 2), (18, 2), (21, 1)])
+def test_from_zero_variant_equals_the_plans_own_schedule_and_the_oracle(n, layers):
+    """Round 3: qmle_run_batch executes the from-|0..0> variant of an all-live plan (first stage
+    on a 2^14-amplitude tile, bit position 6 carried), qmle_apply_inplace the plan's own stages.
+    Same tape, same angles: both must give the oracle's state (n <= 18) and each other's."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    ops1, slots1 = he_layer_ops(n)
+    ops = []
+    for l in range(layers):
+        ops += [(g, w, [s + l * slots1 for s in sl], off) for g, w, sl, off in ops1]
+    ops += [("CRX", [0, n - 1], [0], -1), ("RZ", [n // 2], [1], -1), ("H", [1], [], -1)]
+    slots = layers * slots1
+    ang = np.random.default_rng(n).uniform(0, 2 * np.pi, (2, slots)).astype(np.float32)
+    angd = torch.from_numpy(ang).cuda()
+    plan = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+    var = plan.expval_child()
+    assert var is not None and var.describe()["zero_run"] and var.describe()["stages"][0]["T"] == 14
+    got = plan.run(angd, "state")                      # from |0..0>: the variant
+    st = torch.zeros((2, 1 << n), dtype=torch.complex64, device="cuda")
+    st[:, 0] = 1
+    N.apply_inplace(plan, angd, st)                    # live state: the plan's own schedule
+    assert float((torch.view_as_real(got) - torch.view_as_real(st)).abs().max()) < 2e-6
+    ez = plan.run(angd, "expval", list(range(n))).cpu().numpy()
+    p = (st.abs() ** 2).double().cpu().numpy()
+    idx = np.arange(1 << n)
+    want_z = np.stack([[np.sum(pb * (1 - 2 * ((idx >> (n - 1 - q)) & 1))) for q in range(n)] for pb in p])
+    assert np.abs(ez - want_z).max() < 2e-6
+    if n <= 18:
+        from tests.helpers import oracle_tape
+        for b in range(2):
+            tape = [(g, w, tuple(float(ang[b, s]) for s in sl)) for g, w, sl, _ in ops]
+            want = OE.simulate_pure(tape, n, np.complex128)
+            assert np.abs(got[b].cpu().numpy() - want).max() < 2e-6
+
+
 @pytest.mark.parametrize("n", [14, 16])
 def test_low_control_streaming_mode_every_control_target_pair(n):
     """k_direct_1q mode 7: non-diagonal controlled gates with the control on bit

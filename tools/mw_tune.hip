@@ -249,6 +249,132 @@ __global__ void __launch_bounds__(kThreads) k_mw_read(const ReadArgs a) {
   }
 }
 
+// ---- read + write tile pass without gates: in place (rows of 128 B in and out) vs out of place
+// with the tile written as ONE contiguous 32 KiB block (the layout-permuting pass) ----
+struct RwArgs {
+  const float2 *in;
+  float2 *out;
+  int n, lo, lo2, q;
+  int contig;   // 1: out[tile * 4096 + local]; 0: same addresses as the read
+  int stage;    // 1: through LDS (write, barrier, read back transposed like a gather would)
+};
+template <bool NT, int NLD, bool PF>
+__global__ void __launch_bounds__(2048 / NLD) k_rw(const RwArgs a) {
+  extern __shared__ float4 smem4[];
+  const uint32_t sbo = (uint32_t)(uintptr_t)smem4;
+  constexpr uint32_t NTH = 2048 / NLD;       // threads; thread t, step u -> local float4 index t + u * NTH
+  const uint32_t tid = threadIdx.x, jl = 2u * tid;
+  const int lo = a.lo, lo2 = a.lo2;
+  auto off_of = [&](uint32_t j) {  // local amplitude index (12 bits) -> byte offset inside the state
+    return ((uint64_t)(j & 15u) | ((uint64_t)((j >> 4) & 15u) << lo) | ((uint64_t)(j >> 8) << lo2)) << 3;
+  };
+  const size_t sb = ((size_t)blockIdx.y << a.n) * 8;
+  const char *st = reinterpret_cast<const char *>(a.in) + sb;
+  char *so = reinterpret_cast<char *>(a.out) + sb;
+  const uint32_t n_it = 1u << a.q, tile0 = blockIdx.x << a.q;
+  vf4 v[NLD], w[NLD];
+  auto load = [&](uint32_t t, vf4 (&r)[NLD]) {
+    const uint64_t base = tile_base_bytes(t, lo, lo2);
+    static_for<NLD>([&](auto u) { r[u] = ld4<NT>(st + base + off_of(jl + 2u * (uint32_t)u * NTH)); });
+  };
+  auto store = [&](uint32_t t, vf4 (&r)[NLD]) {
+    const uint64_t base = a.contig ? ((uint64_t)t << 15) : tile_base_bytes(t, lo, lo2);
+    static_for<NLD>([&](auto u) {
+      const uint32_t j = jl + 2u * (uint32_t)u * NTH;
+      vf4 *o = reinterpret_cast<vf4 *>(so + base + (a.contig ? (uint64_t)j << 3 : off_of(j)));
+      if (NT) __builtin_nontemporal_store(r[u], o); else *o = r[u];
+    });
+  };
+  load(tile0, v);
+  for (uint32_t it = 0; it < n_it; ++it) {
+    if (a.stage) {
+      if (it) __syncthreads();
+      static_for<NLD>([&](auto u) { lds_st128(sbo + ((sw(jl + 2u * (uint32_t)u * NTH)) << 3), v[u]); });
+      __syncthreads();
+      static_for<NLD>([&](auto u) { w[u] = lds_ld128(sbo + ((sw(jl + 2u * (uint32_t)u * NTH)) << 3)); });
+    } else {
+      static_for<NLD>([&](auto u) { w[u] = v[u]; });
+    }
+    static_for<NLD>([&](auto u) { w[u].x += 1.0f; });
+    if (PF) {
+      if (it + 1 < n_it) load(tile0 + it + 1, v);
+      store(tile0 + it, w);
+    } else {
+      store(tile0 + it, w);
+      if (it + 1 < n_it) load(tile0 + it + 1, v);
+    }
+  }
+}
+
+// ---- in-place read + write pass over tiles with ARBITRARY high bit positions (8 of them) ----
+struct RwAnyArgs {
+  float2 *st;
+  int n, q;
+  int pos[8];       // the tile's high bit positions, ascending
+  int outer[20];    // the other positions >= 4, ascending
+};
+__global__ void __launch_bounds__(kThreads) k_rw_any(const RwAnyArgs a) {
+  const uint32_t tid = threadIdx.x, jl = 2u * tid;
+  uint64_t goff = jl & 15u;
+  for (int k = 0; k < 5; ++k) goff |= (uint64_t)((jl >> (4 + k)) & 1u) << a.pos[k];
+  uint64_t uo[8];
+  static_for<8>([&](auto u) {
+    uo[u] = ((uint64_t)((u >> 0) & 1) << a.pos[5] | (uint64_t)((u >> 1) & 1) << a.pos[6] | (uint64_t)((u >> 2) & 1) << a.pos[7]) << 3;
+  });
+  char *st = reinterpret_cast<char *>(a.st) + (((size_t)blockIdx.y << a.n) << 3) + (goff << 3);
+  const uint32_t n_it = 1u << a.q, tile0 = blockIdx.x << a.q;
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const uint32_t t = tile0 + it;
+    uint64_t base = 0;
+    for (int i = 0; i < a.n - 12; ++i) base |= (uint64_t)((t >> i) & 1u) << a.outer[i];
+    base <<= 3;
+    vf4 v[8];
+    static_for<8>([&](auto u) { v[u] = ld4<true>(st + base + uo[u]); });
+    static_for<8>([&](auto u) { v[u].x += 1.0f; });
+    static_for<8>([&](auto u) { __builtin_nontemporal_store(v[u], reinterpret_cast<vf4 *>(st + base + uo[u])); });
+  }
+}
+
+// two tiles per iteration (they differ in outer[0]): all 16 loads first, then the stores
+// MODE 0: stores A then B back to back; 1: store A, (delay), store B; 2: loads A, B interleaved per u
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_rw_any2(const RwAnyArgs a) {
+  const uint32_t tid = threadIdx.x, jl = 2u * tid;
+  uint64_t goff = jl & 15u;
+  for (int k = 0; k < 5; ++k) goff |= (uint64_t)((jl >> (4 + k)) & 1u) << a.pos[k];
+  uint64_t uo[8];
+  static_for<8>([&](auto u) {
+    uo[u] = ((uint64_t)((u >> 0) & 1) << a.pos[5] | (uint64_t)((u >> 1) & 1) << a.pos[6] | (uint64_t)((u >> 2) & 1) << a.pos[7]) << 3;
+  });
+  char *st = reinterpret_cast<char *>(a.st) + (((size_t)blockIdx.y << a.n) << 3) + (goff << 3);
+  const uint64_t pair_step = (uint64_t)8 << a.outer[0];
+  const uint32_t n_it = 1u << a.q, tile0 = blockIdx.x << a.q;   // pairs
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const uint32_t t = (tile0 + it) << 1;
+    uint64_t base = 0;
+    for (int i = 1; i < a.n - 12; ++i) base |= (uint64_t)((t >> i) & 1u) << a.outer[i];
+    base <<= 3;
+    vf4 v[8], w[8];
+    if (MODE == 2 || MODE == 3) {
+      static_for<8>([&](auto u) { v[u] = ld4<true>(st + base + uo[u]); w[u] = ld4<true>(st + base + pair_step + uo[u]); });
+    } else {
+      static_for<8>([&](auto u) { v[u] = ld4<true>(st + base + uo[u]); });
+      static_for<8>([&](auto u) { w[u] = ld4<true>(st + base + pair_step + uo[u]); });
+    }
+    static_for<8>([&](auto u) { v[u].x += 1.0f; w[u].x += 1.0f; });
+    if (MODE == 2 || MODE == 4) {
+      static_for<8>([&](auto u) {
+        __builtin_nontemporal_store(v[u], reinterpret_cast<vf4 *>(st + base + uo[u]));
+        __builtin_nontemporal_store(w[u], reinterpret_cast<vf4 *>(st + base + pair_step + uo[u]));
+      });
+    } else {
+      static_for<8>([&](auto u) { __builtin_nontemporal_store(v[u], reinterpret_cast<vf4 *>(st + base + uo[u])); });
+      if (MODE == 1) __builtin_amdgcn_s_sleep(64);
+      static_for<8>([&](auto u) { __builtin_nontemporal_store(w[u], reinterpret_cast<vf4 *>(st + base + pair_step + uo[u])); });
+    }
+  }
+}
+
 __global__ void k_init(float2 *s, uint64_t count, float scale) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -424,6 +550,95 @@ int main(int argc, char **argv) {
       float q; CK(hipMemcpy(&q, out, 4, hipMemcpyDeviceToHost));
       printf("libqmle_sv qmle_meyer_wallach: rc %d  Q %.6f  %.4f ms per call over %d calls\n", rc, q, ms / reps, reps);
     }
+  }
+  if (sweep == 4) {  // read + write pass, n qubits x `states` states (argv[4]) per launch
+    const int states = argc > 4 ? atoi(argv[4]) : 1;
+    float2 *d2;
+    CK(hipFree(d));
+    CK(hipMalloc(&d, ((size_t)states << n) * 8));
+    CK(hipMalloc(&d2, ((size_t)states << n) * 8));
+    CK(hipMemset(d, 0, ((size_t)states << n) * 8));
+    CK(hipMemset(d2, 0, ((size_t)states << n) * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const uint32_t tiles = 1u << (n - kT);
+    const int shapes[][2] = {{4, 8}, {12, 16}};
+    auto time_it = [&](auto kern, int threads, const RwArgs &a, const char *what) {
+      const dim3 grid(tiles >> a.q, states);
+      for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, grid, dim3(threads), 32768, 0, a);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(threads), 32768, 0, a);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      const double gb = 16.0 * std::ldexp(1.0, n) * states / 1e9;
+      printf("rw bits %2d-%2d,%2d-%2d q=%d %-26s %s%s %8.4f ms  %7.2f us/state  %7.1f GB/s\n", a.lo, a.lo + 3, a.lo2, a.lo2 + 3, a.q, what,
+             a.contig ? "contig-out " : "in-place   ", a.stage ? "lds" : "   ", ms, ms * 1e3 / states, gb / (ms * 1e-3));
+      fflush(stdout);
+    };
+    for (auto &sh : shapes)
+      for (int q : {0, 2})
+        for (int mode : {0, 2, 3}) {
+          RwArgs a{d, mode == 0 ? d : d2, n, sh[0], sh[1], q, mode >= 2, mode == 3};
+          time_it(k_rw<true, 8, false>, 256, a, "8 per thread, 256 thr");
+          if (q) time_it(k_rw<true, 8, true>, 256, a, "8 per thread, 256 thr, pf");
+          time_it(k_rw<true, 4, false>, 512, a, "4 per thread, 512 thr");
+          if (q) time_it(k_rw<true, 4, true>, 512, a, "4 per thread, 512 thr, pf");
+          time_it(k_rw<true, 2, false>, 1024, a, "2 per thread, 1024 thr");
+          if (q) time_it(k_rw<true, 2, true>, 1024, a, "2 per thread, 1024 thr, pf");
+        }
+    return 0;
+  }
+  if (sweep == 5) {  // in-place read + write pass, arbitrary tile bits: argv[4] = states, argv[5..] = "b0,b1,..,b7" sets
+    const int states = argc > 4 ? atoi(argv[4]) : 32;
+    CK(hipFree(d));
+    CK(hipMalloc(&d, ((size_t)states << n) * 8));
+    CK(hipMemset(d, 0, ((size_t)states << n) * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int ai = 5; ai < argc; ++ai) {
+      RwAnyArgs a;
+      a.st = d; a.n = n; a.q = 2;
+      int k = 0;
+      const char *c = argv[ai];
+      for (; *c && *c != ':' && k < 8;) { a.pos[k++] = atoi(c); while (*c && *c != ',' && *c != ':') ++c; if (*c == ',') ++c; }
+      if (k != 8) { printf("need 8 positions: %s\n", argv[ai]); continue; }
+      uint32_t used = 15u;
+      for (int i = 0; i < 8; ++i) used |= 1u << a.pos[i];
+      int no = 0;
+      // optional ":q:o1,o2,.." = tiles per workgroup 2^q and the outer positions the LOW tile-index bits map to
+      if (*c == ':') {
+        ++c; a.q = atoi(c); while (*c && *c != ':') ++c;
+        if (*c == ':') ++c;
+        while (*c) { const int b = atoi(c); if (b >= 4 && b < n && !(used >> b & 1u)) { a.outer[no++] = b; used |= 1u << b; } while (*c && *c != ',') ++c; if (*c) ++c; }
+      }
+      for (int b = 4; b < n; ++b) if (!(used >> b & 1u)) a.outer[no++] = b;
+      const dim3 grid((1u << (n - 12)) >> a.q, states);
+      for (int variant = 0; variant < 6; ++variant) {
+        const dim3 g2 = variant ? dim3(grid.x >> 1, states) : grid;
+        auto launch = [&]() {
+          if (variant == 0) hipLaunchKernelGGL(k_rw_any, g2, dim3(kThreads), 0, 0, a);
+          else if (variant == 1) hipLaunchKernelGGL(k_rw_any2<0>, g2, dim3(kThreads), 0, 0, a);
+          else if (variant == 2) hipLaunchKernelGGL(k_rw_any2<1>, g2, dim3(kThreads), 0, 0, a);
+          else if (variant == 3) hipLaunchKernelGGL(k_rw_any2<2>, g2, dim3(kThreads), 0, 0, a);
+          else if (variant == 4) hipLaunchKernelGGL(k_rw_any2<3>, g2, dim3(kThreads), 0, 0, a);
+          else hipLaunchKernelGGL(k_rw_any2<4>, g2, dim3(kThreads), 0, 0, a);
+        };
+        for (int w = 0; w < 3; ++w) launch();
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        printf("rw-any {%s} %s: %7.2f us/state  %7.1f GB/s\n", argv[ai],
+               variant == 0 ? "one tile per iteration      " : variant == 1 ? "pair: 16 loads, 8 + 8 stores" : variant == 2 ? "pair: stores A, sleep, B    " : variant == 3 ? "pair: interleaved per u     " : variant == 4 ? "pair: loads interleaved only" : "pair: stores interleaved only",
+               ms * 1e3 / states, 16.0 * std::ldexp(1.0, n) * states / 1e9 / (ms * 1e-3));
+        fflush(stdout);
+      }
+    }
+    return 0;
   }
   if (sweep == 1) {  // sustained (thermal steady state): `reps` launches per line, the set run twice
     for (int rep = 0; rep < 2; ++rep) {
