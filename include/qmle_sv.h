@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 130 /* 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 140 /* 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -197,6 +197,22 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
  * Workspace: qmle_workspace_bytes(plan, batch, QMLE_MEAS_STATE, 0, 0). */
 int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+
+/* ---- complex128 execution (the reference's jax_enable_x64 mode, operations.py:12-16; switched on
+ * by tests/test_coefficients.py:19, test_entanglement.py:13, test_ansaetze.py:18) ----------------
+ * Same plan, same tape: angles float64 [batch][n_slots]; out = [B][2^n] complex128 (STATE),
+ * [B][2^n] float64 (PROBS), [B][n_obs] float64 (EXPVAL_Z; wire_masks[k] has bit w set iff wire w
+ * takes part in the Z (x) Z ... observable k -- HOST array), [B][2^n][2^n] complex128 (DENSITY,
+ * n <= 12).  Every gate of the tape is applied (no observable folding, no known-zero shortcuts):
+ * the accuracy mode, 1e-10 against a complex128 reference.  n <= 13: the state stays in LDS for
+ * the whole circuit; above, one streaming pass per (merged) operator. */
+int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int meas_type,
+                       const uint32_t *wire_masks, int n_obs, void *d_out, void *d_workspace,
+                       size_t workspace_bytes, qmle_stream stream);
+size_t qmle_workspace_bytes_f64(const qmle_plan *plan, int batch, int meas_type);
+/* optional: the batch-constant blob of qmle_plan_create at full precision (explicit matrices of a
+ * complex128 caller); same length, before the first qmle_run_batch_f64 of the plan */
+int qmle_plan_set_consts_f64(qmle_plan *plan, const double *consts, int n_consts);
 
 /* Optional per-pass HIP-event timing (bench.py's live roofline measurement): between
  * begin and end every pass launch of this plan is bracketed by an event pair on the

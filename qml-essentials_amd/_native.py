@@ -121,6 +121,9 @@ SYMBOLS = [
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_meyer_wallach_reads", _I, [_I]),
+    ("qmle_run_batch_f64", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_workspace_bytes_f64", _SZ, [_VP, _I, _I]),
+    ("qmle_plan_set_consts_f64", _I, [_VP, C.POINTER(C.c_double), _I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
     ("qmle_adjoint_gradient", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
                                    _VP, _I, _VP, _SZ, _VP]),
@@ -342,6 +345,43 @@ class Plan:
         check(rc, "qmle_run_batch")
         return out
 
+    def run64(self, angles, meas: str, wire_groups: Sequence[Sequence[int]] = ()):
+        """complex128 execution of the plan (the reference's ``jax_enable_x64`` mode):
+        ``angles`` float64 [B, n_slots]; returns complex128 states / density matrices, float64
+        probabilities, or float64 ``<Z..Z>`` of every wire group [B, len(wire_groups)]."""
+        torch = require_gpu()
+        if meas not in MEAS:
+            raise ValueError(f"Unknown measurement type: {meas!r}")  # simulation.py:271
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if angles is None:
+            angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float64, device=dev)
+        angles = angles.to(device=dev, dtype=torch.float64).contiguous()
+        if angles.dim() != 2 or (self.n_slots and angles.shape[1] != self.n_slots):
+            raise ValueError(f"angles must be [B, {self.n_slots}], got {tuple(angles.shape)}")
+        B, D, n_obs = int(angles.shape[0]), 1 << self.n_qubits, len(wire_groups)
+        masks = (C.c_uint32 * max(1, n_obs))()
+        for k, g in enumerate(wire_groups):
+            m = 0
+            for w in g:
+                m |= 1 << int(w)
+            masks[k] = m
+        out = {"state": lambda: torch.empty((B, D), dtype=torch.complex128, device=dev),
+               "probs": lambda: torch.empty((B, D), dtype=torch.float64, device=dev),
+               "expval": lambda: torch.empty((B, n_obs), dtype=torch.float64, device=dev),
+               "density": lambda: torch.empty((B, D, D), dtype=torch.complex128, device=dev)}[meas]()
+        wsb = int(lib().qmle_workspace_bytes_f64(self._h, B, MEAS[meas]))
+        ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+        check(lib().qmle_run_batch_f64(self._h, C.c_void_p(angles.data_ptr()), B, MEAS[meas], masks, n_obs,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                       C.c_size_t(ws.numel()), _stream_ptr()), "qmle_run_batch_f64")
+        return out
+
+    def set_consts64(self, consts) -> None:
+        """The batch-constant blob at full precision (complex128 callers with explicit matrices)."""
+        a = np.ascontiguousarray(consts, dtype=np.float64).reshape(-1)
+        check(lib().qmle_plan_set_consts_f64(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), int(a.size)),
+              "qmle_plan_set_consts_f64")
+
     def run_parity(self, angles, wire_groups: Sequence[Sequence[int]], workspace=None,
                    states_in_flight: int = 0):
         """<Z..Z> over every wire group, measured out of the last pass (no stored state).
@@ -414,6 +454,10 @@ def apply_inplace(plan: Plan, angles, states, workspace=None):
 # ---- stand-alone measurement / analysis kernels -------------------------------------
 def _states_info(states):
     torch = require_gpu()
+    if states.dtype == torch.complex128 and states.is_cuda:
+        # complex128 states (utils.enable_x64): the analysis kernels (fidelities, Meyer-Wallach,
+        # marginals, ...) are complex64 -- their results carry float32 accuracy either way
+        states = states.to(torch.complex64)
     if states.dtype != torch.complex64 or not states.is_cuda:
         raise ValueError("states must be a complex64 CUDA tensor [B, 2^n]")
     states = states.contiguous()

@@ -69,8 +69,13 @@ class Coefficients:
         axes = [np.arange(0, 2 * mts * np.pi, 2 * np.pi / n_freqs[i]) for i in range(F)]
         grid = np.array(np.meshgrid(*axes)).T.reshape(-1, F)
         # the engine returns float32; the (tiny) host FFT runs in double so that it adds no
-        # rounding noise of its own to the spectrum
-        outputs = np.asarray(model(inputs=grid.astype(np.float32), **kwargs), dtype=np.float64)
+        # rounding noise of its own to the spectrum.  complex128 mode (utils.enable_x64 /
+        # Model(x64=True)): the grid stays float64 too -- a float32-rounded grid point is off by
+        # 1e-7 rad, which leaks 1e-8 into the analytically vanishing top-frequency coefficients
+        from .utils import x64_enabled
+
+        x64 = x64_enabled() if getattr(model, "x64", None) is None else bool(model.x64)
+        outputs = np.asarray(model(inputs=grid if x64 else grid.astype(np.float32), **kwargs), dtype=np.float64)
         outputs = outputs.reshape(*[a.shape[0] for a in axes], -1).squeeze()
         coeffs = np.fft.fftn(outputs, axes=list(range(F)))
         freqs = [np.fft.fftfreq(int(mts * n_freqs[i]), 1 / n_freqs[i]) for i in range(F)]

@@ -180,6 +180,12 @@ struct qmle_plan {
   // wider tile (it computes one tile per state whatever the size).  Owned; used by run_batch_masks
   // in place of this plan; qmle_apply_inplace / the adjoint sweep keep using this plan's stages.
   qmle_plan *zero_variant = nullptr;
+  // complex128 engine (qmle_run_batch_f64): device copy of `lowered` + the constant blob as doubles
+  // (lazily created); `consts64` optionally holds the caller's constants at full precision
+  void *f64_blob = nullptr;
+  int f64_device = -1;
+  size_t n_user_consts = 0;               // constants handed to qmle_plan_create (the blob grows by permuted copies)
+  std::vector<double> consts64;
   bool whole_state_lds = false;
   int tile_T = 0, tile_L = 0;
   double algo_bytes_per_state = 0;

@@ -51,7 +51,11 @@ class Model:
         remove_zero_encoding: bool = True,
         repeat_batch_axis: List[bool] = [True, True, True],
         pulse_shape: str = "gaussian",
+        x64: Optional[bool] = None,
     ) -> None:
+        # x64 (extension): run this model on the complex128 engine regardless of the global
+        # ``utils.enable_x64`` switch (None = follow it) -- the reference's ``jax_enable_x64`` mode
+        self.x64 = x64
         self.n_qubits = n_qubits
         self.output_qubit = output_qubit
         self.n_layers = n_layers
@@ -841,6 +845,18 @@ class Model:
                  data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
                  force_mean: bool = False, gate_mode: str = "unitary",
                  as_tensor: bool = False):
+        from .utils import x64_enabled, x64_scope
+
+        with x64_scope(self.x64):
+            if x64_enabled():  # complex128: the recorded-tape path only (float64 angle table)
+                params = params.detach().cpu().numpy() if self._is_cuda(params) else params
+                inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
+            return self._forward_impl(params, inputs, pulse_params, enc_params, data_reupload,
+                                      noise_params, execution_type, force_mean, gate_mode, as_tensor,
+                                      x64_enabled())
+
+    def _forward_impl(self, params, inputs, pulse_params, enc_params, data_reupload, noise_params,
+                      execution_type, force_mean, gate_mode, as_tensor, x64=False):
         if (self._is_cuda(params) or self._is_cuda(inputs)) and not as_tensor \
                 and noise_params is None and self.noise_params is None and gate_mode == "unitary" \
                 and pulse_params is None and self.shots is None:
@@ -854,7 +870,7 @@ class Model:
         if (not as_tensor and noise_params is None and self.noise_params is None
                 and gate_mode == "unitary" and pulse_params is None and self.shots is None
                 and self.host_arrays_via_device and not self._is_cuda(params)
-                and not self._is_cuda(inputs)):
+                and not self._is_cuda(inputs) and not x64):
             out = self._forward_host_via_device(params, inputs, enc_params, execution_type,
                                                 force_mean, data_reupload)
             if out is not NotImplemented:

@@ -243,8 +243,8 @@ class LoweredTape:
         self.n_qubits = n_qubits
         self.key = h.hexdigest()
 
-    def angle_table(self, batch: int) -> np.ndarray:
-        table = np.empty((batch, max(1, self.n_slots)), dtype=np.float32)
+    def angle_table(self, batch: int, dtype=np.float32) -> np.ndarray:
+        table = np.empty((batch, max(1, self.n_slots)), dtype=dtype)
         if self.n_slots == 0:
             table[:] = 0
         four_pi = 4.0 * np.pi
@@ -376,6 +376,14 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
         return res if as_tensor else res.cpu().numpy()
     low = LoweredTape(tape, n_qubits)
     plan = get_plan(low)
+    from .utils import x64_enabled
+
+    if x64_enabled() and not sampled:
+        # gate by gate, like the reference (no products of neighbouring 1-qubit gates): the
+        # accuracy mode keeps the reference's operation order as well as its precision
+        plan = get_plan(low, (PLAN_FLAGS or 0) | N.PLAN_NO_MERGE)
+        res = _simulate_x64(plan, low, B, n_qubits, type, list(obs))
+        return res if as_tensor else res.cpu().numpy()
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if sampled:
         res = sample_shots(plan.run(angles, "probs"), n_qubits, type, obs, shots, key, row_offset)
@@ -396,6 +404,36 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
     if as_tensor:
         return res
     return res.cpu().numpy()
+
+
+def _simulate_x64(plan: N.Plan, low: "LoweredTape", B: int, n_qubits: int, type: str, obs):
+    """complex128 execution (``utils.enable_x64`` -- the reference's ``jax_enable_x64`` mode):
+    float64 angle table, ``qmle_run_batch_f64``.  Z / Z-parity observables are measured by the
+    engine; any other observable is applied to the complex128 state with torch (dense ``einsum``
+    over the observable's wires, ``simulation.py:263-269``)."""
+    torch = N.require_gpu()
+    angles = torch.from_numpy(low.angle_table(B, dtype=np.float64)).cuda()
+    if type != "expval":
+        return plan.run64(angles, type)
+    if not obs:
+        return torch.empty((B, 0), dtype=torch.float64, device=angles.device)
+    masks = [z_parity_mask(o) for o in obs]
+    if all(m is not None for m in masks) and len(obs) <= 32:
+        return plan.run64(angles, "expval", masks)
+    psi = plan.run64(angles, "state").reshape((B,) + (2,) * n_qubits)
+    cols = []
+    for ob, m in zip(obs, masks):
+        if m is not None:
+            cols.append(plan.run64(angles, "expval", [m])[:, 0])
+            continue
+        k = len(ob.wires)
+        M = torch.from_numpy(np.asarray(ob.matrix, dtype=np.complex128)).to(psi.device).reshape((2,) * (2 * k))
+        axes = [1 + w for w in ob.wires]
+        moved = torch.movedim(psi, axes, list(range(1, 1 + k)))
+        flat = moved.reshape(B, 2**k, -1)
+        applied = torch.einsum("rc,bcx->brx", M.reshape(2**k, 2**k), flat)
+        cols.append(torch.sum(torch.conj(flat) * applied, dim=(1, 2)).real)
+    return torch.stack(cols, dim=1)
 
 
 def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], n_qubits: int,

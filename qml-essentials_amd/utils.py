@@ -13,6 +13,45 @@ from typing import Optional, Sequence, Union
 import numpy as np
 
 
+# ---------------------------------------------------------------------------------------------
+# complex128 mode.  The reference selects its dtype through the global JAX switch
+# ``jax.config.update("jax_enable_x64", True)`` (``operations.py:12-16``; its own tests switch it
+# on: tests/test_coefficients.py:19, test_entanglement.py:13, test_ansaetze.py:18).  Same here:
+# ``enable_x64()`` makes every noise-free, shot-free execution run on the complex128 engine
+# (``qmle_run_batch_f64``): float64 angles, complex128 states, float64 results.  ``Model(...,
+# x64=True)`` scopes it to one model.  Default off (complex64, like JAX's default).
+# ---------------------------------------------------------------------------------------------
+_X64 = False
+
+
+def enable_x64(on: bool = True) -> None:
+    global _X64
+    _X64 = bool(on)
+
+
+def x64_enabled() -> bool:
+    return _X64
+
+
+class x64_scope:
+    """``with x64_scope(flag):`` -- temporarily force the mode (``None`` leaves it alone)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        global _X64
+        self.prev = _X64
+        if self.on is not None:
+            _X64 = bool(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        global _X64
+        _X64 = self.prev
+        return False
+
+
 class PRNGKey:
     """Immutable key; ``split`` derives independent children."""
 

@@ -1,0 +1,138 @@
+"""GPU: the complex128 engine (``qmle_run_batch_f64``; ``utils.enable_x64`` / ``Model(x64=True)``) --
+the reference's ``jax_enable_x64`` mode (``operations.py:12-16``, switched on by
+``tests/test_coefficients.py:19``).  Parity bar: 1e-10 against the complex128 oracle."""
+import numpy as np
+import pytest
+
+from oracle import circuits as OC
+from oracle import einsum_sim as OE
+from tests.helpers import random_tape, tape_to_native
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _plan_and_angles(tape, n):
+    from qml_essentials_amd import _native as N
+
+    ops, angles32, consts = tape_to_native(tape, n)
+    # (tape_to_native rounds the angle row to float32; the complex128 run takes the tape's own doubles)
+    angles = np.array([float(p) for name, _, params in tape if name != "Barrier" for p in params], dtype=np.float64)
+    assert angles.shape == angles32.shape
+    plan = N.Plan(ops, n, len(angles), consts, 0)
+    ang = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float64)[None, :]).cuda()
+    if ang.shape[1] == 0:
+        ang = torch.zeros((1, 1), dtype=torch.float64, device="cuda")[:, :0]
+    return plan, ang
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 11, 13, 14, 16])
+def test_random_circuits_state_probs_expval_vs_complex128_oracle(n):
+    """Every gate kind of the random tape generator; LDS regime (n <= 13) and the streaming
+    regime (14, 16)."""
+    rng = np.random.default_rng(640 + n)
+    tape = [g for g in random_tape(n, 40 if n > 1 else 10, rng) if g[0] not in ("MAT1", "MAT2")]
+    want = OE.simulate_pure(tape, n, np.complex128)
+    plan, ang = _plan_and_angles(tape, n)
+    got = plan.run64(ang, "state").cpu().numpy()[0]
+    assert got.dtype == np.complex128
+    assert np.abs(got - want).max() < 1e-12
+    probs = plan.run64(ang, "probs").cpu().numpy()[0]
+    assert probs.dtype == np.float64 and np.abs(probs - np.abs(want) ** 2).max() < 1e-12
+    groups = [[q] for q in range(n)] + ([[0, n - 1], list(range(min(n, 3)))] if n > 1 else [])
+    ez = plan.run64(ang, "expval", groups).cpu().numpy()[0]
+    idx = np.arange(2**n)
+    p = np.abs(want) ** 2
+    for k, g in enumerate(groups):
+        sign = np.ones(2**n)
+        for w in g:
+            sign *= 1 - 2 * ((idx >> (n - 1 - w)) & 1)
+        assert abs(ez[k] - np.dot(p, sign)) < 1e-12, (n, g)
+    if n <= 6:
+        rho = plan.run64(ang, "density").cpu().numpy()[0]
+        assert np.abs(rho - np.outer(want, want.conj())).max() < 1e-12
+
+
+def test_batch_rows_and_float32_engine_differ_at_float32_level_only():
+    """Same plan object, both engines: the complex64 result sits 1e-7 from the complex128 one."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n = 10
+    ops, slots = he_layer_ops(n)
+    ang64 = np.random.default_rng(7).uniform(0, 2 * np.pi, (5, slots))
+    plan = N.Plan(ops, n, slots)
+    e64 = plan.run64(torch.from_numpy(ang64).cuda(), "expval", [[q] for q in range(n)]).cpu().numpy()
+    e32 = plan.run(torch.from_numpy(ang64.astype(np.float32)).cuda(), "expval", list(range(n))).cpu().numpy()
+    assert e64.dtype == np.float64 and e32.dtype == np.float32
+    assert 0 < np.abs(e64 - e32).max() < 5e-6
+    spec = OC.ModelSpec(n, 1, "Hardware_Efficient", data_reupload=False)
+    for b in (0, 4):
+        tape = [("RY", [q], (ang64[b, q],)) for q in range(n)]  # he_layer_ops: RY, RZ, RY per wire, then the CX ring
+        tape = []
+        for i, g in enumerate(("RY", "RZ", "RY")):
+            tape += [(g, [q], (ang64[b, i * n + q],)) for q in range(n)]
+        tape += [("CX", list(w), ()) for w in OC.bricks(n, mirror=False) +
+                 OC.bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
+        want = OE.simulate_and_measure(tape, n, "expval", [("PauliZ", [q]) for q in range(n)], np.complex128)
+        assert np.abs(e64[b] - want).max() < 1e-12
+
+
+def test_model_x64_switch_and_scope():
+    """``Model(..., x64=True)`` and the global ``utils.enable_x64``: float64 results equal to the
+    complex128 oracle to 1e-10; the default stays complex64."""
+    from qml_essentials_amd import utils
+    from qml_essentials_amd.model import Model
+
+    rng = np.random.default_rng(11)
+    m64 = Model(5, 2, "Circuit_19", x64=True)
+    m32 = Model(5, 2, "Circuit_19")
+    P = rng.uniform(0, 2 * np.pi, (3, *m64.params.shape[1:]))
+    x = np.array([0.3, 1.1])
+    out64 = np.asarray(m64(params=P, inputs=x))
+    out32 = np.asarray(m32(params=P, inputs=x))
+    assert out64.dtype == np.float64 and out32.dtype == np.float32 and out64.shape == out32.shape
+    spec = OC.ModelSpec(5, 2, "Circuit_19")
+    for i, xi in enumerate(x):
+        for j in range(3):
+            want = OE.simulate_and_measure(OC.model_tape(spec, P[j], [xi], zero_inputs_batch1=False), 5, "expval",
+                                           [("PauliZ", [q]) for q in range(5)], np.complex128)
+            assert np.abs(out64[i, j] - want).max() < 1e-10
+    assert np.abs(out64 - out32).max() < 5e-6
+    assert not utils.x64_enabled()
+    utils.enable_x64()
+    try:
+        assert np.asarray(m32(params=P, inputs=x)).dtype == np.float64
+        st = np.asarray(m32(params=P[0], inputs=x[:1], execution_type="state"))
+        assert st.dtype == np.complex128
+    finally:
+        utils.enable_x64(False)
+    # (execution_type is sticky, as in the reference: model.py:1584-1585)
+    assert np.asarray(m32(params=P, inputs=x, execution_type="expval")).dtype == np.float32
+
+
+def test_general_observables_in_x64():
+    """A non-diagonal observable (PauliX, two-wire Hermitian matrix) on the complex128 state."""
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd import utils
+    from qml_essentials_amd.script import Script
+
+    def circuit(theta):
+        op.RY(theta, wires=0)
+        op.CX(wires=[0, 1])
+        op.RX(0.3, wires=2)
+
+    th = np.linspace(0.1, 2.9, 4)
+    utils.enable_x64()
+    try:
+        res = Script(circuit, n_qubits=3).execute(
+            type="expval", obs=[op.PauliX(0, record=False), op.PauliZ(1, record=False), op.PauliY(2, record=False)],
+            args=(th,), in_axes=(0,))
+    finally:
+        utils.enable_x64(False)
+    assert res.dtype == np.float64 and res.shape == (4, 3)
+    # <X_0> = 0 (entangled with wire 1), <Z_1> = cos(theta), <Y_2> = -sin(0.3)
+    assert np.abs(res[:, 0]).max() < 1e-12
+    assert np.abs(res[:, 1] - np.cos(th)).max() < 1e-12
+    assert np.abs(res[:, 2] + np.sin(0.3)).max() < 1e-12
