@@ -814,7 +814,7 @@ class Model:
     host_arrays_via_device = True
 
     def _forward_host_via_device(self, params, inputs, enc_params, execution_type, force_mean,
-                                 data_reupload):
+                                 data_reupload, as_tensor: bool = False):
         import torch
 
         if data_reupload is not None:
@@ -839,7 +839,7 @@ class Model:
         out = self._forward_device(p, x, enc_params, execution_type, force_mean)
         if out is NotImplemented:
             return NotImplemented
-        return out.cpu().numpy()
+        return out if as_tensor else out.cpu().numpy()
 
     def _forward(self, params=None, inputs=None, pulse_params=None, enc_params=None,
                  data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
@@ -867,12 +867,15 @@ class Model:
                 return out
             params = params.detach().cpu().numpy() if self._is_cuda(params) else params
             inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
-        if (not as_tensor and noise_params is None and self.noise_params is None
+        # (as_tensor: the analysis loops -- Expressibility, Meyer-Wallach -- ask for the raw device
+        # tensor of states; the compiled call serves them too: no tape re-recording per call)
+        if (noise_params is None and self.noise_params is None
                 and gate_mode == "unitary" and pulse_params is None and self.shots is None
                 and self.host_arrays_via_device and not self._is_cuda(params)
-                and not self._is_cuda(inputs) and not x64):
+                and not self._is_cuda(inputs) and not x64
+                and (not as_tensor or (execution_type or self.execution_type) == "state")):
             out = self._forward_host_via_device(params, inputs, enc_params, execution_type,
-                                                force_mean, data_reupload)
+                                                force_mean, data_reupload, as_tensor=as_tensor)
             if out is not NotImplemented:
                 return out
         if noise_params is not None:

@@ -140,6 +140,8 @@ def _install_fake_engine(calls):
 
     simulation.simulate_and_measure = fake_engine
     memory.available_memory_bytes = lambda: 1 << 40
+    from qml_essentials_amd.model import Model
+    Model.host_arrays_via_device = False  # no GPU here: every call takes the Script path (same my_block() split)
     N.require_gpu = lambda: torch
     N.pair_fidelity = lambda st: torch.from_numpy(
         OA.fidelities_pure(st.numpy(), st.shape[0] // 2).astype(np.float32))
