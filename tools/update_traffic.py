@@ -11,7 +11,13 @@ tag = sys.argv[4] if len(sys.argv) > 4 else "fused"   # "dense": the all-amplitu
 source = sys.argv[5] if len(sys.argv) > 5 else None
 # the all-live initialising pass = k_fill_zero (the zeros) + a k_tile2 launch for tile 0 of every state:
 # its fill traffic belongs to k_tile2's per-launch average (one k_tile2 launch per pass either way)
-if tag == "dense" and "k_fill_zero" in pm and "k_tile2" in pm:
+# (round 3: the initialising pass of the from-|0..0> variant is k_fill_zero + the GENERIC kernel on a
+# 2^14-amplitude tile -- then the fill belongs to k_tile and k_tile2's average covers passes 2 and 3)
+if tag == "dense" and "k_fill_zero" in pm and "k_tile" in pm and \
+        pm["k_tile"].get("launches") == pm["k_fill_zero"].get("launches"):
+    for key in ("hbm_read_bytes_per_launch_x2_corrected", "hbm_write_bytes_per_launch"):
+        pm["k_tile"][key] = pm["k_tile"].get(key, 0.0) + pm["k_fill_zero"].get(key, 0.0)
+elif tag == "dense" and "k_fill_zero" in pm and "k_tile2" in pm:
     f, k = pm["k_fill_zero"], pm["k_tile2"]
     share = f.get("launches", 0) / max(1, k.get("launches", 1))
     for key in ("hbm_read_bytes_per_launch_x2_corrected", "hbm_write_bytes_per_launch"):
@@ -32,6 +38,7 @@ for fam, d in pm.items():
 # Meyer-Wallach: bytes per qmle_meyer_wallach CALL = every k_mw_* launch of one call (tag "mw": the
 # counters come from tools/mw_bench.py, `states` = calls profiled)
 if tag == "mw":
+    states = pm.get("k_mw_purity", {}).get("launches", states)   # one purity launch per call
     rd = sum(d.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) * d.get("launches", 0)
              for f, d in pm.items() if f.startswith("k_mw")) / max(1, states)
     wr = sum(d.get("hbm_write_bytes_per_launch", 0.0) * d.get("launches", 0)
