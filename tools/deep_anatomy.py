@@ -9,7 +9,7 @@ from qml_essentials_amd import simulation
 from qml_essentials_amd.model import Model
 
 n, B = 24, int(os.environ.get("DEEP_B", "64"))
-flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB if os.environ.get("DEEP_DEFAULT") is None else 0
+flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB if os.environ.get("DEEP_DEFAULT") is None else int(os.environ["DEEP_DEFAULT"]) & ~1
 simulation.PLAN_FLAGS = flags
 model = Model(n, 4, "Hardware_Efficient", data_reupload=True)
 rng = np.random.default_rng(1000)
@@ -33,5 +33,6 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 ms, cnt, _ = plan.profile_end()
 per = [m / reps / B * 1e3 for m in ms]
+print("   stages:", [(s["T"], s["L"], s["bits"][s["L"] if s["L"] < s["T"] else 0:], s.get("expval_kernel"), bin(s["zero_in"]).count("1")) for s in d["stages"]], "absorbed", top.describe().get("absorbed_ops"))
 print(f"DBG={os.environ.get('QMLE_DBG_T2', '0')}: {e0.elapsed_time(e1) / reps / B * 1e3:.1f} us/state; per pass (groups: us): ",
       [(len(s.get('fast_groups') or s.get('groups') or []), round(t, 1)) for s, t in zip(d["stages"], per)], flush=True)

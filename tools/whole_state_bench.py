@@ -17,7 +17,7 @@ def he_ops(n, layers):
     return ops, slots
 
 
-for n, layers, B in ((10, 6, 4096), (12, 3, 2048), (13, 3, 2048), (9, 6, 4096)):
+for n, layers, B in ((10, 6, 65536), (12, 3, 32768), (13, 3, 16384), (10, 6, 4096), (12, 3, 2048)):
     ops, slots = he_ops(n, layers)
     ang = torch.from_numpy(np.random.default_rng(0).uniform(0, 6.28, (B, slots)).astype(np.float32)).cuda()
     plan = N.Plan(ops, n, slots)
