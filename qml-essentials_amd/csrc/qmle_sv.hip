@@ -1532,6 +1532,62 @@ __device__ __forceinline__ void tile_z_finish(float *out, float *red, float (&ac
   }
 }
 
+// TM_EXPVAL of k_tile2's whole-state tile (T == n >= 10: the tile index IS the amplitude index).
+// Every work item squares its 16 amplitudes once, in the load stage's layout: slot 2u + e has
+// index bit 0 = e and bits T-3.. = u, the lane holds bits 1..6, the wave index bits 7..T-4.  The
+// sign of an observable splits accordingly: the slot part is wave-uniform (8 signed adds on
+// sums or differences of slot pairs), the lane part one popcount, the wave part is applied by the
+// final sum.  Eight observables per round of DPP wave sums, one barrier in all -- tile_epilogue's
+// loop re-read the tile and ran a block sum per observable (a quarter of the kernel at 10 qubits).
+__device__ __forceinline__ void whole_state_expval(const TileArgs &a, uint32_t sl, const uint32_t (&soff)[8],
+                                                   float *red, int tid, int nt, int b) {
+  const int T = a.T, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int nw = nt >= kWave ? nt / kWave : 1;  // <= 8
+  float S[8], Df[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float4 w = lds_ld128(sl ^ soff[u]);
+    const float p0 = w.x * w.x + w.y * w.y, p1 = w.z * w.z + w.w * w.w;
+    S[u] = p0 + p1;
+    Df[u] = p0 - p1;
+  }
+  // (through the kernel argument segment: indexing the by-value struct with a run-time index
+  // makes hipcc copy it to scratch)
+  const uint32_t QMLE_CONSTANT *om =
+      (const uint32_t QMLE_CONSTANT *)((const char QMLE_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs, obs_mask));
+  const int n_obs = a.n_obs;
+  for (int k0 = 0; k0 < n_obs; k0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = 0.f;
+      if (k0 + k < n_obs) {  // (wave-uniform)
+        const uint32_t m = om[k0 + k];
+        const uint32_t mu = (m >> (T - 3)) & 7u;
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float d = (m & 1u) ? Df[u] : S[u];
+          t += (__popc((uint32_t)u & mu) & 1) ? -d : d;
+        }
+        v[k] = (__popc((uint32_t)lane & (m >> 1) & 63u) & 1) ? -t : t;
+      }
+    }
+    wave_sums_dpp63(v);
+    if (lane == kWave - 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(k0 + k) * 8 + wv] = v[k];
+    }
+  }
+  __syncthreads();
+  if (tid < n_obs) {
+    const uint32_t mw = om[tid] >> 7;
+    float r = 0.f;
+    for (int w = 0; w < nw; ++w) r += (__popc((uint32_t)w & mw) & 1) ? -red[tid * 8 + w] : red[tid * 8 + w];
+    reinterpret_cast<float *>(a.out)[(size_t)b * n_obs + tid] = r;
+  }
+}
+
 // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own instantiation: the storing kernel keeps
 // a small register budget).  MULTI: several tiles per workgroup (f.tpw), plain all-live stages
 // with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
@@ -1679,8 +1735,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
     } else if (MEASURE) {
-      if (!(f.dbg & 2))
-        tile_epilogue<false>(a, s, nullptr, red, tile + (uint32_t)i, n_tiles, b, base_cur, qsrc);
+      if (!(f.dbg & 2)) {
+        if (a.meas == TM_EXPVAL) whole_state_expval(a, sl, soff, red, tid, nt, b);
+        else tile_epilogue<false>(a, s, nullptr, red, tile + (uint32_t)i, n_tiles, b, base_cur, qsrc);
+      }
     } else if (a.meas == TM_STORE) {
       if (MULTI) {  // (the next tile's 8 float4 are live: two batches of four keep <= 96 VGPRs)
 #pragma unroll

@@ -628,3 +628,43 @@ def _he_ops(n):
     from tests.test_abi_cpu import he_layer_ops
 
     return he_layer_ops(n)
+
+
+@pytest.mark.parametrize("n", [10, 11, 12, 13])
+def test_whole_state_expval_epilogue_masks(n):
+    """k_tile2's whole-state <Z> epilogue (one LDS tile per sample, n = 10..13): single-wire and
+    parity observables whose positions fall on the work item's slots (positions 0, n-3..n-1), on
+    lane bits (1..6) and on the wave index (7..n-4), more than eight of them (two rounds of wave
+    sums), against the fp64 oracle -- `simulation.measure_state` (`simulation.py:241-261`)."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    rng = np.random.default_rng(4100 + n)
+    ops, slots = [], 0
+    for _ in range(2):
+        o, s = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s
+    B = 5
+    ang = rng.uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)
+    plan = N.Plan(ops, n, slots, flags=N.plan_flags(no_absorb=True))
+    st0 = plan.describe()["stages"][0]
+    assert plan.stats()["whole_state_lds"] == 1 and st0["fast"]
+    # wire w <-> position n - 1 - w
+    groups = [[w] for w in range(n)] + [[0, n - 1], [1, 2, n - 2], list(range(n)), [n - 1, n - 2, n - 3, n - 4],
+                                        [0, 1, 2], [n - 8, n - 9], [3, n - 1], [n // 2]]
+    if n >= 12:
+        groups += [[n - 8], [n - 9, 0], [n - 8, n - 2, 1]]
+    got = plan.run_parity(torch.from_numpy(ang).cuda(), groups).cpu().numpy()
+    z = plan.run(torch.from_numpy(ang).cuda(), "expval", list(range(n))).cpu().numpy()
+    idx = np.arange(2**n)
+    for b in range(B):
+        tape = [(g, w, [float(ang[b, s]) for s in sl]) for g, w, sl, _ in ops]
+        psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
+        pr = np.abs(psi) ** 2
+        for k, g in enumerate(groups):
+            par = np.zeros_like(idx)
+            for w in g:
+                par ^= (idx >> (n - 1 - w)) & 1
+            assert abs(got[b, k] - np.sum(pr * (1 - 2 * par))) < 2e-6, (b, k, g)
+        assert np.allclose(z[b], got[b, :n], atol=1e-7)

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <utility>
 #include <vector>
+#include <algorithm>
 
 #define CK(x)                                                                       \
   do {                                                                              \
@@ -335,6 +336,44 @@ __global__ void __launch_bounds__(kThreads) k_rw_any(const RwAnyArgs a) {
   }
 }
 
+// ---- T = 13 (512 work items, 9 high positions IN THE GIVEN ORDER): pos[0..2] are the three bits a
+// wave's instruction spans (its 8 rows of 128 B), pos[3..5] the wave index, pos[6..8] the 8 loads
+struct RwAny13Args {
+  float2 *st;
+  int n, q;
+  int pos[9];
+  int outer[20];
+};
+__global__ void __launch_bounds__(512) k_rw_any13(const RwAny13Args a) {
+  const uint32_t tid = threadIdx.x, jl = 2u * tid;
+  uint64_t goff = jl & 15u;
+  for (int k = 0; k < 6; ++k) goff |= (uint64_t)((jl >> (4 + k)) & 1u) << a.pos[k];
+  uint64_t uo[8];
+  static_for<8>([&](auto u) {
+    uo[u] = ((uint64_t)((u >> 0) & 1) << a.pos[6] | (uint64_t)((u >> 1) & 1) << a.pos[7] | (uint64_t)((u >> 2) & 1) << a.pos[8]) << 3;
+  });
+  char *st = reinterpret_cast<char *>(a.st) + (((size_t)blockIdx.y << a.n) << 3) + (goff << 3);
+  const uint32_t n_it = 1u << a.q, tile0 = blockIdx.x << a.q;
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const uint32_t t = tile0 + it;
+    uint64_t base = 0;
+    for (int i = 0; i < a.n - 13; ++i) base |= (uint64_t)((t >> i) & 1u) << a.outer[i];
+    base <<= 3;
+    vf4 v[8];
+    static_for<8>([&](auto u) { v[u] = ld4<true>(st + base + uo[u]); });
+    static_for<8>([&](auto u) { v[u].x += 1.0f; });
+    static_for<8>([&](auto u) { __builtin_nontemporal_store(v[u], reinterpret_cast<vf4 *>(st + base + uo[u])); });
+  }
+}
+
+// ---- workgroup dispatch rate: a kernel that touches its LDS once and writes one float per workgroup
+__global__ void k_dispatch_probe(float *out) {
+  extern __shared__ float probe_lds[];
+  probe_lds[threadIdx.x] = (float)threadIdx.x;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = probe_lds[(blockIdx.x + 1) % blockDim.x];
+}
+
 // two tiles per iteration (they differ in outer[0]): all 16 loads first, then the stores
 // MODE 0: stores A then B back to back; 1: store A, (delay), store B; 2: loads A, B interleaved per u
 template <int MODE>
@@ -638,6 +677,125 @@ int main(int argc, char **argv) {
         fflush(stdout);
       }
     }
+    return 0;
+  }
+  if (sweep == 6) {  // T = 13 orderings: argv[4] = states, argv[5] = mode (0: listed orders, 1: search), argv[6..] = "p0,..,p8" sets
+    const int states = argc > 4 ? atoi(argv[4]) : 32;
+    const int mode = argc > 5 ? atoi(argv[5]) : 0;
+    CK(hipFree(d));
+    CK(hipMalloc(&d, ((size_t)states << n) * 8));
+    CK(hipMemset(d, 0, ((size_t)states << n) * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_order = [&](const int *pos, int q) {
+      RwAny13Args a;
+      a.st = d; a.n = n; a.q = q;
+      uint32_t used = 15u;
+      for (int i = 0; i < 9; ++i) { a.pos[i] = pos[i]; used |= 1u << pos[i]; }
+      int no = 0;
+      for (int b = 4; b < n; ++b) if (!(used >> b & 1u)) a.outer[no++] = b;
+      const dim3 grid((1u << (n - 13)) >> q, states);
+      for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_rw_any13, grid, dim3(512), 0, 0, a);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_rw_any13, grid, dim3(512), 0, 0, a);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      return ms / reps * 1e3 / states;
+    };
+    if (mode == 2) {  // data for the scheduler's cost model: random 9-subsets of 4..n-1, sorted + random orders
+      const int n_sets = argc > 6 ? atoi(argv[6]) : 200, n_orders = argc > 7 ? atoi(argv[7]) : 4;
+      uint64_t rs = 0x9E3779B97F4A7C15ull;
+      auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); };
+      for (int si = 0; si < n_sets; ++si) {
+        int cand[32], nc = 0;
+        for (int b = 4; b < n; ++b) cand[nc++] = b;
+        for (int i = 0; i < 9; ++i) { const int j = i + rnd() % (nc - i); std::swap(cand[i], cand[j]); }
+        int set[9];
+        for (int i = 0; i < 9; ++i) set[i] = cand[i];
+        std::sort(set, set + 9);
+        for (int oi = 0; oi <= n_orders; ++oi) {
+          int o[9];
+          for (int i = 0; i < 9; ++i) o[i] = set[i];
+          if (oi) for (int i = 0; i < 9; ++i) { const int j = i + rnd() % (9 - i); std::swap(o[i], o[j]); }
+          const float us = time_order(o, 0);
+          printf("D %d %.2f", oi, us);
+          for (int i = 0; i < 9; ++i) printf(" %d", o[i]);
+          printf("\n");
+        }
+        if (si % 20 == 0) fflush(stdout);
+      }
+      return 0;
+    }
+    for (int ai = 6; ai < argc; ++ai) {
+      int set[9], k = 0;
+      const char *c = argv[ai];
+      for (; *c && k < 9;) { set[k++] = atoi(c); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+      if (k != 9) { printf("need 9 positions: %s\n", argv[ai]); continue; }
+      if (mode == 0) {
+        for (int q = 0; q <= 2; ++q) printf("rw13 {%s} q=%d: %7.2f us/state\n", argv[ai], q, time_order(set, q));
+        fflush(stdout);
+        continue;
+      }
+      // search: every choice of the wave's three positions x every choice of the three load positions
+      // (the remaining three index the wave); ascending inside each class; the given order is the baseline
+      struct R { float us; int o[9]; };
+      std::vector<R> res;
+      const float base0 = time_order(set, 0);
+      for (int m1 = 0; m1 < 512; ++m1) {
+        if (__builtin_popcount(m1) != 3) continue;
+        for (int m2 = 0; m2 < 512; ++m2) {
+          if (__builtin_popcount(m2) != 3 || (m1 & m2)) continue;
+          R r;
+          int w = 0;
+          for (int i = 0; i < 9; ++i) if (m1 >> i & 1) r.o[w++] = set[i];
+          for (int i = 0; i < 9; ++i) if (!((m1 | m2) >> i & 1)) r.o[w++] = set[i];
+          for (int i = 0; i < 9; ++i) if (m2 >> i & 1) r.o[w++] = set[i];
+          r.us = time_order(r.o, 0);
+          res.push_back(r);
+        }
+      }
+      const float base1 = time_order(set, 0);
+      std::sort(res.begin(), res.end(), [](const R &x, const R &y) { return x.us < y.us; });
+      printf("set {%s}: given order %.2f / %.2f us/state; %zu orders, median %.2f, worst %.2f\n", argv[ai], base0, base1,
+             res.size(), res[res.size() / 2].us, res.back().us);
+      for (int i = 0; i < 12 && i < (int)res.size(); ++i) {
+        printf("   %.2f :", res[i].us);
+        for (int j = 0; j < 9; ++j) printf(" %d%s", res[i].o[j], j == 2 || j == 5 ? " |" : "");
+        printf("\n");
+      }
+      // what decides: the best time per wave triple (over the load triples)
+      std::vector<R> best;
+      for (auto &r : res) {
+        bool seen = false;
+        for (auto &b : best) if (b.o[0] == r.o[0] && b.o[1] == r.o[1] && b.o[2] == r.o[2]) { seen = true; break; }
+        if (!seen) best.push_back(r);
+      }
+      printf("   best per wave triple:");
+      for (int i = 0; i < (int)best.size(); ++i) printf("%s {%d,%d,%d} %.1f", i % 8 == 0 ? "\n     " : "", best[i].o[0], best[i].o[1], best[i].o[2], best[i].us);
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
+  if (sweep == 7) {  // dispatch rate: argv[4] = workgroups; block sizes 64..512 x LDS 1..64 KiB
+    const int wgs = argc > 4 ? atoi(argv[4]) : 65536;
+    float *o;
+    CK(hipMalloc(&o, (size_t)wgs * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int threads = 64; threads <= 512; threads *= 2)
+      for (int kib = 1; kib <= 64; kib *= 2) {
+        const int g = wgs * 64 / threads;  // same number of waves
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_dispatch_probe, dim3(g), dim3(threads), kib * 1024, 0, o);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_dispatch_probe, dim3(g), dim3(threads), kib * 1024, 0, o);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("dispatch: %6d workgroups x %3d threads, %2d KiB LDS: %7.1f us per launch (%.1f workgroups/us, %.1f waves/us)\n", g, threads, kib,
+               ms / reps * 1e3, g / (ms / reps * 1e3), (double)g * threads / 64 / (ms / reps * 1e3));
+      }
     return 0;
   }
   if (sweep == 1) {  // sustained (thermal steady state): `reps` launches per line, the set run twice
