@@ -815,6 +815,17 @@ int compile_plan(qmle_plan *p) {
       } else {
         st.kind = ST_TILE;
         // pad the tile with the lowest free bit positions
+        // (tuning: QMLE_PAD_HIGH=1 pads the LAST stage from the top instead)
+        const int pad_high_env = std::getenv("QMLE_PAD_HIGH") ? atoi(std::getenv("QMLE_PAD_HIGH")) : 0;
+        if (pad_high_env && !p->stages.empty() && n_done + members.size() == nl) {
+          if (carry >= stageL && carry < n && (Q & bit(carry))) {  // the carried position serves read+write passes
+            uint64_t need = 0;
+            for (int mi : members) need |= op_mask(p->lowered[mi], n);
+            if (!(need & bit(carry))) Q &= ~bit(carry);
+          }
+          if (pad_high_env >= 2 && popc(Q) < T) Q |= bit(pad_high_env);  // (one chosen low position)
+          for (int b = n - 1; b >= 0 && popc(Q) < T; --b) Q |= bit(b);
+        }
         for (int b = 0; b < n && popc(Q) < T; ++b) Q |= bit(b);
         st.T = popc(Q);
         int nt = 0, no = 0;
@@ -1007,7 +1018,7 @@ int compile_plan(qmle_plan *p) {
       if (c < best_cost * (k >= 12 && best < 12 ? 0.98 : 1.0) - 1e-9) { best_cost = c; best = k; }
     }
     // (tuning only: force one of the candidates to measure it against the model's choice)
-    static const int force = std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;
+    const int force = std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;  // (read per compile: tools/cand_sweep.py)
     if (force >= 0 && force < 48 && cand[force % 6][0] < n && (force < 12 || zero_run)) best = force;
     run_cand(best);
     p->chosen_candidate = best;

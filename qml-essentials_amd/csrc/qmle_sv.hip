@@ -4696,7 +4696,7 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
       v->flags = flags | QMLE_PLAN_INTERNAL_ZERO_RUN;
       v->ops = p->ops;
       v->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
-      static const bool forced = std::getenv("QMLE_FORCE_CAND") != nullptr;  // (tuning: always run the forced schedule)
+      const bool forced = std::getenv("QMLE_FORCE_CAND") != nullptr;  // (tuning: always run the forced schedule)
       if (compile_plan(v) == QMLE_OK && v->mat_floats == p->mat_floats && (forced || v->model_cost < p->model_cost - 0.5))
         p->zero_variant = v;
       else

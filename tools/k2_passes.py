@@ -7,8 +7,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qml_essentials_amd import _native as N
 from tests.test_abi_cpu import he_layer_ops
 
-n, B = 24, int(os.environ.get("K2_B", "128"))
-ops, slots = he_layer_ops(n)
+n = int(os.environ.get("K2_N", "24"))
+B = int(os.environ.get("K2_B", str(max(2, 128 >> max(0, n - 24)) if n >= 24 else 128 << min(4, 24 - n))))
+layers = int(os.environ.get("K2_LAYERS", "1"))
+ops, slots = [], 0
+for _ in range(layers):
+    o, s_ = he_layer_ops(n)
+    ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+    slots += s_
 ang = torch.from_numpy(np.random.default_rng(1000).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
 flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
 top = N.Plan(ops, n, slots, flags=flags)

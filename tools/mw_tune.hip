@@ -374,6 +374,31 @@ __global__ void k_dispatch_probe(float *out) {
   if (threadIdx.x == 0) out[blockIdx.x] = probe_lds[(blockIdx.x + 1) % blockDim.x];
 }
 
+// read-only walk of T = 12 tiles with 8 high positions in the given order (the measuring pass's
+// memory side): pos[0..2] span a wave's instruction, pos[3..4] the wave index, pos[5..7] the 8 loads
+__global__ void __launch_bounds__(kThreads) k_ro_any(const RwAnyArgs a, float *sink) {
+  const uint32_t tid = threadIdx.x, jl = 2u * tid;
+  uint64_t goff = jl & 15u;
+  for (int k = 0; k < 5; ++k) goff |= (uint64_t)((jl >> (4 + k)) & 1u) << a.pos[k];
+  uint64_t uo[8];
+  static_for<8>([&](auto u) {
+    uo[u] = ((uint64_t)((u >> 0) & 1) << a.pos[5] | (uint64_t)((u >> 1) & 1) << a.pos[6] | (uint64_t)((u >> 2) & 1) << a.pos[7]) << 3;
+  });
+  const char *st = reinterpret_cast<const char *>(a.st) + (((size_t)blockIdx.y << a.n) << 3) + (goff << 3);
+  const uint32_t n_it = 1u << a.q, tile0 = blockIdx.x << a.q;
+  float acc = 0.f;
+  for (uint32_t it = 0; it < n_it; ++it) {
+    const uint32_t t = tile0 + it;
+    uint64_t base = 0;
+    for (int i = 0; i < a.n - 12; ++i) base |= (uint64_t)((t >> i) & 1u) << a.outer[i];
+    base <<= 3;
+    vf4 v[8];
+    static_for<8>([&](auto u) { v[u] = ld4<true>(st + base + uo[u]); });
+    static_for<8>([&](auto u) { acc += v[u].x * v[u].y + v[u].z * v[u].w; });
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
 // two tiles per iteration (they differ in outer[0]): all 16 loads first, then the stores
 // MODE 0: stores A then B back to back; 1: store A, (delay), store B; 2: loads A, B interleaved per u
 template <int MODE>
@@ -796,6 +821,72 @@ int main(int argc, char **argv) {
         printf("dispatch: %6d workgroups x %3d threads, %2d KiB LDS: %7.1f us per launch (%.1f workgroups/us, %.1f waves/us)\n", g, threads, kib,
                ms / reps * 1e3, g / (ms / reps * 1e3), (double)g * threads / 64 / (ms / reps * 1e3));
       }
+    return 0;
+  }
+  if (sweep == 8) {  // read-only T = 12 shapes holding argv[5] ("p,q,..": forced positions), argv[4] = states, argv[6] = q
+    const int states = argc > 4 ? atoi(argv[4]) : 32;
+    const int q = argc > 6 ? atoi(argv[6]) : 2;
+    CK(hipFree(d));
+    CK(hipMalloc(&d, ((size_t)states << n) * 8));
+    CK(hipMemset(d, 0, ((size_t)states << n) * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_order = [&](const int *pos) {
+      RwAnyArgs a;
+      a.st = d; a.n = n; a.q = q;
+      uint32_t used = 15u;
+      for (int i = 0; i < 8; ++i) { a.pos[i] = pos[i]; used |= 1u << pos[i]; }
+      int no = 0;
+      for (int b = 4; b < n; ++b) if (!(used >> b & 1u)) a.outer[no++] = b;
+      const dim3 grid((1u << (n - 12)) >> q, states);
+      for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_ro_any, grid, dim3(kThreads), 0, 0, a, rows);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_ro_any, grid, dim3(kThreads), 0, 0, a, rows);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      return ms / reps * 1e3 / states;
+    };
+    int forced[8], nf = 0;
+    if (argc > 5) { const char *c = argv[5]; for (; *c && nf < 8;) { forced[nf++] = atoi(c); while (*c && *c != ',') ++c; if (*c == ',') ++c; } }
+    uint32_t fm = 0;
+    for (int i = 0; i < nf; ++i) fm |= 1u << forced[i];
+    struct R { float us; int o[8]; };
+    std::vector<R> res;
+    const int need = 8 - nf;
+    for (uint32_t m = 0; m < (1u << n); m += 16) {  // candidate sets of positions 4..n-1
+      if (m & fm) continue;
+      if (__builtin_popcount(m) != need) continue;
+      R r; int w = 0;
+      for (int b = 4; b < n; ++b) if (((m | fm) >> b) & 1u) r.o[w++] = b;
+      r.us = time_order(r.o);
+      res.push_back(r);
+    }
+    std::sort(res.begin(), res.end(), [](const R &x, const R &y) { return x.us < y.us; });
+    printf("read-only T=12, forced {%s}, q=%d: %zu sets (ascending order); median %.2f worst %.2f us/state\n", argc > 5 ? argv[5] : "", q, res.size(),
+           res[res.size() / 2].us, res.back().us);
+    for (int i = 0; i < (std::getenv("RO_ALL") ? (int)res.size() : 25) && i < (int)res.size(); ++i) {
+      printf("   %.2f :", res[i].us);
+      for (int j = 0; j < 8; ++j) printf(" %d", res[i].o[j]);
+      printf("\n");
+    }
+    // orders of the best three sets: every wave triple, rest ascending
+    for (int bi = 0; bi < 3 && bi < (int)res.size(); ++bi) {
+      const R base = res[bi];
+      std::vector<R> ord;
+      for (int m1 = 0; m1 < 256; ++m1) {
+        if (__builtin_popcount(m1) != 3) continue;
+        R r; int w = 0;
+        for (int i = 0; i < 8; ++i) if (m1 >> i & 1) r.o[w++] = base.o[i];
+        for (int i = 0; i < 8; ++i) if (!(m1 >> i & 1)) r.o[w++] = base.o[i];
+        r.us = time_order(r.o);
+        ord.push_back(r);
+      }
+      std::sort(ord.begin(), ord.end(), [](const R &x, const R &y) { return x.us < y.us; });
+      printf("  orders of set %d (ascending %.2f): best", bi, time_order(base.o));
+      for (int i = 0; i < 4; ++i) { printf("  %.2f [", ord[i].us); for (int j = 0; j < 8; ++j) printf("%d%s", ord[i].o[j], j == 2 ? " | " : j < 7 ? "," : "]"); }
+      printf("  worst %.2f\n", ord.back().us);
+    }
     return 0;
   }
   if (sweep == 1) {  // sustained (thermal steady state): `reps` launches per line, the set run twice
