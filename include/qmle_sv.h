@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 140 /* 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 141 /* 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -272,6 +272,14 @@ size_t qmle_meyer_wallach_workspace_bytes(int n_qubits, int batch);
  * bench.py's bytes-moved accounting): the passes of the tile scheme from 12 qubits on, one
  * cache-resident sweep per wire below */
 int qmle_meyer_wallach_reads(int n_qubits);
+/* Host only, no device work: out[i] = the i-th value of
+ * numpy.random.Generator(numpy.random.Philox(key=key)).uniform(low, high, n).astype(float32),
+ * bit for bit (Philox4x64-10, numpy's counter and double conventions).  The parameter sampler
+ * behind Model.initialize_params -- the reference's jax.random.uniform (model.py:687-693) runs
+ * on a threefry stream that cannot be reproduced here; the build's stream is
+ * numpy's Philox, and numpy's own loop (~9 ns per value) was two thirds of the wall-clock of
+ * Expressibility(12 q, 1024 pairs). */
+int qmle_philox_uniform_f32(const uint64_t key[2], uint64_t n, double low, double high, float *out);
 /* numpy.histogram(values, bins=linspace(lo,hi,n_bins+1)) counts (last bin
  * right-inclusive) -- expressibility.py:104-108; d_counts int32[n_bins], zeroed
  * by the call */

@@ -121,6 +121,7 @@ SYMBOLS = [
     ("qmle_meyer_wallach", _I, [_VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_meyer_wallach_reads", _I, [_I]),
+    ("qmle_philox_uniform_f32", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP]),
     ("qmle_run_batch_f64", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_workspace_bytes_f64", _SZ, [_VP, _I, _I]),
     ("qmle_plan_set_consts_f64", _I, [_VP, C.POINTER(C.c_double), _I]),
@@ -596,6 +597,18 @@ def meyer_wallach(states, return_purities: bool = False):
 def mw_reads(n_qubits: int) -> int:
     """HBM reads of the state per ``meyer_wallach`` call at this size (host only)."""
     return int(lib().qmle_meyer_wallach_reads(int(n_qubits)))
+
+
+def philox_uniform(key, count: int, low: float, high: float) -> np.ndarray:
+    """``numpy.random.Generator(numpy.random.Philox(key=key)).uniform(low, high, count)
+    .astype(float32)``, bit for bit, from the library's host-side generator (no GPU involved)."""
+    key = np.ascontiguousarray(key, dtype=np.uint64)
+    if key.shape != (2,):
+        raise ValueError("Philox4x64 takes a key of two 64-bit words")
+    out = np.empty(int(count), dtype=np.float32)
+    check(lib().qmle_philox_uniform_f32(key.ctypes.data, int(count), float(low), float(high),
+                                          out.ctypes.data))
+    return out
 
 
 def histogram(values, n_bins: int, lo: float = 0.0, hi: float = 1.0):

@@ -8,6 +8,7 @@ Philox counter RNG, which like threefry is keyed and splittable.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence, Union
 
 import numpy as np
@@ -98,8 +99,17 @@ def safe_random_split(random_key: Optional[PRNGKey], *args, num: int = 2, **kwar
 
 def uniform(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
             maxval: float = 1.0) -> np.ndarray:
-    g = as_key(random_key).generator()
-    return g.uniform(minval, maxval, size=tuple(shape)).astype(np.float32)
+    # numpy's Philox4x64-10 stream under the key's SeedSequence, produced by the library's host-side
+    # generator (csrc/qmle_rng.cpp: the same floats, bit for bit -- tests/test_abi_cpu.py -- at a
+    # fraction of numpy's ~9 ns per value; QMLE_NUMPY_SAMPLER=1 takes numpy's own loop)
+    k = as_key(random_key)
+    shape = tuple(int(d) for d in shape)
+    if os.environ.get("QMLE_NUMPY_SAMPLER"):
+        return k.generator().uniform(minval, maxval, size=shape).astype(np.float32)
+    from . import _native as N
+
+    n = int(np.prod(shape)) if shape else 1
+    return N.philox_uniform(k._seq.generate_state(2, np.uint64), n, minval, maxval).reshape(shape)
 
 
 class random:  # namespace so that ``from ...utils import random; random.key(0)`` reads like jax

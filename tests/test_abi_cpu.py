@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_header_symbols():
     lib = N.lib()
-    assert lib.qmle_sv_version() == 140
+    assert lib.qmle_sv_version() == 141
     header = open(os.path.join(ROOT, "include", "qmle_sv.h")).read()
     declared = set(re.findall(r"\b(qmle_[a-z_0-9]+)\s*\(", header))
     declared -= {"qmle_op", "qmle_plan"}
@@ -291,3 +291,35 @@ def test_fast_tile_groups_fold_cx_into_the_layout():
     # forced geometries outside 10..13 tile bits fall back as well
     small = N.Plan(ops, 24, slots, flags=N.PLAN_NO_SPARSE | N.plan_flags(tile_bits=8, low_bits=4))
     assert not any(s["fast"] for s in small.describe()["stages"])
+
+
+def test_philox_sampler_is_numpys_stream_bit_for_bit():
+    """qmle_philox_uniform_f32 (host-side, csrc/qmle_rng.cpp) == numpy's Philox4x64-10 stream
+    through Generator.uniform + float32 cast: every length around the block / batch / thread
+    boundaries, spawned keys, other ranges -- and `utils.uniform`, the sampler behind
+    `Model.initialize_params` (reference: `model.py:687-693`, threefry stream: SURVEY 8-c), draws
+    the same parameters with either loop."""
+    import os
+
+    from qml_essentials_amd import utils
+
+    for seed in (0, 1000, 2**40 + 3):
+        for n in (0, 1, 2, 3, 4, 5, 11, 12, 13, 31, 32, 33, 16383, 16384, 32767, 32769, 73728, 131072, 262147):
+            seq = np.random.SeedSequence(seed)
+            ref = np.random.Generator(np.random.Philox(np.random.SeedSequence(seed))).uniform(0, 2 * np.pi, n).astype(np.float32)
+            got = N.philox_uniform(seq.generate_state(2, np.uint64), n, 0.0, 2 * np.pi)
+            assert np.array_equal(ref, got), (seed, n)
+    for child in np.random.SeedSequence(5).spawn(3):
+        ref = np.random.Generator(np.random.Philox(child)).uniform(-1.5, 3.25, 1001).astype(np.float32)
+        again = np.random.SeedSequence(entropy=child.entropy, spawn_key=child.spawn_key)
+        assert np.array_equal(ref, N.philox_uniform(again.generate_state(2, np.uint64), 1001, -1.5, 3.25))
+    k = utils.key(7).split(3)[1]
+    mine = utils.uniform(k, (64, 3, 11), 0.0, 2 * np.pi)
+    os.environ["QMLE_NUMPY_SAMPLER"] = "1"
+    try:
+        theirs = utils.uniform(k, (64, 3, 11), 0.0, 2 * np.pi)
+    finally:
+        del os.environ["QMLE_NUMPY_SAMPLER"]
+    assert mine.dtype == np.float32 and mine.shape == theirs.shape and np.array_equal(mine, theirs)
+    with pytest.raises(ValueError):
+        N.philox_uniform(np.zeros(3, np.uint64), 4, 0.0, 1.0)
