@@ -1576,14 +1576,14 @@ __device__ __forceinline__ void whole_state_expval(const TileArgs &a, uint32_t s
     wave_sums_dpp63(v);
     if (lane == kWave - 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) red[(k0 + k) * 8 + wv] = v[k];
+      for (int k = 0; k < 8; ++k) red[(k0 + k) * nw + wv] = v[k];  // (k0 + k < 32: launch_tile sizes red as 32 x nw)
     }
   }
   __syncthreads();
   if (tid < n_obs) {
     const uint32_t mw = om[tid] >> 7;
     float r = 0.f;
-    for (int w = 0; w < nw; ++w) r += (__popc((uint32_t)w & mw) & 1) ? -red[tid * 8 + w] : red[tid * 8 + w];
+    for (int w = 0; w < nw; ++w) r += (__popc((uint32_t)w & mw) & 1) ? -red[tid * nw + w] : red[tid * nw + w];
     reinterpret_cast<float *>(a.out)[(size_t)b * n_obs + tid] = r;
   }
 }
@@ -4435,7 +4435,10 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     if (dbg & 1) f.n_groups = 0;
     // T >= 10: the per-tile epilogues' scratch fits inside the tile; the whole-state <Z> epilogue
     // reduces while amplitudes are still being read and gets its own 288 floats
-    const size_t lds2 = ((size_t)8 << st.T) + (meas == TM_EXPVAL ? 288 * sizeof(float) : 0);
+    // (whole_state_expval: one float per observable and wave -- 128 B at 10 qubits instead of the
+    // 1152 B of round 2's epilogue: 18-19 instead of 17 single-wave workgroups per CU)
+    const size_t lds2 = ((size_t)8 << st.T) +
+                        (meas == TM_EXPVAL ? (size_t)QMLE_MAX_QUBITS * (threads >= kWave ? threads / kWave : 1) * sizeof(float) : 0);
     const bool measure = !(meas == TM_STORE || meas == TM_PROBS);
 #define QMLE_T2_GO(NT, ME, MU) \
   hipLaunchKernelGGL((k_tile2<NT, ME, MU>), grid, dim3(threads), lds2, stream, a, f)
