@@ -668,3 +668,32 @@ def test_whole_state_expval_epilogue_masks(n):
                 par ^= (idx >> (n - 1 - w)) & 1
             assert abs(got[b, k] - np.sum(pr * (1 - 2 * par))) < 2e-6, (b, k, g)
         assert np.allclose(z[b], got[b, :n], atol=1e-7)
+
+
+def test_last_stage_padding_switch_changes_the_tile_not_the_result(monkeypatch):
+    """QMLE_PAD_HIGH (tuning switch): the last stage's spare tile positions come from the
+    top -- another tile, the same <Z> as the default schedule and as the C-side oracle path."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n = 20
+    ops, slots = he_layer_ops(n)
+    ang = torch.from_numpy(np.random.default_rng(77).uniform(0, 2 * np.pi, (3, slots)).astype(np.float32)).cuda()
+    flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
+    base = N.Plan(ops, n, slots, flags=flags)
+    want = base.run(ang, "expval", list(range(n))).cpu().numpy()
+    tiles = {}
+    for v in ("1", "8"):
+        monkeypatch.setenv("QMLE_PAD_HIGH", v)
+        p = N.Plan(ops, n, slots, flags=flags)
+        tiles[v] = (p.expval_child() or p).describe()["stages"][-1]["bits"]
+        got = p.run(ang, "expval", list(range(n))).cpu().numpy()
+        assert np.allclose(got, want, atol=2e-6), (v, np.abs(got - want).max())
+    monkeypatch.delenv("QMLE_PAD_HIGH")
+    default_tile = (base.expval_child() or base).describe()["stages"][-1]["bits"]
+    assert tiles["1"] != default_tile or tiles["8"] != default_tile
+    tape = [(g, w, [float(ang[0, s]) for s in sl]) for g, w, sl, _ in ops]
+    psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
+    pr = (np.abs(psi) ** 2).reshape((2,) * n)
+    z = [float(pr.take(0, axis=w).sum() - pr.take(1, axis=w).sum()) for w in range(n)]
+    assert np.allclose(want[0], z, atol=2e-6)
