@@ -462,6 +462,64 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=5):
             "note": "median of %d calls, max over ranks; device -> host copy + host FFT included" % reps}
 
 
+def sampling_loops_cpu(budget_pairs=128, budget_points=384):
+    """CPU restatement of BASELINE configs 3 and 4 timed beside the GPU legs (rank 0, N = 1): the
+    NumPy-einsum oracle (oracle/einsum_sim.py, one thread, complex64 like the reference's default)
+    on a bounded sample of the SAME parameter sets / grid points, extrapolated to the full loop, and
+    compared with the GPU's fidelities / expectation values (complex128 oracle, 1e-6)."""
+    from oracle import circuits as OC, einsum_sim as OE
+    from qml_essentials_amd.expressibility import Expressibility
+    from qml_essentials_amd.model import Model
+
+    out = {}
+    n, S = 12, 1024
+    m = Model(n, 3, "Hardware_Efficient", data_reupload=False)
+    fid = Expressibility._sample_state_fidelities(m, S, random_key=1000).cpu().numpy()
+    params = np.asarray(m.params)
+    spec = OC.ModelSpec(n, 3, "Hardware_Efficient", data_reupload=False)
+    idx = np.random.default_rng(0).choice(S, budget_pairs, replace=False)
+    t0 = time.perf_counter()
+    for i in idx:
+        a = OE.simulate_pure(OC.model_tape(spec, params[i], [0.0]), n, np.complex64)
+        b = OE.simulate_pure(OC.model_tape(spec, params[i + S], [0.0]), n, np.complex64)
+        abs(np.vdot(a, b)) ** 2
+    sec = time.perf_counter() - t0
+    worst = 0.0
+    for i in idx[:8]:
+        a = OE.simulate_pure(OC.model_tape(spec, params[i], [0.0]), n, np.complex128)
+        b = OE.simulate_pure(OC.model_tape(spec, params[i + S], [0.0]), n, np.complex128)
+        worst = max(worst, abs(float(fid[i]) - abs(np.vdot(a, b)) ** 2))
+    if worst > 1e-5:
+        raise SystemExit(f"bench.py: GPU fidelities differ from the CPU oracle by {worst:.3e}")
+    out["c3"] = {"seconds_full_loop_extrapolated": round(sec * S / budget_pairs, 3), "cores": 1, "kind": "port",
+                 "sample": f"{budget_pairs} of the {S} pairs ({2 * budget_pairs} statevectors, 144 gates each), "
+                           f"oracle/einsum_sim.py complex64, {sec:.2f} s",
+                 "max_abs_diff_gpu_vs_fp64_oracle": worst}
+    n, G = 10, 4096
+    m = Model(n, 6, "Hardware_Efficient")
+    p = np.asarray(m.params[0])
+    grid = (np.arange(G, dtype=np.float64) * 2 * np.pi / G).astype(np.float32).reshape(G, 1)
+    gpu = np.asarray(m(inputs=grid, force_mean=True))
+    spec = OC.ModelSpec(n, 6, "Hardware_Efficient")
+    obs = [("PauliZ", [q]) for q in range(n)]
+    idx = np.random.default_rng(1).choice(G, budget_points, replace=False)
+    t0 = time.perf_counter()
+    for k in idx:
+        OE.simulate_and_measure(OC.model_tape(spec, p, [float(grid[k, 0])]), n, "expval", obs, np.complex64)
+    sec = time.perf_counter() - t0
+    worst = 0.0
+    for k in idx[:8]:
+        want = OE.simulate_and_measure(OC.model_tape(spec, p, [float(grid[k, 0])]), n, "expval", obs, np.complex128)
+        worst = max(worst, abs(float(gpu[k]) - float(np.mean(want))))
+    if worst > 1e-5:
+        raise SystemExit(f"bench.py: GPU grid values differ from the CPU oracle by {worst:.3e}")
+    out["c4"] = {"seconds_full_loop_extrapolated": round(sec * G / budget_points, 3), "cores": 1, "kind": "port",
+                 "sample": f"{budget_points} of the {G} grid points (340 gates + <Z> on 10 wires each), "
+                           f"oracle/einsum_sim.py complex64, {sec:.2f} s",
+                 "max_abs_diff_gpu_vs_fp64_oracle": worst}
+    return out
+
+
 def lds_regime_leg(n, layers, dru, batch, meas, reps=10):
     """Whole-state-in-LDS regime (n <= 14): circuit (+ measurement) of `batch` states in ONE launch;
     `kernel_ms` = HIP events around the whole call on the GPU (angle table, fp64 matrix builder,
@@ -829,6 +887,17 @@ def main(argv=None):
             result["cpu_baseline"]["other_legs"] = {"error": str(e)}
         del head
         torch.cuda.empty_cache()
+        # BASELINE configs 3 / 4 on the host's CPU (bounded sample of the same loops) + parity
+        try:
+            cpu_loops = sampling_loops_cpu()
+            if c3 is not None:
+                c3["cpu_baseline"] = cpu_loops["c3"]
+            if c4 is not None:
+                c4["cpu_baseline"] = cpu_loops["c4"]
+        except SystemExit:
+            raise
+        except Exception as e:  # pragma: no cover
+            result["sampling_loops_cpu_error"] = str(e)
         # LDS-resident regime (n <= 14 is bound by LDS / fp32 VALU, not by HBM)
         try:
             result["lds_regime"] = {
