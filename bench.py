@@ -654,6 +654,36 @@ def mw_28q_leg(n=28, reps=100, warmup=25):
                                  "fetched per call"}}
 
 
+def mw_cpu_baseline(n_small=24, n_full=28):
+    """CPU restatement of BASELINE config 5 beside the GPU leg: the NumPy oracle's qubit purities
+    (oracle/analysis.py, one thread) on the same kind of state at n_small qubits -- one 2^28 state
+    costs the oracle minutes -- extrapolated by the state size, and compared with the GPU's
+    purities of that very state."""
+    from oracle import analysis as OA
+    from oracle.circuits import bricks
+    from qml_essentials_amd import _native as N
+
+    n = n_small
+    ops = [(g, [q], [i * n + q], -1) for i, g in enumerate(("RY", "RZ", "RY")) for q in range(n)]
+    ops += [("CX", [a, b], [], -1) for a, b in bricks(n, mirror=False) +
+            bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
+    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, 3 * n)).astype(np.float32)).cuda()
+    st = N.Plan(ops, n, 3 * n).run(ang, "state")
+    q, pur = N.meyer_wallach(st, return_purities=True)
+    psi = st[0].cpu().numpy()
+    t0 = time.perf_counter()
+    OA.qubit_purities_pure(psi, n)  # complex64, like the reference's default: the timed run
+    sec = time.perf_counter() - t0
+    want = OA.qubit_purities_pure(psi.astype(np.complex128), n)  # the checker: fp64 sums
+    worst = float(np.abs(pur[0].cpu().numpy().astype(np.float64) - want).max())
+    if worst > 1e-5:
+        raise SystemExit(f"bench.py: GPU qubit purities differ from the CPU oracle by {worst:.3e}")
+    return {"seconds_extrapolated": round(sec * 2.0 ** (n_full - n_small), 2), "cores": 1, "kind": "port",
+            "sample": f"one {n_small}-qubit state of the same circuit (128 MiB; {sec:.2f} s for its {n_small} "
+                      f"purities with oracle/analysis.py qubit_purities_pure), scaled by 2^{n_full - n_small}",
+            "max_abs_diff_gpu_vs_fp64_oracle_purities": worst}
+
+
 def cpu_baseline(n, params_rows, budget_s, gpu_rows):
     """Oracle C/OpenMP port on a bounded sample of the same workload (rank 0, N=1); its <Z>
     values must equal the GPU's rows for the same parameter sets (atol 1e-5) or the run fails."""
@@ -914,6 +944,13 @@ def main(argv=None):
                 result[key] = fn()
             except Exception as e:  # pragma: no cover - e.g. not enough free HBM
                 result[key] = {"error": str(e)}
+        if isinstance(result.get("mw_28q"), dict) and "error" not in result["mw_28q"]:
+            try:
+                result["mw_28q"]["cpu_baseline"] = mw_cpu_baseline()
+            except SystemExit:
+                raise
+            except Exception as e:  # pragma: no cover
+                result["mw_28q"]["cpu_baseline"] = {"error": str(e)}
     distributed.barrier()
     print(json.dumps(result), flush=True)
 
