@@ -136,3 +136,29 @@ def test_general_observables_in_x64():
     assert np.abs(res[:, 0]).max() < 1e-12
     assert np.abs(res[:, 1] - np.cos(th)).max() < 1e-12
     assert np.abs(res[:, 2] + np.sin(0.3)).max() < 1e-12
+
+
+@pytest.mark.parametrize("circuit_type,n_qubits,n_layers,output_qubit", [
+    ("Circuit_1", 3, 1, [0, 1]), ("Circuit_9", 4, 1, 0), ("Circuit_19", 5, 1, 0),
+    ("Hardware_Efficient", 4, 2, -1)])
+def test_fourier_series_reproduces_the_model_in_x64(circuit_type, n_qubits, n_layers, output_qubit):
+    """`tests/test_coefficients.py:25-70` the way the reference runs it -- that module switches
+    `jax_enable_x64` on (`:19`): spectrum and re-evaluated Fourier series in float64 / complex128,
+    equal to the model to 1e-10 (1e-5 is all the complex64 engine can promise)."""
+    from qml_essentials_amd.coefficients import Coefficients
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.utils import x64_scope
+
+    with x64_scope(True):
+        model = Model(n_qubits=n_qubits, n_layers=n_layers, circuit_type=circuit_type,
+                      output_qubit=output_qubit)
+        coeffs, freqs = Coefficients.get_spectrum(model)
+        assert coeffs.shape == model.degree and coeffs.dtype == np.complex128
+        ref = np.linspace(-np.pi, np.pi, 10)
+        exp_model = np.asarray(model(params=None, inputs=ref, force_mean=True))
+        assert exp_model.dtype == np.float64
+        exp_fourier = Coefficients.evaluate_Fourier_series(coefficients=coeffs, frequencies=freqs, inputs=ref)
+        assert np.allclose(exp_model, exp_fourier, atol=1e-10), np.abs(exp_model - exp_fourier).max()
+    # and the complex64 engine on the same model agrees with the float64 values at its own level
+    exp32 = np.asarray(model(params=None, inputs=ref, force_mean=True))
+    assert exp32.dtype == np.float32 and np.allclose(exp32, exp_model, atol=2e-6)
