@@ -386,7 +386,9 @@ class Script:
         """
         tape, low, n_qubits, B, slots, leaf_shapes, batched = self._trace_for_gradient(
             obs, args, kwargs, in_axes, argnums)
-        base = low.angle_table(B).astype(np.float64)
+        from .utils import x64_enabled
+
+        base = low.angle_table(B, dtype=np.float64) if x64_enabled() else low.angle_table(B).astype(np.float64)
         grads = {k: np.zeros((B, len(obs)) + tuple(shp)) for k, shp in leaf_shapes.items()}
         if slots:
             rows = []
@@ -397,8 +399,12 @@ class Script:
                     t = base.copy()
                     t[:, slot] += shift
                     rows.append(t)
-            table = np.concatenate(rows, axis=0).astype(np.float32)
-            plan = simulation.get_plan(low)
+            if x64_enabled():  # shifted circuits on the complex128 engine, gate by gate like simulate()
+                table = np.concatenate(rows, axis=0)
+                plan = simulation.get_plan(low, (simulation.PLAN_FLAGS or 0) | N.PLAN_NO_MERGE)
+            else:
+                table = np.concatenate(rows, axis=0).astype(np.float32)
+                plan = simulation.get_plan(low)
             vals = simulation.run_expval_table(plan, table, obs, n_qubits)  # (rows*B, n_obs)
             vals = vals.reshape(-1, B, len(obs))
             r = 0

@@ -445,6 +445,15 @@ def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], 
     parity = bool(obs) and all(m is not None for m in masks) and len(obs) <= 32
     out = []
     from . import memory
+    if table.dtype == np.float64:  # the complex128 engine (x64 mode): Z / Z-parity observables only
+        if not parity:
+            raise NotImplementedError("parameter shift in x64 mode needs Z / Z-parity observables")
+        chunk = max(1, memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]), "expval", False,
+                                                 len(obs), n_ops=plan.n_ops) // 2)
+        for r0 in range(0, table.shape[0], chunk):
+            ang = torch.from_numpy(np.ascontiguousarray(table[r0:r0 + chunk])).cuda()
+            out.append(plan.run64(ang, "expval", masks).cpu().numpy())
+        return np.concatenate(out, axis=0)
     chunk = memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]),
                                       "expval" if (single_z or parity) else "state", False, len(obs),
                                       n_ops=plan.n_ops)

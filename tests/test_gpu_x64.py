@@ -162,3 +162,31 @@ def test_fourier_series_reproduces_the_model_in_x64(circuit_type, n_qubits, n_la
     # and the complex64 engine on the same model agrees with the float64 values at its own level
     exp32 = np.asarray(model(params=None, inputs=ref, force_mean=True))
     assert exp32.dtype == np.float32 and np.allclose(exp32, exp_model, atol=2e-6)
+
+
+def test_parameter_shift_gradient_in_x64():
+    """`Model.gradient` under `x64_scope`: the shifted circuits run on the complex128 engine --
+    central differences of the float64 model (`tests/test_jaqsi.py:131-141`'s jax.grad case runs
+    with x64 on) agree to 1e-9, where the complex64 engine stops at ~1e-7."""
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.utils import x64_scope
+
+    m = Model(4, 2, "Hardware_Efficient")
+    x = np.array([0.3])
+    g32 = np.asarray(m.gradient(inputs=x, force_mean=True))
+    with x64_scope(True):
+        g64 = np.asarray(m.gradient(inputs=x, force_mean=True))
+        gi = np.asarray(m.gradient(inputs=x, wrt="inputs", force_mean=True))
+        p = np.asarray(m.params, dtype=np.float64).copy()
+        f = lambda q, xx=x: float(np.asarray(m(params=q, inputs=xx, force_mean=True)))
+        eps = 1e-5
+        fd = np.zeros_like(p)
+        for i in np.ndindex(*p.shape):
+            a, b = p.copy(), p.copy()
+            a[i] += eps
+            b[i] -= eps
+            fd[i] = (f(a) - f(b)) / (2 * eps)
+        fdi = (f(p, x + eps) - f(p, x - eps)) / (2 * eps)
+    assert np.abs(g64.reshape(fd.shape) - fd).max() < 1e-9
+    assert abs(float(gi.reshape(-1)[0]) - fdi) < 1e-9
+    assert 0 < np.abs(g32 - g64).max() < 1e-5
