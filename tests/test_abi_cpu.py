@@ -304,7 +304,8 @@ def test_philox_sampler_is_numpys_stream_bit_for_bit():
     from qml_essentials_amd import utils
 
     for seed in (0, 1000, 2**40 + 3):
-        for n in (0, 1, 2, 3, 4, 5, 11, 12, 13, 31, 32, 33, 16383, 16384, 32767, 32769, 73728, 131072, 262147):
+        for n in (0, 1, 2, 3, 4, 5, 11, 12, 13, 31, 32, 33, 16383, 16384, 32767, 32769, 73728, 131072, 262147,
+                  524288 + 5, (1 << 20) + 3, 3 * (1 << 20) + 1):  # (the last three: 2, 4 and 8 threads)
             seq = np.random.SeedSequence(seed)
             ref = np.random.Generator(np.random.Philox(np.random.SeedSequence(seed))).uniform(0, 2 * np.pi, n).astype(np.float32)
             got = N.philox_uniform(seq.generate_state(2, np.uint64), n, 0.0, 2 * np.pi)
