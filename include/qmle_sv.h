@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 141 /* 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 142 /* 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -213,6 +213,13 @@ size_t qmle_workspace_bytes_f64(const qmle_plan *plan, int batch, int meas_type)
 /* optional: the batch-constant blob of qmle_plan_create at full precision (explicit matrices of a
  * complex128 caller); same length, before the first qmle_run_batch_f64 of the plan */
 int qmle_plan_set_consts_f64(qmle_plan *plan, const double *consts, int n_consts);
+/* complex128 counterpart of qmle_apply_inplace: the plan's operators on resident states
+ * [batch][2^n] complex128 (batch <= 65535 per call), no initialisation, no measurement.  The
+ * doubled-register density-matrix path uses it between Kraus channels in x64 mode
+ * (simulation.py:107-128). */
+int qmle_apply_inplace_f64(qmle_plan *plan, const double *d_angles, int batch, void *d_states,
+                           void *d_workspace, size_t workspace_bytes, qmle_stream stream);
+size_t qmle_apply_inplace_f64_workspace_bytes(const qmle_plan *plan, int batch);
 
 /* Optional per-pass HIP-event timing (bench.py's live roofline measurement): between
  * begin and end every pass launch of this plan is bracketed by an event pair on the

@@ -125,6 +125,8 @@ SYMBOLS = [
     ("qmle_run_batch_f64", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_workspace_bytes_f64", _SZ, [_VP, _I, _I]),
     ("qmle_plan_set_consts_f64", _I, [_VP, C.POINTER(C.c_double), _I]),
+    ("qmle_apply_inplace_f64", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
+    ("qmle_apply_inplace_f64_workspace_bytes", _SZ, [_VP, _I]),
     ("qmle_histogram", _I, [_VP, C.c_int64, _I, _F, _F, _VP, _VP]),
     ("qmle_adjoint_gradient", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
                                    _VP, _I, _VP, _SZ, _VP]),
@@ -449,6 +451,25 @@ def apply_inplace(plan: Plan, angles, states, workspace=None):
                                    C.c_void_p(states.data_ptr()), C.c_void_p(workspace.data_ptr()),
                                    C.c_size_t(workspace.numel()), _stream_ptr()),
           "qmle_apply_inplace")
+    return states
+
+
+def apply_inplace64(plan: Plan, angles, states):
+    """complex128 counterpart of :func:`apply_inplace` (``qmle_apply_inplace_f64``): ``plan``'s
+    operators on resident complex128 ``states`` [B <= 65535, 2^n], float64 ``angles``."""
+    torch = require_gpu()
+    B = int(states.shape[0])
+    if states.dtype != torch.complex128 or not states.is_cuda or not states.is_contiguous():
+        raise ValueError("states must be a contiguous complex128 CUDA tensor [B, 2^n]")
+    if angles is None:
+        angles = torch.zeros((B, max(1, plan.n_slots)), dtype=torch.float64, device=states.device)
+    angles = angles.to(dtype=torch.float64).contiguous()
+    need = int(lib().qmle_apply_inplace_f64_workspace_bytes(plan._h, B))
+    ws = torch.empty(need, dtype=torch.uint8, device=states.device)
+    check(lib().qmle_apply_inplace_f64(plan._h, C.c_void_p(angles.data_ptr()), B,
+                                       C.c_void_p(states.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                       C.c_size_t(need), _stream_ptr()),
+          "qmle_apply_inplace_f64")
     return states
 
 

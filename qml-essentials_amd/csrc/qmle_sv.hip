@@ -6102,6 +6102,41 @@ size_t qmle_workspace_bytes_f64(const qmle_plan *plan, int batch, int meas_type)
   return total;
 }
 
+// complex128 counterpart of qmle_apply_inplace: the plan's operators, one launch each, on resident
+// states (no initialisation, no measurement) -- what the doubled-register density path needs
+// between two Kraus channels (simulation.py:107-128, operations.py:485-512, 1551-1578)
+size_t qmle_apply_inplace_f64_workspace_bytes(const qmle_plan *plan, int batch) {  // the matrix rows
+  if (!plan || batch < 1) return 0;
+  return align_up((size_t)batch * (plan->mat_floats ? plan->mat_floats : 1) * sizeof(double), 256) + 512;
+}
+int qmle_apply_inplace_f64(qmle_plan *plan, const double *d_angles, int batch, void *d_states,
+                           void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || batch > 65535 || !d_states || !d_workspace) return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  if (workspace_bytes < qmle_apply_inplace_f64_workspace_bytes(plan, batch)) return QMLE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = ensure_device_plan(plan);
+  if (rc != QMLE_OK) return rc;
+  rc = ensure_f64(plan);
+  if (rc != QMLE_OK) return rc;
+  const double *d_c64 = (const double *)((char *)plan->f64_blob + align_up(plan->lowered.size() * sizeof(LoweredOp) + 16, 256));
+  char *ws = (char *)d_workspace;
+  ws += (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+  double *d_mats = (double *)ws;
+  if (!plan->groups.empty()) {
+    const int ng = (int)plan->groups.size();
+    hipLaunchKernelGGL(k_build_matrices_f64, dim3((ng + 63) / 64, batch), dim3(64), 0, stream, plan->dev.d_build,
+                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats);
+  }
+  const int n = plan->n;
+  const unsigned gx = grid_for(((size_t)1 << n) / 2, 256, 1u << 16);
+  for (size_t k = 0; k < plan->lowered.size(); ++k)
+    hipLaunchKernelGGL(k64_op, dim3(gx ? gx : 1, batch), dim3(256), 0, stream, (double2 *)d_states, n, plan->lowered[k],
+                       d_mats, plan->mat_floats, d_c64, d_angles, plan->n_slots);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
 int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int meas_type,
                        const uint32_t *wire_masks, int n_obs, void *d_out, void *d_workspace,
                        size_t workspace_bytes, qmle_stream stream_) {

@@ -237,7 +237,8 @@ class Operation:
             raise ValueError(f"{self.name}: matrix shape {m.shape} does not match {k} wire(s)")
         if k > 2:
             raise NotImplementedError(f"{self.name}: generic {k}-qubit matrices are not supported")
-        blob = np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
+        # (float64: LoweredTape keeps this copy for the complex128 engine and casts for the complex64 one)
+        blob = np.stack([m.real, m.imag], axis=-1).astype(np.float64).reshape(-1)
         return ("MAT1" if k == 1 else "MAT2"), self.wires, [], blob
 
 
@@ -264,7 +265,7 @@ def conj_lower(op_: "Operation", n_qubits: int, offset: int):
         neg = _CONJ_NEGATE[name]
         return name, wires, [(-p if j in neg else p) for j, p in enumerate(params)], None
     if name in ("MAT1", "MAT2", "MAT4"):
-        b = np.array(blob, dtype=np.float32).reshape(-1, 2)
+        b = np.array(blob, dtype=np.float64).reshape(-1, 2)
         b[:, 1] *= -1
         return name, wires, [], b.reshape(-1)
     if name == "DIAG_ALL":
@@ -273,7 +274,7 @@ def conj_lower(op_: "Operation", n_qubits: int, offset: int):
     m = np.conj(np.asarray(op_.matrix))
     if m.ndim != 2 or len(wires) > 2:
         raise NotImplementedError(f"conj({op_.name}) is not available on the engine")
-    blob = np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
+    blob = np.stack([m.real, m.imag], axis=-1).astype(np.float64).reshape(-1)
     return ("MAT1" if len(wires) == 1 else "MAT2"), wires, [], blob
 
 
@@ -596,8 +597,8 @@ class DiagonalQubitUnitary(Operation):
         k = len(self.wires)
         if k == n_qubits and self.wires == list(range(n_qubits)):
             if self._marks is not None:
-                return "DIAG_ALL", [], [self._scale], self._marks.astype(np.float32)
-            return "DIAG_ALL", [], [1.0], (-np.angle(self.diag)).astype(np.float32)
+                return "DIAG_ALL", [], [self._scale], np.asarray(self._marks, dtype=np.float64)
+            return "DIAG_ALL", [], [1.0], (-np.angle(self.diag)).astype(np.float64)
         if self.diag is None:
             raise NotImplementedError("batched diagonal on a wire subset")
         return Operation.lower(self, n_qubits)

@@ -75,7 +75,7 @@ class _WideChannel:
                 wk, wb = ket + [bra[0]], bra + [ket[0]]
             else:
                 wk, wb = ket, bra
-            blob = lambda M: np.stack([M.real, M.imag], axis=-1).astype(np.float32).reshape(-1)  # noqa: E731
+            blob = lambda M: np.stack([M.real, M.imag], axis=-1).astype(np.float64).reshape(-1)  # noqa: E731
             yield [_Lowered(("MAT4", wk, [], blob(K))), _Lowered(("MAT4", wb, [], blob(np.conj(K))))]
 
 
@@ -103,7 +103,7 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
                 out.append(_WideChannel(op_.kraus_matrices(), op_.wires))
                 continue
             S = op_.superoperator()
-            blob = np.stack([S.real, S.imag], axis=-1).astype(np.float32).reshape(-1)
+            blob = np.stack([S.real, S.imag], axis=-1).astype(np.float64).reshape(-1)
             wires = list(op_.wires) + [w + n_qubits for w in op_.wires]
             out.append(_Lowered(("MAT2" if k == 1 else "MAT4", wires, [], blob)))
             continue
@@ -115,19 +115,27 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
             # the doubled register with marks m_i - m_j
             m = np.asarray(low[3], dtype=np.float64)
             out.append(_Lowered(("DIAG_ALL", [], low[2],
-                                 (m[:, None] - m[None, :]).reshape(-1).astype(np.float32))))
+                                 (m[:, None] - m[None, :]).reshape(-1))))
             continue
         out.append(_Lowered(low))
         out.append(_Lowered(conj_lower(op_, n_qubits, n_qubits)))
     return out
 
 
-def _apply_segment(seg, n2: int, B: int, rho_vec):
+def _apply_segment(seg, n2: int, B: int, rho_vec, x64: bool = False):
     """Run a run of lowered ops on the doubled register: from |0..0> when ``rho_vec`` is
-    None, else in place on the resident ``rho_vec``."""
+    None, else in place on the resident ``rho_vec`` (complex128 engine when ``x64``)."""
     torch = N.require_gpu()
     low = LoweredTape(seg, n2)
     plan = get_plan(low)
+    if x64:
+        angles = torch.from_numpy(low.angle_table(B, dtype=np.float64)).cuda()
+        if rho_vec is None:
+            return plan.run64(angles, "state")
+        for b0 in range(0, B, 65535):
+            sl = slice(b0, min(B, b0 + 65535))
+            N.apply_inplace64(plan, angles[sl] if low.n_slots else None, rho_vec[sl])
+        return rho_vec
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if rho_vec is None:
         return plan.run(angles, "state")
@@ -137,8 +145,8 @@ def _apply_segment(seg, n2: int, B: int, rho_vec):
     return rho_vec
 
 
-def _evolve_density(tape: Sequence[Operation], n_qubits: int, B: int):
-    """vec(rho) [B, 4^n] after the whole (noisy) tape."""
+def _evolve_density(tape: Sequence[Operation], n_qubits: int, B: int, x64: bool = False):
+    """vec(rho) [B, 4^n] after the whole (noisy) tape (complex128 when ``x64``)."""
     torch = N.require_gpu()
     n2 = 2 * n_qubits
     rho_vec, seg = None, []
@@ -147,13 +155,13 @@ def _evolve_density(tape: Sequence[Operation], n_qubits: int, B: int):
             seg.append(item)
             continue
         if seg or rho_vec is None:
-            rho_vec = _apply_segment(seg, n2, B, rho_vec)
+            rho_vec = _apply_segment(seg, n2, B, rho_vec, x64)
             seg = []
         if item is None:
             break
         acc = torch.zeros_like(rho_vec)
         for pair in item.kraus_plans(n_qubits):
-            acc += _apply_segment(pair, n2, B, rho_vec.clone())
+            acc += _apply_segment(pair, n2, B, rho_vec.clone(), x64)
         rho_vec = acc
     return rho_vec
 
@@ -186,7 +194,41 @@ def _density_expval(rho_vec, n_qubits: int, obs: Sequence[Operation]):
     return out
 
 
-def _simulate_mixed(tape: Sequence[Operation], n_qubits: int, type: str, obs, B: int):
+def _density_measure_x64(rho_vec, n_qubits: int, type: str, obs):
+    """Measurements of a complex128 density matrix (x64 mode): float64 throughout; the diagonal
+    and its signed sums are a few thousand numbers -- torch, not a kernel.  Non-diagonal
+    observables are applied to the ket wires by the complex128 engine, then traced."""
+    torch = N.require_gpu()
+    B, D = rho_vec.shape[0], 1 << n_qubits
+    rho = rho_vec.view(B, D, D)
+    if type == "density":
+        return rho
+    diag = torch.diagonal(rho, dim1=1, dim2=2).real.contiguous()
+    if type == "probs":
+        return diag
+    obs = list(obs)
+    if not obs:
+        return torch.empty((B, 0), dtype=torch.float64, device=rho_vec.device)
+    out = torch.empty((B, len(obs)), dtype=torch.float64, device=rho_vec.device)
+    idx = torch.arange(D, device=rho_vec.device)
+    for k, ob in enumerate(obs):
+        m = z_parity_mask(ob)
+        if m is not None:
+            par = torch.zeros_like(idx)
+            for w in m:
+                par ^= (idx >> (n_qubits - 1 - w)) & 1
+            out[:, k] = (diag * (1.0 - 2.0 * par.double())).sum(dim=1)
+            continue
+        low = LoweredTape([ob], 2 * n_qubits)
+        plan = get_plan(low, N.PLAN_NO_FUSION)
+        scratch = rho_vec.clone()
+        for b0 in range(0, B, 65535):
+            N.apply_inplace64(plan, None, scratch[b0:b0 + 65535])
+        out[:, k] = torch.diagonal(scratch.view(B, D, D), dim1=1, dim2=2).real.sum(dim=1)
+    return out
+
+
+def _simulate_mixed(tape: Sequence[Operation], n_qubits: int, type: str, obs, B: int, x64: bool = False):
     """Noisy tape -> measurement, with rho evolved as a 2n-wire pure register
     (``simulation.py:106-128`` ``simulate_mixed`` + ``:204-271`` ``measure_state``)."""
     if n_qubits > MAX_DENSITY_QUBITS:
@@ -199,6 +241,8 @@ def _simulate_mixed(tape: Sequence[Operation], n_qubits: int, type: str, obs, B:
             "Use 'density' instead."
         )
     torch = N.require_gpu()
+    if x64:
+        return _density_measure_x64(_evolve_density(tape, n_qubits, B, True), n_qubits, type, obs)
     rho_vec = _evolve_density(tape, n_qubits, B)
     D = 1 << n_qubits
     if type == "density":
@@ -215,7 +259,7 @@ class LoweredTape:
     """Engine view of a tape: op list, per-slot values, const blob, structure key."""
 
     def __init__(self, tape: Sequence[Operation], n_qubits: int):
-        self.ops, self.values, blobs = [], [], []
+        self.ops, self.values, blobs, blobs64 = [], [], [], []
         self.ops_periodic = []  # per slot: the gate is 4 pi-periodic in this angle
         h = hashlib.blake2b(digest_size=16)
         h.update(str(n_qubits).encode())
@@ -233,12 +277,14 @@ class LoweredTape:
             off = -1
             if blob is not None:
                 off = const_len
-                blobs.append(np.asarray(blob, dtype=np.float32))
+                blobs64.append(np.asarray(blob, dtype=np.float64).reshape(-1))
+                blobs.append(blobs64[-1].astype(np.float32))
                 const_len += blobs[-1].size
-                h.update(blobs[-1].tobytes())
+                h.update(blobs64[-1].tobytes())  # (the complex128 engine reads the float64 copy)
             self.ops.append((name, list(wires), slots, off))
             h.update(f"{name}{wires}{len(slots)}{off};".encode())
         self.consts = np.concatenate(blobs) if blobs else np.zeros(0, dtype=np.float32)
+        self.consts64 = np.concatenate(blobs64) if blobs64 else np.zeros(0, dtype=np.float64)
         self.n_slots = len(self.values)
         self.n_qubits = n_qubits
         self.key = h.hexdigest()
@@ -277,6 +323,8 @@ def get_plan(low: LoweredTape, flags: Optional[int] = None) -> N.Plan:
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         plan = N.Plan(low.ops, low.n_qubits, low.n_slots, low.consts, flags)
+        if low.consts64.size:  # explicit matrices at full precision for complex128 runs of this plan
+            plan.set_consts64(low.consts64)
         _PLAN_CACHE[key] = plan
         if len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
             _PLAN_CACHE.popitem(last=False)
@@ -370,7 +418,10 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
     B = int(batch) if batch is not None else _tape_batch(tape)
     sampled = shots is not None and type in ("probs", "expval")
     if any(isinstance(o, KrausChannel) for o in tape):
-        res = _simulate_mixed(tape, n_qubits, "probs" if sampled else type, obs, B)
+        from .utils import x64_enabled
+
+        res = _simulate_mixed(tape, n_qubits, "probs" if sampled else type, obs, B,
+                              x64=x64_enabled() and not sampled)
         if sampled:
             res = sample_shots(res, n_qubits, type, obs, shots, key, row_offset)
         return res if as_tensor else res.cpu().numpy()

@@ -229,3 +229,90 @@ def test_golomb_encoding_with_noise():
 
     rho = _replay_script(tape, 2).execute(type="density")
     assert np.allclose(rho, ON.simulate_mixed(frontend_to_oracle(tape), 2), atol=ATOL)
+
+
+# ---- the same row on the complex128 engine (x64 mode: the reference runs TestNoise with
+# jax_enable_x64 on, tests/test_jaqsi.py:57) -------------------------------------------------
+X64_ATOL = 1e-12
+
+
+@pytest.mark.parametrize("cls,params", CHANNELS)
+def test_single_channel_density_in_x64(cls, params):
+    from qml_essentials_amd.utils import x64_scope
+
+    theta = 0.8
+
+    def circuit(t):
+        op.RX(t, wires=0)
+        cls(*params, wires=0)
+
+    with x64_scope(True):
+        rho = Script(f=circuit).execute(type="density", args=(np.array(theta),))
+    want = ON.simulate_mixed([("RX", [0], (theta,)), (cls.__name__, [0], params)], 1)
+    assert rho.dtype == np.complex128 and rho.shape == (2, 2)
+    assert np.abs(rho - want).max() < X64_ATOL
+
+
+def test_random_noisy_tape_all_measurements_in_x64():
+    from qml_essentials_amd.utils import x64_scope
+
+    rng = np.random.default_rng(11)
+    n = 3
+    tape = _noisy_tape(rng)
+    want = ON.simulate_mixed(frontend_to_oracle(tape), n)
+    script = _replay_script(tape, n)
+    herm = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    herm = herm + herm.conj().T
+    obs = [op.PauliZ(wires=0, record=False), op.PauliZ(wires=2, record=False),
+           js.build_parity_observable([0, 2]), op.PauliX(wires=1, record=False),
+           op.Hermitian(herm, wires=[2, 0], record=False)]
+    dense = [OD.lift(np.asarray(o.matrix), o.wires, n) for o in obs]
+    with x64_scope(True):
+        rho = script.execute(type="density")
+        probs = script.execute(type="probs")
+        got = script.execute(type="expval", obs=obs)
+        got_z = script.execute(type="expval", obs=obs[:2])
+    assert rho.dtype == np.complex128 and np.abs(rho - want).max() < X64_ATOL
+    assert probs.dtype == np.float64 and np.abs(probs - np.real(np.diag(want))).max() < X64_ATOL
+    assert np.abs(got - ON.measure_density(want, n, "expval", dense)).max() < 1e-11
+    assert np.abs(got_z - ON.measure_density(want, n, "expval", dense[:2])).max() < X64_ATOL
+    # and the complex64 engine agrees with it at its own level
+    rho32 = script.execute(type="density")
+    assert rho32.dtype == np.complex64 and 0 < np.abs(rho32 - rho).max() < ATOL
+
+
+def test_wide_channel_mid_circuit_in_x64():
+    from qml_essentials_amd.utils import x64_scope
+
+    n = 4
+    with recording() as tape:
+        for q in range(n):
+            op.RY(0.3 + q, wires=q)
+        op.CX(wires=[0, 3])
+        UnitaryGates.NQubitDepolarizingChannel(0.3, [3, 0, 2])
+        op.CRX(0.7, wires=[2, 1])
+        UnitaryGates.NQubitDepolarizingChannel(0.2, [0, 1, 2, 3])
+        op.RX(0.4, wires=1)
+        op.AmplitudeDamping(0.1, wires=1)
+    with x64_scope(True):
+        rho = _replay_script(tape, n).execute(type="density")
+    want = ON.simulate_mixed(frontend_to_oracle(tape), n)
+    assert np.abs(rho - want).max() < X64_ATOL
+
+
+def test_noisy_model_batched_in_x64():
+    """Model(noise_params=...) with a batch of inputs: float64 expectation values within 1e-11 of the
+    complex64 run's neighbourhood (2e-6) and Hermitian, trace-one density matrices."""
+    from qml_essentials_amd.utils import x64_scope
+
+    m = Model(3, 1, "Hardware_Efficient")
+    x = np.linspace(-1.0, 1.0, 5)
+    e32 = np.asarray(m(inputs=x, noise_params=NOISE))
+    with x64_scope(True):
+        e64 = np.asarray(m(inputs=x, noise_params=NOISE))
+        rho = np.asarray(m(inputs=x, noise_params=NOISE, execution_type="density"))
+    assert e64.dtype == np.float64 and e64.shape == e32.shape
+    assert 0 < np.abs(e64 - e32).max() < 5e-6
+    assert rho.dtype == np.complex128
+    assert np.abs(np.trace(rho, axis1=-2, axis2=-1) - 1).max() < 1e-12
+    assert np.abs(rho - np.conj(np.swapaxes(rho, -1, -2))).max() < 1e-13
