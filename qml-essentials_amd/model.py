@@ -575,6 +575,13 @@ class Model:
         ``cotangent``.  Same numbers as the parameter-shift rule at O(gates) instead of
         O(gates x angles) cost.
         """
+        from .utils import x64_enabled, x64_scope
+
+        if self.x64 is not None and bool(self.x64) != x64_enabled():  # Model(x64=...) scopes the mode
+            with x64_scope(self.x64):
+                return self.gradient(params=params, inputs=inputs, enc_params=enc_params, wrt=wrt,
+                                     force_mean=force_mean, data_reupload=data_reupload,
+                                     method=method, cotangent=cotangent)
         if method == "auto":  # measured (profiles/r01_gradients.md): from 14 qubits the fused
             # backward sweep beats the batched parameter shift 5-40x; below, psi and lambda live
             # in LDS and the single-launch sweep wins once there is a batch to spread over the CUs
@@ -606,7 +613,20 @@ class Model:
                    None, None, None)
         argnum = {"params": 0, "inputs": 1, "enc_params": 4}[wrt]
         kwargs = dict(noise_params=self.noise_params, gate_mode="unitary")
-        if method == "adjoint":
+        if method == "adjoint" and x64_enabled():
+            # the adjoint sweep is a complex64 kernel: in x64 mode the same vector-Jacobian product
+            # comes from the parameter-shift Jacobian of the complex128 engine, contracted here
+            n_out = len(obs)
+            (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
+                                          in_axes=in_axes if B > 1 else None, argnums=(argnum,))
+            if B == 1:
+                jac = jac[None]
+            if cotangent is not None or force_mean:
+                w = (np.full((B, n_out), 1.0 / n_out) if cotangent is None
+                     else np.asarray(cotangent, dtype=np.float64).reshape(B, n_out))
+                jac = np.einsum("bk,bk...->b...", w, jac)[:, None]
+                force_mean = True
+        elif method == "adjoint":
             n_out = len(obs)
             ax = in_axes if B > 1 else None
             if cotangent is not None or force_mean:

@@ -190,3 +190,28 @@ def test_parameter_shift_gradient_in_x64():
     assert np.abs(g64.reshape(fd.shape) - fd).max() < 1e-9
     assert abs(float(gi.reshape(-1)[0]) - fdi) < 1e-9
     assert 0 < np.abs(g32 - g64).max() < 1e-5
+
+
+def test_adjoint_method_and_model_scope_in_x64():
+    """`method="adjoint"` under x64: the vector-Jacobian product of the complex128 parameter-shift
+    Jacobian (the adjoint sweep itself is complex64) -- equal to the contraction done by hand and
+    to the complex64 adjoint at float32 level; `Model(x64=True).gradient` scopes the mode itself."""
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.utils import x64_enabled, x64_scope
+
+    m = Model(4, 2, "Hardware_Efficient")
+    x = np.array([0.1, -0.4, 0.9])
+    rng = np.random.default_rng(3)
+    ct = rng.normal(size=(3, 4))
+    a32 = np.asarray(m.gradient(inputs=x, method="adjoint", cotangent=ct))
+    with x64_scope(True):
+        J = np.asarray(m.gradient(inputs=x))                       # (3, 4, *params)
+        a64 = np.asarray(m.gradient(inputs=x, method="adjoint", cotangent=ct))
+        mean64 = np.asarray(m.gradient(inputs=x, method="adjoint", force_mean=True))
+    assert a64.shape == a32.shape and np.abs(a64 - np.einsum("bk,bk...->b...", ct, J)).max() < 1e-13
+    assert np.abs(mean64 - J.mean(axis=1)).max() < 1e-13
+    assert 0 < np.abs(a64 - a32).max() < 2e-5
+    mx = Model(4, 2, "Hardware_Efficient", x64=True)
+    assert not x64_enabled()
+    gx = np.asarray(mx.gradient(inputs=x))
+    assert np.abs(gx - J).max() < 1e-13 and not x64_enabled()
