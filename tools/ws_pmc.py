@@ -1,3 +1,5 @@
+"""Largest value of every collected counter per kernel from `rocprofv3 --pmc ... --output-format csv`
+directories (tools/whole_state_bench.py under SQ_* counters): python tools/ws_pmc.py <dir> [<dir> ...]."""
 import csv, glob, collections, sys
 for d in sys.argv[1:]:
     f = glob.glob(d + "/*counter_collection.csv")

@@ -1,3 +1,6 @@
+"""Median per-launch time of each kernel and shape from a `rocprofv3 --kernel-trace --output-format csv`
+run of tools/whole_state_bench.py (five shapes x 23 launches): python tools/ws_trace.py, run from the
+repo root after `rocprofv3 ... -d gpurun_out/ws/prof -o ws -- python3 tools/whole_state_bench.py`."""
 import csv,glob,collections
 f=glob.glob("gpurun_out/ws/prof/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
