@@ -691,11 +691,13 @@ def cpu_baseline(n, params_rows, budget_s, gpu_rows):
 
     spec = OC.ModelSpec(n, 1, "Hardware_Efficient", data_reupload=False)
     threads = c_port.lib().svc_max_threads()
-    done, t0, worst = 0, time.perf_counter(), 0.0
+    done, t0, worst, per_state = 0, time.perf_counter(), 0.0, []
     while True:
+        t1 = time.perf_counter()
         tape = OC.model_tape(spec, params_rows[done], [0.0])
         psi = c_port.simulate(tape, n)
         ez = c_port.expval_z(psi, n, list(range(n)))
+        per_state.append(time.perf_counter() - t1)
         worst = max(worst, float(np.max(np.abs(ez - gpu_rows[done]))))
         done += 1
         el = time.perf_counter() - t0
@@ -707,6 +709,9 @@ def cpu_baseline(n, params_rows, budget_s, gpu_rows):
     return {"value": round(done * gates / el, 2), "unit": "gate-applies/s", "cores": threads,
             "kind": "port", "statevectors_per_s": round(done / el, 4),
             "max_abs_diff_vs_gpu_expvals": worst,
+            # the host is shared (other tenants of the 8-GPU box): the spread of the sample, not one number
+            "gate_applies_per_s_fastest_median_slowest_state": [round(gates / t, 1) for t in
+                                                                (min(per_state), float(np.median(per_state)), max(per_state))],
             "sample": f"{done} of the statevectors of one step (same tape: {gates} gates + <Z> on "
                       f"{n} wires, n={n}), oracle/sv_cpu.c with {threads} OpenMP threads (parallel "
                       f"first-touch initialisation), {el:.1f} s; every <Z> row compared with the GPU's"}
