@@ -1680,10 +1680,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   }
   const bool plain = MULTI || (!a.init_zero && !a.zin_local);
   float4 v[8];
-  if (plain) {
+  // the 8 loads of a tile.  Multi-tile walks over a stage with known zeros INSIDE the tile
+  // (zin_local; every tile live: launch_tile) read only the amplitudes that can be non-zero, like
+  // the one-tile path below -- round 3: those stages used to keep one tile per workgroup, and at
+  // T = 13 (two workgroups per CU, started together and finishing together) their loads and their
+  // gate groups never overlapped: 34 us of traffic + 80 us of arithmetic = 113 us for the 9-group
+  // pass of the default engine's deep run (profiles/r03_deep_default_anatomy.txt)
+  const uint32_t zl_m = MULTI ? (a.zin_local & ~1u) : 0u;
+  const bool z0_m = MULTI && (a.zin_local & 1u) != 0;
+  auto load_tile = [&](const char *p) {
+    if (MULTI && a.zin_local) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
-  }
+      for (int u = 0; u < 8; ++u) {
+        v[u] = z4;
+        if (((jl | ((uint32_t)u << (T - 3))) & zl_m) == 0) {
+          v[u] = ld4<NT>(reinterpret_cast<const float4 *>(p + uoff[u] + goff8));
+          if (z0_m) v[u].z = v[u].w = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(p + uoff[u] + goff8));
+    }
+  };
+  if (plain) load_tile(st);
   const uint32_t sl_outer = sl;
   float zacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // MEASURE && MULTI: tile_z_accumulate
   for (int i = 0; i < tpw; ++i) {
@@ -1694,8 +1714,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
       // the sums moved into registers: no gain)
       base += f.tile_stride;
       st += f.tile_stride * sizeof(float2);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+      load_tile(st);
     }
     if (!MULTI && a.init_zero) {
 #pragma unroll
@@ -1726,11 +1745,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     if (!MEASURE && i + 1 < tpw) {  // (plain storing stages only) the next tile: loads in flight from here on
       base += f.tile_stride;  // (the tiles of a walk differ in the lowest outer bits only: launch_tile)
       st += f.tile_stride * sizeof(float2);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4<NT>(reinterpret_cast<const float4 *>(st + uoff[u] + goff8));
+      load_tile(st);
     }
 
-    tile2_groups(sbo, addr, f, mrow, tid, !MULTI && a.zin_local != 0);  // known zeros: Stage::zero_in
+    tile2_groups(sbo, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
 
     if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
@@ -4410,7 +4428,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     const int tpw_max = tpw_env > 0 ? tpw_env : meas == TM_EXPVAL_PARTIAL ? 8 : 4;
     f.tpw = 1;
     f.tile_stride = 0;
-    if (!a.init_zero && !a.zin_local && !a.zin_outer && !a.compact && st.T < p->n &&
+    // (known zeros inside the tile are fine -- the walk's loads skip them; known-zero TILES are not)
+    const bool multi_zin = std::getenv("QMLE_NO_MULTI_ZIN") == nullptr;  // (read per launch: the A/B test toggles it)
+    if (!a.init_zero && (!a.zin_local || multi_zin) && !a.zin_outer && !a.compact && st.T < p->n &&
         (meas == TM_STORE || meas == TM_PROBS || meas == TM_EXPVAL_PARTIAL)) {
       // (consecutive tile indices differ in the lowest run of outer bit positions only)
       int run0 = 1;
@@ -4430,6 +4450,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
         *row_shift = 31 - __builtin_clz((unsigned)f.tpw);
       }
     }
+    static const bool dbg_launch = std::getenv("QMLE_DBG_LAUNCH") != nullptr;
+    if (dbg_launch) fprintf(stderr, "[launch_tile] T=%d init_zero=%d zin_local=%x zin_outer=%x compact=%d meas=%d tpw=%d grid=(%u,%u)\n", st.T, a.init_zero, a.zin_local, a.zin_outer, a.compact, meas, f.tpw, grid.x, grid.y);
     static const int dbg = std::getenv("QMLE_DBG_T2") ? atoi(std::getenv("QMLE_DBG_T2")) : 0;
     f.dbg = dbg;
     if (dbg & 1) f.n_groups = 0;

@@ -697,3 +697,36 @@ def test_last_stage_padding_switch_changes_the_tile_not_the_result(monkeypatch):
     pr = (np.abs(psi) ** 2).reshape((2,) * n)
     z = [float(pr.take(0, axis=w).sum() - pr.take(1, axis=w).sum()) for w in range(n)]
     assert np.allclose(want[0], z, atol=2e-6)
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_multi_tile_walk_over_known_zeros_inside_the_tile(layers, monkeypatch):
+    """Default engine (known-zero tracking), n = 22: stages whose tile still holds known-zero
+    positions while every tile is live run as multi-tile walks whose loads skip the zeros
+    (round 3).  Same state, bit for bit, as with one tile per workgroup (QMLE_NO_MULTI_ZIN=1, the
+    round-2 launch), <Z> within float32 summation order, the all-live plan's state at float32 level."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n, B = 22, 32  # (>= 5120 workgroups after halving the grid: launch_tile's condition for a walk)
+    ops, slots = [], 0
+    for _ in range(layers):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    ang = torch.from_numpy(np.random.default_rng(31 + layers).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots)
+    zin_stage = [s for s in plan.describe()["stages"][1:] if s["kind"] == "tile" and s["zero_in"]
+                 and all((s["zero_in"] >> b) & 1 == 0 for b in range(n) if b not in s["bits"])]
+    assert zin_stage, "no stage with known zeros inside the tile only: pick another circuit"
+    walk = plan.run(ang, "state")
+    z_walk = plan.run(ang, "expval", list(range(n)))
+    monkeypatch.setenv("QMLE_NO_MULTI_ZIN", "1")
+    single = plan.run(ang, "state")
+    z_single = plan.run(ang, "expval", list(range(n)))
+    monkeypatch.delenv("QMLE_NO_MULTI_ZIN")
+    assert torch.equal(walk, single)
+    # (<Z>: the walk sums a workgroup's tiles in registers before the row reduction -- another order)
+    assert (z_walk - z_single).abs().max().item() < 5e-7
+    dense = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE).run(ang[:4], "state")
+    assert (walk[:4] - dense).abs().max().item() < 2e-6
