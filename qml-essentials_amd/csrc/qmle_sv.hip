@@ -1322,7 +1322,8 @@ struct Tile2Args {
   const uint32_t *tbl;      // qmle_plan::tbl2 on the device
   int n_groups;
   int n_ops_stage;          // ops of all the stage's groups (one contiguous stream in `ops`)
-  int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue, 4 / 8: see tile2_groups
+  int dbg;                  // QMLE_DBG_T2 (timing anatomy only): 1 no groups, 2 no epilogue, 4 / 8: see tile2_groups,
+                            // 16 no global stores of a storing pass, 32 no global loads (constants instead)
   uint32_t gtab;            // index into tbl: per-lane global byte offset inside the tile
   uint32_t uoff8[8];        // byte offsets of the lane's 8 float4 (the tile's top three bits)
   // tile index -> amplitude offset of the tile: the outer bit positions as <= 6 contiguous runs
@@ -1689,7 +1690,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   const uint32_t zl_m = MULTI ? (a.zin_local & ~1u) : 0u;
   const bool z0_m = MULTI && (a.zin_local & 1u) != 0;
   auto load_tile = [&](const char *p) {
-    if (MULTI && a.zin_local) {
+    if (f.dbg & 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = make_float4(1e-3f, 0.f, 1e-3f, 0.f);
+    } else if (MULTI && a.zin_local) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         v[u] = z4;
@@ -1765,14 +1769,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
 #pragma unroll
           for (int u = 0; u < 4; ++u) w[u] = lds_ld128(sl ^ soff[h + u]);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[h + u] + goff8), w[u]);
+          for (int u = 0; u < 4; ++u) if (!(f.dbg & 16) || w[u].x == 123.f) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[h + u] + goff8), w[u]);
         }
       } else {
         float4 w[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) w[u] = lds_ld128(sl ^ soff[u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[u] + goff8), w[u]);
+        for (int u = 0; u < 8; ++u) if (!(f.dbg & 16) || w[u].x == 123.f) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[u] + goff8), w[u]);
       }
     } else {
       char *po = reinterpret_cast<char *>(reinterpret_cast<float *>(a.out) + (size_t)b * D + base_cur);
