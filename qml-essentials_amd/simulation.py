@@ -420,20 +420,24 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
     if any(isinstance(o, KrausChannel) for o in tape):
         from .utils import x64_enabled
 
-        res = _simulate_mixed(tape, n_qubits, "probs" if sampled else type, obs, B,
-                              x64=x64_enabled() and not sampled)
-        if sampled:
-            res = sample_shots(res, n_qubits, type, obs, shots, key, row_offset)
+        res = _simulate_mixed(tape, n_qubits, "probs" if sampled else type, obs, B, x64=x64_enabled())
+        if sampled:  # (x64: the sampler takes the float64 probabilities rounded once to float32)
+            res = sample_shots(res.float() if res.dtype != torch.float32 else res, n_qubits, type, obs,
+                               shots, key, row_offset)
         return res if as_tensor else res.cpu().numpy()
     low = LoweredTape(tape, n_qubits)
     plan = get_plan(low)
     from .utils import x64_enabled
 
-    if x64_enabled() and not sampled:
+    if x64_enabled():
         # gate by gate, like the reference (no products of neighbouring 1-qubit gates): the
         # accuracy mode keeps the reference's operation order as well as its precision
         plan = get_plan(low, (PLAN_FLAGS or 0) | N.PLAN_NO_MERGE)
-        res = _simulate_x64(plan, low, B, n_qubits, type, list(obs))
+        if sampled:  # shots: drawn from the complex128 probabilities, rounded once to float32
+            res = sample_shots(_simulate_x64(plan, low, B, n_qubits, "probs", []).float(), n_qubits, type,
+                               obs, shots, key, row_offset)
+        else:
+            res = _simulate_x64(plan, low, B, n_qubits, type, list(obs))
         return res if as_tensor else res.cpu().numpy()
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if sampled:

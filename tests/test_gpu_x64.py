@@ -215,3 +215,34 @@ def test_adjoint_method_and_model_scope_in_x64():
     assert not x64_enabled()
     gx = np.asarray(mx.gradient(inputs=x))
     assert np.abs(gx - J).max() < 1e-13 and not x64_enabled()
+
+
+def test_shots_in_x64_draw_from_the_complex128_probabilities():
+    """Shot estimates under x64 (pure and noisy): the sampler takes the float64 probabilities
+    rounded once to float32 -- same Philox streams, so the counts equal the complex64 run's except
+    where a CDF boundary moved by ~1e-8 (at most a few shots in 10^5)."""
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd.script import Script
+    from qml_essentials_amd.utils import key, x64_scope
+
+    def circuit(t):
+        op.RX(t, wires=0)
+        op.RY(0.4, wires=1)
+        op.CX(wires=[0, 1])
+        op.RZ(0.3, wires=2)
+        op.H(wires=2)
+
+    def noisy(t):
+        circuit(t)
+        op.BitFlip(0.1, wires=1)
+
+    shots = 100_000
+    for f in (circuit, noisy):
+        s = Script(f=f, n_qubits=3)
+        a = s.execute(type="probs", args=(np.array(0.7),), shots=shots, key=key(5))
+        with x64_scope(True):
+            b = s.execute(type="probs", args=(np.array(0.7),), shots=shots, key=key(5))
+            exact = s.execute(type="probs", args=(np.array(0.7),))
+        assert exact.dtype == np.float64
+        assert np.abs(np.asarray(a) - np.asarray(b)).sum() * shots <= 8  # a few boundary shots
+        assert np.abs(np.asarray(b) - exact).max() < 5 / np.sqrt(shots)
