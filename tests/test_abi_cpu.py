@@ -324,3 +324,34 @@ def test_philox_sampler_is_numpys_stream_bit_for_bit():
     assert mine.dtype == np.float32 and mine.shape == theirs.shape and np.array_equal(mine, theirs)
     with pytest.raises(ValueError):
         N.philox_uniform(np.zeros(3, np.uint64), 4, 0.0, 1.0)
+
+
+def test_every_schedule_candidate_places_every_gate_exactly_once(monkeypatch):
+    """Plan-compiler invariant, all 48 candidates (tile geometry x lazy CX x wide first tile / carried
+    position 6) and the last-stage padding switch: whatever the schedule, the stages' `src_ops` are a
+    permutation of the tape -- no gate dropped, none applied twice -- and the tile of every stage
+    holds the positions its gates act on (wire w <-> position n - 1 - w)."""
+    n = 20
+    ops, slots = [], 0
+    for _ in range(3):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    seen = set()
+    for pad in (None, "1"):
+        if pad:
+            monkeypatch.setenv("QMLE_PAD_HIGH", pad)
+        for k in range(48):
+            monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
+            top = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+            d = (top.expval_child() or top).describe()
+            placed = sorted(s for st in d["stages"] for s in st["src_ops"])
+            assert placed == list(range(len(ops))), (k, pad)
+            for st in d["stages"]:
+                if st["kind"] != "tile":
+                    continue
+                tile = set(st["bits"])
+                for s in st["src_ops"]:
+                    assert all(n - 1 - w in tile for w in ops[s][1]), (k, pad, s)
+            seen.add(tuple(tuple(st["bits"]) for st in d["stages"] if st["kind"] == "tile"))
+    assert len(seen) >= 8  # (the candidates really are different schedules)
