@@ -730,3 +730,42 @@ def test_multi_tile_walk_over_known_zeros_inside_the_tile(layers, monkeypatch):
     assert (z_walk - z_single).abs().max().item() < 5e-7
     dense = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE).run(ang[:4], "state")
     assert (walk[:4] - dense).abs().max().item() < 2e-6
+
+
+def test_every_schedule_candidate_gives_the_same_result(monkeypatch):
+    """All 48 schedule candidates of the plan compiler (QMLE_FORCE_CAND; tile geometry x lazy CX x
+    wide first tile / carried position 6), with and without the last-stage padding switch, on one
+    3-layer circuit at n = 18: state and <Z> equal the model-chosen schedule's at float32 level and
+    the fp64 oracle's <Z> -- the rarely chosen geometries (L = 5..7 rows, T = 13 with a carried
+    position) run the same kernels as the common ones."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n, B = 18, 3
+    ops, slots = [], 0
+    for _ in range(3):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    ang = torch.from_numpy(np.random.default_rng(91).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
+    flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
+    ref = N.Plan(ops, n, slots, flags=flags)
+    want_s = ref.run(ang, "state")
+    want_z = ref.run(ang, "expval", list(range(n)))
+    tape = [(g, w, [float(ang[0, s]) for s in sl]) for g, w, sl, _ in ops]
+    psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
+    pr = (np.abs(psi) ** 2).reshape((2,) * n)
+    z = np.array([pr.take(0, axis=w).sum() - pr.take(1, axis=w).sum() for w in range(n)])
+    assert np.abs(want_z[0].cpu().numpy() - z).max() < 2e-6
+    shapes = set()
+    for pad in (None, "1"):
+        if pad:
+            monkeypatch.setenv("QMLE_PAD_HIGH", pad)
+        for k in range(48):
+            monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
+            p = N.Plan(ops, n, slots, flags=flags)
+            d = (p.expval_child() or p).describe()
+            shapes.add(tuple(tuple(st["bits"]) for st in d["stages"]))
+            assert (p.run(ang, "state") - want_s).abs().max().item() < 2e-6, (k, pad)
+            assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 2e-6, (k, pad)
+    assert len(shapes) >= 8
