@@ -769,3 +769,32 @@ def test_every_schedule_candidate_gives_the_same_result(monkeypatch):
             assert (p.run(ang, "state") - want_s).abs().max().item() < 2e-6, (k, pad)
             assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 2e-6, (k, pad)
     assert len(shapes) >= 8
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_default_engine_under_every_tile_geometry(layers, monkeypatch):
+    """The default engine (known-zero tracking, observable folding) under each of its 12 schedule
+    candidates (QMLE_FORCE_CAND 0..11: six tile geometries x lazy CX) at n = 18: state, <Z> and a
+    parity observable equal the all-live plan's -- its special first-pass kernels are chosen per
+    stage shape, and every shape must reach the same answer."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n, B = 18, 4
+    ops, slots = [], 0
+    for _ in range(layers):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    ang = torch.from_numpy(np.random.default_rng(17 + layers).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
+    dense = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
+    want_s = dense.run(ang, "state")
+    want_z = dense.run(ang, "expval", list(range(n)))
+    groups = [[0, n - 1], [3, 4, 5], list(range(n))]
+    want_p = dense.run_parity(ang, groups)
+    for k in range(12):
+        monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
+        p = N.Plan(ops, n, slots)
+        assert (p.run(ang, "state") - want_s).abs().max().item() < 2e-6, k
+        assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 2e-6, k
+        assert (p.run_parity(ang, groups) - want_p).abs().max().item() < 2e-6, k
