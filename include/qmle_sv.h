@@ -25,6 +25,12 @@
  * = qmle_status.  Plans are immutable after creation except for a lazily created
  * device copy of their descriptors; one stream per call; no other global state.
  * All pointers named d_* are device pointers, everything else is host memory.
+ * Batch limits: qmle_run_batch / _parity / _f64 take any batch >= 1 (they cut it into launches
+ * themselves); the stand-alone kernels on resident states (qmle_expval_z, qmle_probs,
+ * qmle_marginal_probs, qmle_meyer_wallach, qmle_overlap, qmle_expval_parity, qmle_density*,
+ * qmle_apply_inplace*, qmle_sample_counts, qmle_probs_diag_expval) take batch <= 65535 per call
+ * (one grid row per sample), qmle_adjoint_gradient batch <= 32767 -- QMLE_ERR_INVALID_ARG above
+ * that; the Python host side slices longer batches (qml-essentials_amd/_native.py).
  */
 #ifndef QMLE_SV_H
 #define QMLE_SV_H

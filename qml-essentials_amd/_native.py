@@ -8,6 +8,7 @@ called without a GPU, this module raises.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import json
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -474,6 +475,33 @@ def apply_inplace64(plan: Plan, angles, states):
 
 
 # ---- stand-alone measurement / analysis kernels -------------------------------------
+MAX_ROWS = 65535  # one launch covers at most this many samples (grid.y); the wrappers below cut longer batches
+
+
+def _row_chunked(*tensor_args: int, max_rows: int = MAX_ROWS):
+    """Run the wrapped call on slices of at most ``max_rows`` rows of the positional tensor
+    arguments ``tensor_args`` and concatenate the results (a tensor or a tuple of tensors / None)."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def run(*args, **kwargs):
+            rows = int(args[tensor_args[0]].shape[0]) if args[tensor_args[0]].dim() > 1 else 1
+            if rows <= max_rows:
+                return fn(*args, **kwargs)
+            torch = require_gpu()
+            parts = []
+            for lo in range(0, rows, max_rows):
+                a = list(args)
+                for i in tensor_args:
+                    a[i] = args[i][lo:lo + max_rows].contiguous()
+                parts.append(fn(*a, **kwargs))
+            if isinstance(parts[0], tuple):
+                return tuple(None if p0 is None else torch.cat([p[k] for p in parts], dim=0)
+                             for k, p0 in enumerate(parts[0]))
+            return torch.cat(parts, dim=0)
+        return run
+    return deco
+
+
 def _states_info(states):
     torch = require_gpu()
     if states.dtype == torch.complex128 and states.is_cuda:
@@ -492,6 +520,7 @@ def _states_info(states):
     return torch, states, B, n
 
 
+@_row_chunked(0)
 def expval_z(states, obs_wires: Sequence[int]):
     torch, states, B, n = _states_info(states)
     out = torch.empty((B, len(obs_wires)), dtype=torch.float32, device=states.device)
@@ -511,6 +540,7 @@ def probs(states):
     return out
 
 
+@_row_chunked(0)
 def density(states):
     torch, states, B, n = _states_info(states)
     out = torch.empty((B, 1 << n, 1 << n), dtype=torch.complex64, device=states.device)
@@ -519,6 +549,7 @@ def density(states):
     return out
 
 
+@_row_chunked(0)
 def marginal_probs(states, keep: Sequence[int]):
     torch, states, B, n = _states_info(states)
     out = torch.empty((B, 1 << len(keep)), dtype=torch.float32, device=states.device)
@@ -534,6 +565,10 @@ def pair_fidelity(states):
     if B % 2:
         raise ValueError("pair_fidelity needs an even number of states")
     S = B // 2
+    if S > MAX_ROWS:  # pairs (i, i + S): cut the pair index range, both halves per slice
+        return torch.cat([pair_fidelity(torch.cat([states[lo:min(S, lo + MAX_ROWS)],
+                                                   states[S + lo:S + min(S, lo + MAX_ROWS)]]))
+                          for lo in range(0, S, MAX_ROWS)])
     out = torch.empty((S,), dtype=torch.float32, device=states.device)
     wsb = int(lib().qmle_pair_fidelity_workspace_bytes(n, S))
     ws = torch.empty(wsb, dtype=torch.uint8, device=states.device)
@@ -543,6 +578,7 @@ def pair_fidelity(states):
     return out
 
 
+@_row_chunked(0)
 def density_probs(rho_vec, n_qubits: int):
     """diag(rho) of vectorised density matrices [B, 4^n] -> float32 [B, 2^n]."""
     torch = require_gpu()
@@ -554,6 +590,7 @@ def density_probs(rho_vec, n_qubits: int):
     return out
 
 
+@_row_chunked(0)
 def density_expval_z(rho_vec, n_qubits: int, obs_wires: Sequence[int]):
     torch = require_gpu()
     rho_vec = rho_vec.contiguous()
@@ -566,6 +603,7 @@ def density_expval_z(rho_vec, n_qubits: int, obs_wires: Sequence[int]):
     return out
 
 
+@_row_chunked(0, 1)
 def overlap(a, b):
     """<a_i|b_i> for two [B, 2^n] complex64 tensors -> complex64 [B]."""
     torch, a, B, n = _states_info(a)
@@ -581,6 +619,7 @@ def overlap(a, b):
     return out
 
 
+@_row_chunked(0)
 def expval_parity(states, wire_groups):
     """<Z..Z> on each group of wires -> float32 [B, len(groups)]."""
     torch, states, B, n = _states_info(states)
@@ -602,6 +641,7 @@ def expval_parity(states, wire_groups):
     return out
 
 
+@_row_chunked(0)
 def meyer_wallach(states, return_purities: bool = False):
     torch, states, B, n = _states_info(states)
     out = torch.empty((B,), dtype=torch.float32, device=states.device)
@@ -708,6 +748,7 @@ class AdjointTerm(C.Structure):
                 ("marks_off", C.c_int32)]
 
 
+@_row_chunked(2, 3, 4, max_rows=32767)  # (psi and lambda of a sample share a launch: 2 B <= 65535)
 def adjoint_gradient(fwd: Plan, rev: Plan, angles_fwd, angles_rev, weights,
                      wire_groups: Sequence[Sequence[int]], terms, n_grad_slots: int):
     """One backward sweep: d/d(angle) of sum_k weights[b, k] <Z..Z>_k -> float32 [B, n_grad_slots].

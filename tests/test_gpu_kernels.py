@@ -798,3 +798,41 @@ def test_default_engine_under_every_tile_geometry(layers, monkeypatch):
         assert (p.run(ang, "state") - want_s).abs().max().item() < 2e-6, k
         assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 2e-6, k
         assert (p.run_parity(ang, groups) - want_p).abs().max().item() < 2e-6, k
+
+
+def test_batches_longer_than_one_launch_row_limit():
+    """More than 65 535 samples per call (the grid's y extent; reference loops have no such bound:
+    `script.py:399-553` only chunks for memory): every engine entry point and stand-alone analysis
+    wrapper cuts the batch itself -- rows around the seam equal the same rows computed alone."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    n, B = 4, 65540
+    ops, slots = he_layer_ops(n)
+    rng = np.random.default_rng(5)
+    ang = torch.from_numpy(rng.uniform(0, 6.28, (B, slots)).astype(np.float32)).cuda()
+    rows = [0, 1, 65534, 65535, 65536, 65539]
+    plan = N.Plan(ops, n, slots)
+    sub_ang = ang[rows].contiguous()
+    st, st_sub = plan.run(ang, "state"), plan.run(sub_ang, "state")
+    assert torch.equal(st[rows], st_sub)
+    assert torch.equal(plan.run(ang, "expval", list(range(n)))[rows], plan.run(sub_ang, "expval", list(range(n))))
+    assert torch.equal(plan.run(ang, "probs")[rows], plan.run(sub_ang, "probs"))
+    assert torch.equal(plan.run_parity(ang, [[0, 3], [1]])[rows], plan.run_parity(sub_ang, [[0, 3], [1]]))
+    q, pur = N.meyer_wallach(st, return_purities=True)
+    q_sub, pur_sub = N.meyer_wallach(st_sub, return_purities=True)
+    assert q.shape == (B,) and torch.equal(q[rows], q_sub) and torch.equal(pur[rows], pur_sub)
+    for fn in (lambda s: N.expval_z(s, [0, 2, 3]), lambda s: N.marginal_probs(s, [1, 3]), N.probs, N.density,
+               lambda s: N.expval_parity(s, [[0, 1], [2]])):
+        assert torch.equal(fn(st)[rows], fn(st_sub))
+    assert torch.equal(N.overlap(st, st.flip(0))[rows], N.overlap(st_sub, st.flip(0)[rows].contiguous()))
+    # pairs (i, i + S) with S > 65535
+    big = torch.cat([st, st[:B]])[: 2 * 65538]
+    S = big.shape[0] // 2
+    fid = N.pair_fidelity(big)
+    pick = [0, 65534, 65535, 65536, S - 1]
+    want = torch.stack([(big[i].conj() * big[i + S]).sum().abs() ** 2 for i in pick])
+    assert fid.shape == (S,) and (fid[pick] - want).abs().max().item() < 1e-6
+    # complex128 engine
+    o64 = plan.run64(ang.double(), "expval", [[q_] for q_ in range(n)])
+    assert o64.shape == (B, n) and (o64[rows].float() - plan.run(sub_ang, "expval", list(range(n)))).abs().max().item() < 1e-6

@@ -610,3 +610,24 @@ def test_relative_entropy_order():
     ent.append(Entanglement.relative_entropy(ghz, n_samples=1, n_sigmas=100, random_key=random.key(1000)))
     assert all(ent[i] <= ent[i + 1] for i in range(len(ent) - 1)), ent
     assert abs(ent[-1] - 1.0) < 1e-6
+
+
+def test_analysis_loops_beyond_the_launch_row_limit():
+    """More samples than one launch holds (65 535 states; 32 767 for the adjoint sweep, which keeps
+    psi and lambda of a sample side by side): Meyer-Wallach over 70 000 parameter samples and
+    adjoint gradients of 33 000 inputs run in slices; rows around the seam equal the same rows
+    computed in a small batch."""
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+
+    m = Model(3, 1, "Hardware_Efficient")
+    q = Entanglement.meyer_wallach(m, n_samples=70000, random_key=3)
+    assert np.isfinite(q) and 0.0 < float(q) < 1.0
+    q_small = Entanglement.meyer_wallach(m, n_samples=5000, random_key=3)
+    assert abs(float(q) - float(q_small)) < 0.02
+    m2 = Model(3, 1, "Hardware_Efficient")
+    x = np.linspace(-1.0, 1.0, 33000)
+    g = np.asarray(m2.gradient(inputs=x, method="adjoint", force_mean=True))
+    rows = [0, 32766, 32767, 32768, 32999]
+    g_sub = np.asarray(m2.gradient(inputs=x[rows], method="adjoint", force_mean=True))
+    assert g.shape[0] == 33000 and np.allclose(g[rows], g_sub, atol=1e-6)
