@@ -346,9 +346,9 @@ def test_known_zero_fuzz_short():
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("n", [29, 30])
+@pytest.mark.parametrize("n", [29, 30, 32])
 def test_registers_beyond_28_qubits(n):
-    """n = 29 / 30 (4 / 8 GiB per state; the fast tile kernel addresses a state with 32-bit byte
+    """n = 29 / 30 / 32 = QMLE_MAX_QUBITS (4 / 8 / 32 GiB per state; the fast tile kernel addresses a state with 32-bit byte
     offsets up to n = 28, larger registers take the generic kernels): RY on every wire, CX on the
     first and the last pair, a diagonal and a controlled rotation -- closed forms <Z_w> = cos t_w,
     <Z_1> = cos t_0 cos t_1, <Z_{n-1}> = cos t_{n-2} cos t_{n-1} (`operations.py:1029-1031,1074`);
@@ -356,6 +356,7 @@ def test_registers_beyond_28_qubits(n):
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n)
+    tol = 2e-6 if n <= 30 else 4e-6  # (float32 sums over 2^32 amplitudes)
     th = rng.uniform(0, np.pi, n).astype(np.float32)
     th[[0, n - 2]], th[[1, n - 1]] = np.pi / 2, np.pi / 3
     ops = [("RY", [q], [q], -1) for q in range(n)] + [("CX", [0, 1], [], -1), ("CX", [n - 2, n - 1], [], -1),
@@ -366,17 +367,17 @@ def test_registers_beyond_28_qubits(n):
     want[n - 1] = np.cos(th[n - 2]) * np.cos(th[n - 1])
     for flags in (0, N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB):
         z = N.Plan(ops, n, n + 2, flags=flags).run(ang, "expval", list(range(n))).cpu().numpy()[0]
-        assert np.abs(z - want).max() < 2e-6, flags
+        assert np.abs(z - want).max() < tol, flags
     st = N.Plan(ops, n, n + 2).run(ang, "state")
     assert abs(float((st.abs() ** 2).sum()) - 1.0) < 1e-5
-    assert np.abs(N.expval_z(st, list(range(n))).cpu().numpy()[0] - want).max() < 2e-6
+    assert np.abs(N.expval_z(st, list(range(n))).cpu().numpy()[0] - want).max() < tol
     q, pur = N.meyer_wallach(st, return_purities=True)
     pur = pur.cpu().numpy()[0].astype(np.float64)
     # wires outside the two CX pairs are in product states (purity 1); a pair RY(a), RY(b), CX has
     # Tr rho^2 = 1 - sin^2(a) cos^2(b) / 2 on both of its wires: 0.875 for a = pi/2, b = pi/3
     free = [w for w in range(n) if w not in (0, 1, n - 2, n - 1)]
-    assert np.abs(pur[free] - 1.0).max() < 5e-6
-    assert np.abs(pur[[0, 1, n - 2, n - 1]] - 0.875).max() < 5e-6
-    assert abs(float(q) - 2 * (1 - pur.mean())) < 5e-6
+    assert np.abs(pur[free] - 1.0).max() < 2 * tol
+    assert np.abs(pur[[0, 1, n - 2, n - 1]] - 0.875).max() < 2 * tol
+    assert abs(float(q) - 2 * (1 - pur.mean())) < 2 * tol
     del st
     torch.cuda.empty_cache()
