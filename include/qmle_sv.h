@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 142 /* 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 143 /* 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -293,6 +293,10 @@ int qmle_meyer_wallach_reads(int n_qubits);
  * numpy's Philox, and numpy's own loop (~9 ns per value) was two thirds of the wall-clock of
  * Expressibility(12 q, 1024 pairs). */
 int qmle_philox_uniform_f32(const uint64_t key[2], uint64_t n, double low, double high, float *out);
+/* The same stream written by the GPU into d_out (one work item per Philox block; bit for bit the
+ * host version's floats): what utils.uniform uses when a GPU is present. */
+int qmle_philox_uniform_f32_device(const uint64_t key[2], uint64_t n, double low, double high,
+                                   float *d_out, qmle_stream stream);
 /* numpy.histogram(values, bins=linspace(lo,hi,n_bins+1)) counts (last bin
  * right-inclusive) -- expressibility.py:104-108; d_counts int32[n_bins], zeroed
  * by the call */

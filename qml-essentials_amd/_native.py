@@ -123,6 +123,7 @@ SYMBOLS = [
     ("qmle_meyer_wallach_workspace_bytes", _SZ, [_I, _I]),
     ("qmle_meyer_wallach_reads", _I, [_I]),
     ("qmle_philox_uniform_f32", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP]),
+    ("qmle_philox_uniform_f32_device", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP, _VP]),
     ("qmle_run_batch_f64", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_workspace_bytes_f64", _SZ, [_VP, _I, _I]),
     ("qmle_plan_set_consts_f64", _I, [_VP, C.POINTER(C.c_double), _I]),
@@ -669,6 +670,19 @@ def philox_uniform(key, count: int, low: float, high: float) -> np.ndarray:
     out = np.empty(int(count), dtype=np.float32)
     check(lib().qmle_philox_uniform_f32(key.ctypes.data, int(count), float(low), float(high),
                                           out.ctypes.data))
+    return out
+
+
+def philox_uniform_device(key, count: int, low: float, high: float):
+    """:func:`philox_uniform` written by the GPU: float32 CUDA tensor [count], the same bits."""
+    torch = require_gpu()
+    key = np.ascontiguousarray(key, dtype=np.uint64)
+    if key.shape != (2,):
+        raise ValueError("Philox4x64 takes a key of two 64-bit words")
+    out = torch.empty((int(count),), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    check(lib().qmle_philox_uniform_f32_device(key.ctypes.data, int(count), float(low), float(high),
+                                               C.c_void_p(out.data_ptr()), _stream_ptr()),
+          "qmle_philox_uniform_f32_device")
     return out
 
 

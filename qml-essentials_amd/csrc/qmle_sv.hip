@@ -3132,6 +3132,38 @@ k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
 
 // Meyer-Wallach cross terms c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) plus the
 // populations a_j, d_j; one launch per bit (v1: n reads of the state).
+// ---- parameter sampler on the device ---------------------------------------------------------
+// numpy's Philox4x64-10 stream (csrc/qmle_rng.cpp restates it on the host): block b of the stream
+// is philox(counter = b + 1, key) -- any block on its own, one work item per block of four values.
+// The arithmetic after the generator is numpy's, rounding for rounding: u = (x >> 11) * 2^-53
+// (exact), low + range * u as a rounded product and a rounded sum (no fused multiply-add), cast to
+// float32.  Expressibility(12 q, 1024 pairs) spent 0.4 of its 0.9 ms drawing parameters on the host.
+__global__ void __launch_bounds__(256)
+k_philox_uniform(uint64_t k0, uint64_t k1, uint64_t n, double low, double range, float *__restrict__ out) {
+  const uint64_t blocks = (n + 3) / 4;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t c0 = b + 1, c1 = 0, c2 = 0, c3 = 0, a0 = k0, a1 = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint64_t M0 = 0xD2E7470EE14C6C93ull, M1 = 0xCA5A826395121157ull;
+      const uint64_t hi0 = __umul64hi(M0, c0), lo0 = M0 * c0, hi1 = __umul64hi(M1, c2), lo1 = M1 * c2;
+      const uint64_t n0 = hi1 ^ c1 ^ a0, n2 = hi0 ^ c3 ^ a1;
+      c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+      a0 += 0x9E3779B97F4A7C15ull;
+      a1 += 0xBB67AE8584CAA73Bull;
+    }
+    const uint64_t v[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t i = 4 * b + (uint64_t)j;
+      if (i < n) {
+        const double u = __dmul_rn((double)(v[j] >> 11), 1.0 / 9007199254740992.0);
+        out[i] = (float)__dadd_rn(low, __dmul_rn(range, u));
+      }
+    }
+  }
+}
+
 // partial[b][bit][block] = (re c, im c, a, d)
 __global__ void __launch_bounds__(256)
 k_cross_partial(const float4 *__restrict__ states, int n, int p, float4 *__restrict__ partial,
@@ -5987,6 +6019,16 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
                        (const float4 *)d_states, n_qubits, p, (float4 *)d_workspace, nb);
   hipLaunchKernelGGL(k_mw_final, dim3(batch), dim3(nb >= 256 ? 256 : 64), 0, stream,
                      (const float4 *)d_workspace, n_qubits, nb, batch, d_out, d_purities);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_philox_uniform_f32_device(const uint64_t key[2], uint64_t n, double low, double high, float *d_out,
+                                   qmle_stream stream_) {
+  if (!key || (!d_out && n > 0) || n > (1ull << 40)) return QMLE_ERR_INVALID_ARG;
+  if (n == 0) return QMLE_OK;
+  hipLaunchKernelGGL(k_philox_uniform, dim3(grid_for((n + 3) / 4, 256, 1u << 16)), dim3(256), 0, (hipStream_t)stream_,
+                     key[0], key[1], n, low, high - low, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

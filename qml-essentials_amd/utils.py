@@ -109,7 +109,22 @@ def uniform(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
     from . import _native as N
 
     n = int(np.prod(shape)) if shape else 1
-    return N.philox_uniform(k._seq.generate_state(2, np.uint64), n, minval, maxval).reshape(shape)
+    state = k._seq.generate_state(2, np.uint64)
+    # large draws on a GPU box: the same stream written by the GPU (one work item per Philox block)
+    # and copied back -- the host loop costs 0.14 ms per 73 728 values in a hot loop and 0.4 ms inside
+    # an analysis loop that has just waited for the GPU; QMLE_HOST_SAMPLER=1 keeps the host loop
+    if n >= 16384 and not os.environ.get("QMLE_HOST_SAMPLER") and _gpu_present():
+        return N.philox_uniform_device(state, n, minval, maxval).cpu().numpy().reshape(shape)
+    return N.philox_uniform(state, n, minval, maxval).reshape(shape)
+
+
+def _gpu_present() -> bool:
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except Exception:  # pragma: no cover
+        return False
 
 
 class random:  # namespace so that ``from ...utils import random; random.key(0)`` reads like jax

@@ -836,3 +836,34 @@ def test_batches_longer_than_one_launch_row_limit():
     # complex128 engine
     o64 = plan.run64(ang.double(), "expval", [[q_] for q_ in range(n)])
     assert o64.shape == (B, n) and (o64[rows].float() - plan.run(sub_ang, "expval", list(range(n)))).abs().max().item() < 1e-6
+
+
+def test_device_parameter_sampler_is_numpys_stream_bit_for_bit():
+    """qmle_philox_uniform_f32_device == numpy.random.Generator(Philox(key)).uniform(...).astype(float32)
+    == the host-side qmle_philox_uniform_f32, for lengths around the block boundaries, spawned keys and
+    other ranges; `utils.uniform` (the sampler of `Model.initialize_params`, `model.py:687-693`) draws
+    the same parameters through either."""
+    import os
+
+    from qml_essentials_amd import _native as N
+    from qml_essentials_amd import utils
+
+    for seed in (0, 1000, 2**40 + 3):
+        for n in (1, 2, 3, 4, 5, 1023, 1024, 1025, 73728, 262147, (1 << 20) + 1):
+            state = np.random.SeedSequence(seed).generate_state(2, np.uint64)
+            ref = np.random.Generator(np.random.Philox(np.random.SeedSequence(seed))).uniform(0, 2 * np.pi, n).astype(np.float32)
+            got = N.philox_uniform_device(state, n, 0.0, 2 * np.pi).cpu().numpy()
+            assert np.array_equal(ref, got), (seed, n)
+            assert np.array_equal(got, N.philox_uniform(state, n, 0.0, 2 * np.pi))
+    child = np.random.SeedSequence(5).spawn(3)[2]
+    ref = np.random.Generator(np.random.Philox(child)).uniform(-1.5, 3.25, 40001).astype(np.float32)
+    again = np.random.SeedSequence(entropy=child.entropy, spawn_key=child.spawn_key)
+    assert np.array_equal(ref, N.philox_uniform_device(again.generate_state(2, np.uint64), 40001, -1.5, 3.25).cpu().numpy())
+    k = utils.key(7).split(3)[1]
+    a = utils.uniform(k, (2048, 3, 12), 0.0, 2 * np.pi)          # device route (>= 16384 values)
+    os.environ["QMLE_HOST_SAMPLER"] = "1"
+    try:
+        b = utils.uniform(k, (2048, 3, 12), 0.0, 2 * np.pi)      # host route
+    finally:
+        del os.environ["QMLE_HOST_SAMPLER"]
+    assert a.dtype == np.float32 and a.shape == (2048, 3, 12) and np.array_equal(a, b)
