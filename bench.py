@@ -406,21 +406,27 @@ VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak, /opt/skills/guides/MI355X_M
 
 def _wall(fn, reps):
     """Median wall-clock of `fn` over `reps` calls, each bracketed by synchronize + barrier;
-    max over ranks per call (the job is done when the slowest rank is)."""
+    max over ranks per call (the job is done when the slowest rank is).  Also the GPU's share:
+    HIP events on the launch stream around the call (first launch enqueued -> last kernel done),
+    median over the calls on this rank."""
     from qml_essentials_amd import distributed
 
-    ts = []
+    ts, gs = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(reps):
         torch.cuda.synchronize()
         distributed.barrier()
         t0 = time.perf_counter()
+        e0.record()
         out = fn()
+        e1.record()
         torch.cuda.synchronize()
         ts.append(max(max_over_ranks(time.perf_counter() - t0)))
-    return sorted(ts)[len(ts) // 2], out
+        gs.append(e0.elapsed_time(e1))
+    return sorted(ts)[len(ts) // 2], out, sorted(gs)[len(gs) // 2]
 
 
-def expressibility_leg(n=12, samples=1024, reps=5):
+def expressibility_leg(n=12, samples=1024, reps=21):
     """BASELINE config 3 (strong scaling): KL-to-Haar, 12 qubits, 1024 pairs (2048 states), HE 3
     layers, no DRU; the PAIRS are split over the ranks, one all-gather of 1024 floats."""
     from qml_essentials_amd import distributed
@@ -429,16 +435,20 @@ def expressibility_leg(n=12, samples=1024, reps=5):
 
     m = Model(n, 3, "Hardware_Efficient", data_reupload=False)
     Expressibility.kl_divergence_to_haar(m, n_samples=max(64, distributed.world()[1]), n_bins=75, random_key=1)
-    sec, kl = _wall(lambda: Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75,
-                                                                 random_key=1000), reps)
+    for _ in range(3):
+        Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75, random_key=1000)
+    sec, kl, gpu_ms = _wall(lambda: Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75,
+                                                                         random_key=1000), reps)
     size = distributed.world()[1]
-    return {"seconds": round(sec, 6), "kl": float(np.mean(kl)), "n_qubits": n, "pairs": samples,
+    return {"seconds": round(sec, 6), "gpu_ms": round(gpu_ms, 4), "kl": float(np.mean(kl)), "n_qubits": n, "pairs": samples,
             "pairs_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(samples, size)],
             "scaling": "strong", "collective": "one all-gather of the fidelities (4 KiB)",
-            "note": "median of %d calls, max over ranks; host-side parameter sampling + histogram included" % reps}
+            "note": "median of %d calls, max over ranks; the whole call: parameter sampling (on the GPU), 2 x pairs states, "
+                    "fidelities, histogram (GPU), one device -> host copy of the 75 counts, KL on the host; gpu_ms = HIP events "
+                    "around the call on the launch stream" % reps}
 
 
-def fourier_grid_leg(n=10, layers=6, points=4096, reps=5):
+def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
     """BASELINE config 4 (strong scaling): Model(10, 6, HE) on the 2^12-point input grid,
     expval averaged over the wires; the GRID is split over the ranks (512 points per GPU at N = 8),
     one all-gather of (4096, 10) floats; the FFT of the 4096 values runs on the host."""
@@ -449,17 +459,21 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=5):
     x = torch.from_numpy((2 * np.pi * np.arange(points) / points).astype(np.float32).reshape(-1, 1)).cuda()
 
     def call():
+        # what Coefficients._fourier_transform does with its own (device-resident) grid: one
+        # device -> host copy of the 4096 values, float64 FFT on the host (25 us)
         y = m(inputs=x, force_mean=True)
         return np.fft.fft(y.cpu().numpy().astype(np.float64)) / points
 
-    call()
-    sec, coeffs = _wall(call, reps)
+    for _ in range(3):
+        call()
+    sec, coeffs, gpu_ms = _wall(call, reps)
     size = distributed.world()[1]
-    return {"seconds": round(sec, 6), "n_qubits": n, "n_layers": layers, "grid_points": points,
+    return {"seconds": round(sec, 6), "gpu_ms": round(gpu_ms, 4), "n_qubits": n, "n_layers": layers, "grid_points": points,
             "points_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(points, size)],
             "c0": float(coeffs[0].real), "max_abs_coeff_beyond_degree": float(np.abs(coeffs[layers * n + 1:points // 2]).max()),
             "scaling": "strong", "collective": "one all-gather of the expectation values (160 KiB)",
-            "note": "median of %d calls, max over ranks; device -> host copy + host FFT included" % reps}
+            "note": "median of %d calls, max over ranks; circuit batch on the GPU, one device -> host copy of the values, "
+                    "float64 FFT on the host; gpu_ms = HIP events around the call on the launch stream" % reps}
 
 
 def sampling_loops_cpu(budget_pairs=128, budget_points=384):

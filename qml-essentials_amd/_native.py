@@ -181,7 +181,13 @@ def check(status: int, what: str = "") -> None:
     raise _STATUS_EXC.get(status, RuntimeError)(f"{what}: {msg} (qmle status {status})")
 
 
+_torch_gpu = None  # torch, once a GPU has been seen (the answer does not change within a process)
+
+
 def require_gpu():
+    global _torch_gpu
+    if _torch_gpu is not None:
+        return _torch_gpu
     import torch
 
     if not torch.cuda.is_available():
@@ -189,13 +195,28 @@ def require_gpu():
             "qml-essentials_amd needs an AMD GPU (gfx950); no CPU fallback exists. "
             "Run on the MI355X box (gpurun)."
         )
+    _torch_gpu = torch
     return torch
 
 
-def _stream_ptr():
-    import torch
+def current_device():
+    """``torch.device`` of the current GPU (cached objects: this sits on every call's path)."""
+    torch = require_gpu()
+    i = torch.cuda.current_device()
+    d = _devices.get(i)
+    if d is None:
+        d = _devices[i] = torch.device("cuda", i)
+    return d
 
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+_devices: dict = {}
+
+
+def _stream_ptr():
+    # the raw hipStream_t of torch's current stream (what `current_stream().cuda_stream` returns,
+    # without building a Stream object per launch)
+    torch = require_gpu()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _i32(values: Sequence[int]):
@@ -323,7 +344,7 @@ class Plan:
         torch = require_gpu()
         if meas not in MEAS:
             raise ValueError(f"Unknown measurement type: {meas!r}")  # simulation.py:271
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = current_device()
         if angles is None:
             angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float32, device=dev)
         angles = angles.to(device=dev, dtype=torch.float32).contiguous()
@@ -357,7 +378,7 @@ class Plan:
         torch = require_gpu()
         if meas not in MEAS:
             raise ValueError(f"Unknown measurement type: {meas!r}")  # simulation.py:271
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = current_device()
         if angles is None:
             angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float64, device=dev)
         angles = angles.to(device=dev, dtype=torch.float64).contiguous()
@@ -392,7 +413,7 @@ class Plan:
         """<Z..Z> over every wire group, measured out of the last pass (no stored state).
         Returns float32 [B, len(wire_groups)]."""
         torch = require_gpu()
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = current_device()
         if angles is None:
             angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float32, device=dev)
         angles = angles.to(device=dev, dtype=torch.float32).contiguous()
@@ -679,7 +700,7 @@ def philox_uniform_device(key, count: int, low: float, high: float):
     key = np.ascontiguousarray(key, dtype=np.uint64)
     if key.shape != (2,):
         raise ValueError("Philox4x64 takes a key of two 64-bit words")
-    out = torch.empty((int(count),), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty((int(count),), dtype=torch.float32, device=current_device())
     check(lib().qmle_philox_uniform_f32_device(key.ctypes.data, int(count), float(low), float(high),
                                                C.c_void_p(out.data_ptr()), _stream_ptr()),
           "qmle_philox_uniform_f32_device")

@@ -47,12 +47,16 @@ class Entanglement:
             random_key = model.initialize_params(random_key, repeat=int(n_samples))
         kwargs.setdefault("inputs", None)
         kwargs.pop("execution_type", None)
-        params = np.asarray(model.params)
+        # sampled parameters stay on the GPU (the reference's are jax device arrays,
+        # entanglement.py:52-60); small draws / user-set parameters are host arrays
+        params = model.device_params()
+        if params is None:
+            params = np.asarray(model.params)
         total = params.shape[0]
         lo, hi, sharded = distributed.my_block(total, params, kwargs.get("inputs"))
         with distributed.local_only():
-            states = model._forward(params=params[lo:hi], execution_type="state",
-                                    as_tensor=True, **kwargs)
+            states = model._forward(params=params[lo:hi] if sharded else params,
+                                    execution_type="state", as_tensor=True, **kwargs)
         model.params = params
         ent = cls._compute_meyer_wallach_meas(states, model.n_qubits)
         if sharded:

@@ -30,22 +30,34 @@ class Expressibility:
         kwargs = dict(kwargs or {})
         n_samples = int(n_samples)
         model.initialize_params(random_key, repeat=n_samples * 2)
-        params = np.asarray(model.params)
-        lo, hi, sharded = distributed.my_block(n_samples, params, kwargs.get("inputs"))
-        local = np.concatenate([params[lo:hi], params[n_samples + lo: n_samples + hi]])
         kwargs.pop("execution_type", None)
+        torch = N.require_gpu()
+        # The samples stay where they were drawn (the reference's are jax device arrays,
+        # model.py:687-693 -> expressibility.py:38-46): a large draw is written by the GPU sampler
+        # and handed to the engine as it lies; only small draws come from the host generator.
+        params = model.device_params()
+        if params is None:
+            params = np.asarray(model.params)
+        lo, hi, sharded = distributed.my_block(n_samples, params, kwargs.get("inputs"))
+        if sharded:  # this rank's pairs {i, i + S}: both states of a pair stay on one rank
+            local = params.reshape(2, n_samples, *params.shape[1:])[:, lo:hi]
+            local = local.reshape(2 * (hi - lo), *params.shape[1:])
+        else:
+            local = params
         with distributed.local_only():
             states = model._forward(params=local, execution_type="state", as_tensor=True, **kwargs)
-        model.params = params
+        model.params = params  # (all 2S sets, like the reference)
         b_i = model.batch_shape[0]
+        if b_i == 1:
+            fid = N.pair_fidelity(states)                       # (local pairs,)
+            if sharded:
+                fid = distributed.all_gather_rows(fid, n_samples)
+            return fid
         states = states.reshape(b_i, 2 * (hi - lo), -1)
-        fid = [N.pair_fidelity(states[i].contiguous()) for i in range(b_i)]
-        torch = N.require_gpu()
-        fid = torch.stack(fid, dim=1)  # (local pairs, B_I)
+        fid = torch.stack([N.pair_fidelity(states[i]) for i in range(b_i)], dim=1)  # (pairs, B_I)
         if sharded:
             fid = distributed.all_gather_rows(fid, n_samples)
-        fid = fid.transpose(0, 1)
-        return fid[0] if b_i == 1 else fid  # device tensor, (S,) or (B_I, S)
+        return fid.transpose(0, 1)  # device tensor (B_I, S)
 
     @classmethod
     def state_fidelities(cls, n_samples: int, n_bins: int, model: Model, random_key=None,
@@ -58,10 +70,12 @@ class Expressibility:
         fid = cls._sample_state_fidelities(model=model, n_samples=n_samples,
                                            random_key=random_key, kwargs=kwargs)
         y = np.linspace(0, 1, n_bins + 1)
+        # bin on the GPU; the one device -> host copy of the call is the (rows x n_bins) counts
         if fid.dim() == 1:
             z = N.histogram(fid, n_bins, 0.0, 1.0).cpu().numpy() / n_samples
         else:
-            z = np.stack([N.histogram(row, n_bins, 0.0, 1.0).cpu().numpy() for row in fid]) / n_samples
+            torch = N.require_gpu()
+            z = torch.stack([N.histogram(row, n_bins, 0.0, 1.0) for row in fid]).cpu().numpy() / n_samples
         return y, z
 
     @classmethod

@@ -22,7 +22,8 @@ from .tape import recording
 from .ansaetze import Ansaetze, Circuit, Encoding
 from .batching import to_numpy
 from .gates import Gates
-from .utils import PRNGKey, as_key, safe_random_split, uniform
+from .utils import (PRNGKey, as_key, device_sampling, safe_random_split, uniform,
+                    uniform_device)
 
 log = logging.getLogger(__name__)
 
@@ -56,6 +57,7 @@ class Model:
         # x64 (extension): run this model on the complex128 engine regardless of the global
         # ``utils.enable_x64`` switch (None = follow it) -- the reference's ``jax_enable_x64`` mode
         self.x64 = x64
+        self._params, self._params_dev = None, None
         self.n_qubits = n_qubits
         self.output_qubit = output_qubit
         self.n_layers = n_layers
@@ -180,14 +182,29 @@ class Model:
 
     @property
     def params(self) -> np.ndarray:
+        """Host view of the parameters.  When they were drawn (or set) on the GPU the host
+        mirror is materialised on first access -- like a ``jax`` device array, which the
+        reference's ``params`` are (``model.py:687-693``), turns into NumPy only when asked."""
+        if self._params is None:
+            self._params = self._params_dev.detach().cpu().numpy().astype(np.float64)
         return self._params
 
     @params.setter
     def params(self, value) -> None:
+        if self._is_cuda(value):  # device-resident: no copy, the host mirror is lazy
+            value = value.detach()
+            if value.dim() == 2:
+                value = value.unsqueeze(0)
+            self._params_dev, self._params = value, None
+            return
         value = to_numpy(value)
         if len(value.shape) == 2:
             value = value.reshape(1, *value.shape)
-        self._params = value
+        self._params, self._params_dev = value, None
+
+    def device_params(self):
+        """The float32 CUDA tensor behind ``params`` when they live on the GPU, else None."""
+        return self._params_dev
 
     @property
     def enc_params(self) -> np.ndarray:
@@ -284,9 +301,13 @@ class Model:
         )
 
         def draw():
+            # large draws stay where the GPU sampler wrote them (the analysis loops feed them
+            # straight back into the engine); `params` materialises a host mirror on demand
+            if device_sampling(int(np.prod(shape))):
+                return uniform_device(sub, shape, minval=lo, maxval=hi)
             return uniform(sub, shape, minval=lo, maxval=hi)
 
-        def pin_controlled(params: np.ndarray, value: float) -> np.ndarray:
+        def pin_controlled(params, value: float):
             idx = self.pqc.get_control_indices(self.n_qubits)
             if idx is None:
                 warnings.warn(
@@ -295,7 +316,8 @@ class Model:
                     UserWarning,
                 )
                 return params
-            params = np.array(params)
+            if not self._is_cuda(params):
+                params = np.array(params)
             if len(idx) == 3 and None in idx:
                 params[:, :, idx[0]:idx[1]:idx[2]] = value
             else:
@@ -695,7 +717,7 @@ class Model:
         return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
     def _forward_device(self, params, inputs, enc_params, execution_type, force_mean,
-                        _want_call: bool = False):
+                        _want_call: bool = False, raw: bool = False):
         """``__call__`` for CUDA-tensor ``params`` / ``inputs``: nothing per sample happens on
         the host and the result stays on the GPU (a ``torch`` tensor).  Falls back to the host
         path (returns ``NotImplemented``) for partial-wire density / probs or non-affine angles."""
@@ -793,6 +815,8 @@ class Model:
         result = cc.run(leaves, divs, mods, hi - lo, lo)
         if sharded:
             result = distributed.all_gather_rows(result, B)
+        if raw:  # the analysis loops' (B, ...) device tensor, batch axis flat
+            return result
         result = result.reshape((*[int(d) for d in self.eff_batch_shape], *self._result_shape))
         result = result.squeeze()
         if et in ("expval", "probs") and force_mean and result.dim() > 0 and self._result_shape[0] > 1:
@@ -877,16 +901,25 @@ class Model:
 
     def _forward_impl(self, params, inputs, pulse_params, enc_params, data_reupload, noise_params,
                       execution_type, force_mean, gate_mode, as_tensor, x64=False):
-        if (self._is_cuda(params) or self._is_cuda(inputs)) and not as_tensor \
+        user_cuda = self._is_cuda(params) or self._is_cuda(inputs)
+        own_dev = params is None and self._params_dev is not None and not x64
+        if own_dev:  # the model's own parameters live on the GPU (a large initialize_params draw)
+            params = self._params_dev
+        if (self._is_cuda(params) or self._is_cuda(inputs)) \
+                and (not as_tensor or (execution_type or self.execution_type) == "state") \
                 and noise_params is None and self.noise_params is None and gate_mode == "unitary" \
                 and pulse_params is None and self.shots is None:
             if data_reupload is not None:
                 self.data_reupload = data_reupload
-            out = self._forward_device(params, inputs, enc_params, execution_type, force_mean)
+            out = self._forward_device(params, inputs, enc_params, execution_type, force_mean,
+                                       raw=as_tensor)
             if out is not NotImplemented:
-                return out
-            params = params.detach().cpu().numpy() if self._is_cuda(params) else params
-            inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
+                # CUDA tensors in -> CUDA tensor out; host arguments get a host array back
+                return out if (user_cuda or as_tensor) else out.cpu().numpy()
+        if own_dev:
+            params = None  # (-> the lazily materialised host mirror, self.params)
+        params = params.detach().cpu().numpy() if self._is_cuda(params) else params
+        inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
         # (as_tensor: the analysis loops -- Expressibility, Meyer-Wallach -- ask for the raw device
         # tensor of states; the compiled call serves them too: no tape re-recording per call)
         if (noise_params is None and self.noise_params is None

@@ -97,6 +97,42 @@ def safe_random_split(random_key: Optional[PRNGKey], *args, num: int = 2, **kwar
     return tuple(parts) if num == 2 else parts
 
 
+def _philox_words(k: PRNGKey) -> np.ndarray:
+    """The two 64-bit key words numpy's Philox takes from the key's SeedSequence (cached per key:
+    the hash behind ``generate_state`` costs ~10 us, an analysis loop re-seeded with the same key
+    every call should not pay it each time)."""
+    ident = (k._seq.entropy, tuple(k._seq.spawn_key), k._seq.pool_size)
+    w = _WORDS.get(ident)
+    if w is None:
+        if len(_WORDS) > 4096:
+            _WORDS.clear()
+        w = _WORDS[ident] = k._seq.generate_state(2, np.uint64)
+    return w
+
+
+_WORDS: dict = {}
+DEVICE_SAMPLER_MIN = 16384  # draws of at least this many values are written by the GPU
+
+
+def device_sampling(n: int) -> bool:
+    """True when a draw of ``n`` values comes from the GPU sampler (``uniform`` copies it back,
+    ``uniform_device`` leaves it in HBM)."""
+    return (n >= DEVICE_SAMPLER_MIN and not os.environ.get("QMLE_HOST_SAMPLER")
+            and not os.environ.get("QMLE_NUMPY_SAMPLER") and _gpu_present())
+
+
+def uniform_device(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
+                   maxval: float = 1.0):
+    """:func:`uniform` left where the GPU wrote it: a float32 CUDA tensor of ``shape`` holding
+    numpy's Philox stream bit for bit (``qmle_philox_uniform_f32_device``).  What
+    ``jax.random.uniform`` hands the reference (``model.py:687-693``) is a device array too."""
+    from . import _native as N
+
+    shape = tuple(int(d) for d in shape)
+    n = int(np.prod(shape)) if shape else 1
+    return N.philox_uniform_device(_philox_words(as_key(random_key)), n, minval, maxval).reshape(shape)
+
+
 def uniform(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
             maxval: float = 1.0) -> np.ndarray:
     # numpy's Philox4x64-10 stream under the key's SeedSequence, produced by the library's host-side
@@ -109,13 +145,12 @@ def uniform(random_key: PRNGKey, shape: Sequence[int], minval: float = 0.0,
     from . import _native as N
 
     n = int(np.prod(shape)) if shape else 1
-    state = k._seq.generate_state(2, np.uint64)
     # large draws on a GPU box: the same stream written by the GPU (one work item per Philox block)
     # and copied back -- the host loop costs 0.14 ms per 73 728 values in a hot loop and 0.4 ms inside
     # an analysis loop that has just waited for the GPU; QMLE_HOST_SAMPLER=1 keeps the host loop
-    if n >= 16384 and not os.environ.get("QMLE_HOST_SAMPLER") and _gpu_present():
-        return N.philox_uniform_device(state, n, minval, maxval).cpu().numpy().reshape(shape)
-    return N.philox_uniform(state, n, minval, maxval).reshape(shape)
+    if device_sampling(n):
+        return uniform_device(k, shape, minval, maxval).cpu().numpy()
+    return N.philox_uniform(_philox_words(k), n, minval, maxval).reshape(shape)
 
 
 def _gpu_present() -> bool:
