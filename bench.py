@@ -125,7 +125,7 @@ def plan_flags(flags):
 
 
 def kernel_of_stage(st, i, n_stages, n, dense):
-    """Which kernel a stage launch runs (mirrors launch_tile / run_batch_masks in qmle_sv.hip)."""
+    """Which kernel a stage launch runs (mirrors launch_tile in qmle_tile.hip / run_batch_masks in qmle_engine.hip)."""
     if st["kind"] != "tile":
         return {"direct": "k_direct_1q", "diag_all": "k_diag_all"}[st["kind"]]
     if i == n_stages - 1:  # <Z> out of the last pass: a single-group pass measures in registers
@@ -252,10 +252,11 @@ def source_sha16():
     """Hash of the sources that decide what a kernel launch moves: profiles/traffic.json records the
     one its PMC counters were collected for, and a mismatch makes `traffic` null (never stale)."""
     h = hashlib.sha256()
-    for rel in ("qml-essentials_amd/csrc/qmle_sv.hip", "qml-essentials_amd/csrc/qmle_plan.cpp",
-                "qml-essentials_amd/csrc/qmle_internal.h"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+    csrc = os.path.join(ROOT, "qml-essentials_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):  # every translation unit and header of libqmle_sv
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + f.read())
     return h.hexdigest()[:16]
 
 

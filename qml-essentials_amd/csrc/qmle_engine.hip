@@ -1,0 +1,752 @@
+// libqmle_sv, engine: plan objects on the device, the angle table / gate matrix builders, and the
+// C-ABI entry points that run a plan (qmle_run_batch, qmle_apply_inplace, profiling).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <new>
+#include <utility>
+
+#include "qmle_internal.h"
+#include "qmle_host.h"
+#include "qmle_dev.h"
+#include "qmle_matrices.h"
+
+namespace {
+
+__global__ void k_build_matrices(const BuildOp *__restrict__ build,
+                                 const BuildGroup *__restrict__ groups, int n_groups,
+                                 const float *__restrict__ angles, int n_slots,
+                                 const float *__restrict__ consts, float *__restrict__ mats,
+                                 uint32_t mat_floats) {
+  build_matrices_body<float, float, float>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats);
+}
+
+// ---------------------------------------------------------------------------
+// angle table from device-resident leaves:  table[b][s] = c[s] + sum_t coef[t] * leaf_{arg[t]}[row][idx[t]]
+// (gate angles are affine in params / inputs, ansaetze.py:323-371, model.py:804-816); the row
+// of leaf k for flattened sample b is (b / div_k) % mod_k -- the cartesian batch of
+// model.py:1449-1481 without materialising the repeats.
+// ---------------------------------------------------------------------------
+struct AngleLeaves {
+  const float *ptr[8];
+  long long stride[8];  // floats per row
+  int div[8], mod[8];
+};
+
+__global__ void __launch_bounds__(256)
+k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restrict__ arg,
+               const int *__restrict__ idx, const float *__restrict__ coef,
+               const float *__restrict__ cst, const double *__restrict__ period, int n_slots,
+               long long batch, long long b_offset, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * n_slots) return;
+  const long long b = i / n_slots;
+  const int s = (int)(i - b * n_slots);
+  const long long gb = b + b_offset;
+  // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
+  // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
+  // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
+  double acc = (double)cst[s];
+  for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
+    const int k = arg[t];
+    const long long row = (gb / lv.div[k]) % lv.mod[k];
+    acc = fma((double)coef[t], (double)lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
+  }
+  const double per = period ? period[s] : 0.0;
+  if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
+  out[i] = (float)acc;
+}
+
+}  // namespace
+
+namespace qmle {
+
+int ensure_device_plan(qmle_plan *p) {
+  if (p->dev.blob) {
+    // the plan's device image lives on the device of its first run: refuse another one rather
+    // than hand kernels a pointer they cannot read
+    return p->dev.device == current_device() ? QMLE_OK : QMLE_ERR_UNSUPPORTED;
+  }
+  p->dev.device = current_device();
+  const size_t b_ops = align_up(p->dev_ops.size() * sizeof(LoweredOp) + 16, 256);
+  const size_t b_build = align_up(p->build_ops.size() * sizeof(BuildOp) + 16, 256);
+  const size_t b_groups = align_up(p->groups.size() * sizeof(BuildGroup) + 16, 256);
+  const size_t b_consts = align_up(p->consts.size() * sizeof(float) + 16, 256);
+  const size_t b_opg = align_up(p->op_groups.size() * sizeof(OpGroup) + 16, 256);
+  const size_t b_ops2 = align_up(p->ops2.size() * sizeof(LoweredOp) + 16, 256);
+  const size_t b_grp2 = align_up(p->groups2.size() * sizeof(Group2) + 16, 256);
+  const size_t b_tbl2 = align_up(p->tbl2.size() * sizeof(uint32_t) + 16, 256);
+  const size_t total = b_ops + b_build + b_groups + b_consts + b_opg + b_ops2 + b_grp2 + b_tbl2;
+  char *blob = nullptr;
+  HIPCHK(hipMalloc((void **)&blob, total));
+  p->dev.blob = blob;
+  p->dev.blob_bytes = total;
+  p->dev.d_ops = (LoweredOp *)blob;
+  p->dev.d_build = (BuildOp *)(blob + b_ops);
+  p->dev.d_groups = (BuildGroup *)(blob + b_ops + b_build);
+  p->dev.d_consts = (float *)(blob + b_ops + b_build + b_groups);
+  p->dev.d_op_groups = (OpGroup *)(blob + b_ops + b_build + b_groups + b_consts);
+  char *fast = blob + b_ops + b_build + b_groups + b_consts + b_opg;
+  p->dev.d_ops2 = (LoweredOp *)fast;
+  p->dev.d_groups2 = (Group2 *)(fast + b_ops2);
+  p->dev.d_tbl2 = (uint32_t *)(fast + b_ops2 + b_grp2);
+  if (!p->ops2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_ops2, p->ops2.data(), p->ops2.size() * sizeof(LoweredOp),
+                     hipMemcpyHostToDevice));
+  if (!p->groups2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_groups2, p->groups2.data(), p->groups2.size() * sizeof(Group2),
+                     hipMemcpyHostToDevice));
+  if (!p->tbl2.empty())
+    HIPCHK(hipMemcpy(p->dev.d_tbl2, p->tbl2.data(), p->tbl2.size() * sizeof(uint32_t),
+                     hipMemcpyHostToDevice));
+  if (!p->op_groups.empty())
+    HIPCHK(hipMemcpy(p->dev.d_op_groups, p->op_groups.data(),
+                     p->op_groups.size() * sizeof(OpGroup), hipMemcpyHostToDevice));
+  if (!p->dev_ops.empty())
+    HIPCHK(hipMemcpy(p->dev.d_ops, p->dev_ops.data(), p->dev_ops.size() * sizeof(LoweredOp),
+                     hipMemcpyHostToDevice));
+  if (!p->build_ops.empty())
+    HIPCHK(hipMemcpy(p->dev.d_build, p->build_ops.data(),
+                     p->build_ops.size() * sizeof(BuildOp), hipMemcpyHostToDevice));
+  if (!p->groups.empty())
+    HIPCHK(hipMemcpy(p->dev.d_groups, p->groups.data(), p->groups.size() * sizeof(BuildGroup),
+                     hipMemcpyHostToDevice));
+  if (!p->consts.empty())
+    HIPCHK(hipMemcpy(p->dev.d_consts, p->consts.data(), p->consts.size() * sizeof(float),
+                     hipMemcpyHostToDevice));
+  return QMLE_OK;
+}
+
+// A run that starts from |0..0> keeps track of the amplitudes that are still exactly zero
+// (Stage::zero_in); the prefetching experiment does not.
+bool plan_sparse(const qmle_plan *p) {
+  static const bool pf_env = std::getenv("QMLE_PREFETCH") != nullptr;
+  return !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)) && !pf_env;
+}
+
+// per-sample gate matrices for the whole batch: d_mats[b][mat_floats] from d_angles[b][n_slots]
+int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream) {
+  if (p->groups.empty()) return QMLE_OK;
+  const int ng = (int)p->groups.size();
+  for (int b0 = 0; b0 < batch; b0 += 65535) {
+    const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
+    hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, bc), dim3(64), 0, stream, p->dev.d_build,
+                       p->dev.d_groups, ng, d_angles + (size_t)b0 * p->n_slots, p->n_slots, p->dev.d_consts,
+                       d_mats + (size_t)b0 * p->mat_floats, p->mat_floats);
+  }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+}  // namespace qmle
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+// (every qmle_* function below is declared extern "C" by include/qmle_sv.h; the definitions inherit it)
+
+int qmle_sv_version(void) { return QMLE_SV_VERSION; }
+
+const char *qmle_status_string(int status) {
+  switch (status) {
+    case QMLE_OK: return "ok";
+    case QMLE_ERR_INVALID_ARG: return "invalid argument";
+    case QMLE_ERR_WIRE_COUNT: return "wrong number of wires for gate";
+    case QMLE_ERR_DUPLICATE_WIRES: return "duplicate wires";
+    case QMLE_ERR_WIRE_RANGE: return "wire index out of range";
+    case QMLE_ERR_UNKNOWN_OP: return "unknown opcode";
+    case QMLE_ERR_MEAS_TYPE: return "unknown measurement type";
+    case QMLE_ERR_WORKSPACE: return "workspace too small";
+    case QMLE_ERR_HIP: return "HIP runtime error";
+    case QMLE_ERR_NO_DEVICE: return "no HIP device";
+    case QMLE_ERR_UNSUPPORTED: return "unsupported configuration";
+    case QMLE_ERR_SLOT_RANGE: return "angle slot out of range";
+    case QMLE_ERR_INTERNAL: return "internal invariant violated (kernel LDS layout)";
+    default: return "unknown status";
+  }
+}
+
+int qmle_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
+                     const float *consts, int n_consts, unsigned flags, qmle_plan **out) {
+  if (!out || n_ops < 0 || n_slots < 0 || n_consts < 0 || (n_ops > 0 && !ops))
+    return QMLE_ERR_INVALID_ARG;
+  *out = nullptr;
+  qmle_plan *p = new (std::nothrow) qmle_plan();
+  if (!p) return QMLE_ERR_INVALID_ARG;
+  flags &= ~QMLE_PLAN_INTERNAL_ZERO_RUN;  // internal: set below on the plans only qmle_run_batch executes
+  p->n = n_qubits;
+  p->n_slots = n_slots;
+  p->flags = flags;
+  p->ops.assign(ops, ops + n_ops);
+  if (n_consts > 0) p->consts.assign(consts, consts + n_consts);
+  p->n_user_consts = (size_t)(n_consts > 0 ? n_consts : 0);
+  const int rc = compile_plan(p);
+  if (rc != QMLE_OK) {
+    delete p;
+    return rc;
+  }
+  // The same tape scheduled for runs from |0..0> only (wider first tile): what qmle_run_batch
+  // executes in place of `p` when the pass-cost model prefers it.  qmle_apply_inplace and the
+  // adjoint sweep apply stages to LIVE states and keep `p`'s own schedule.
+  static const bool no_wide = std::getenv("QMLE_NO_WIDE_FIRST") != nullptr;
+  if (!no_wide && !p->whole_state_lds && !(flags & (QMLE_PLAN_NO_FUSION | QMLE_PLAN_PREFETCH)) &&
+      !((flags >> 8) & 0xffffu) && p->stages.size() >= 2 && p->stages[0].kind == ST_TILE) {
+    qmle_plan *v = new (std::nothrow) qmle_plan();
+    if (v) {
+      v->n = n_qubits;
+      v->n_slots = n_slots;
+      v->flags = flags | QMLE_PLAN_INTERNAL_ZERO_RUN;
+      v->ops = p->ops;
+      v->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
+      const bool forced = std::getenv("QMLE_FORCE_CAND") != nullptr;  // (tuning: always run the forced schedule)
+      if (compile_plan(v) == QMLE_OK && v->mat_floats == p->mat_floats && (forced || v->model_cost < p->model_cost - 0.5))
+        p->zero_variant = v;
+      else
+        delete v;
+    }
+  }
+  // <Z> measurements run a second plan without the trailing gates that only relabel basis
+  // states or add phases (they are folded into the observables at run time)
+  if (!(flags & (QMLE_PLAN_NO_ABSORB | QMLE_PLAN_NO_FUSION))) {
+    std::vector<qmle_op> kept;
+    split_expval_tail(p->ops, p->n, kept, p->absorbed);
+    if (!p->absorbed.empty()) {
+      qmle_plan *c = new (std::nothrow) qmle_plan();
+      if (c) {
+        c->n = n_qubits;
+        c->n_slots = n_slots;
+        c->flags = flags | QMLE_PLAN_NO_ABSORB | QMLE_PLAN_INTERNAL_ZERO_RUN;  // a child only ever runs from |0..0>
+        c->ops = kept;
+        c->consts.assign(p->consts.begin(), p->consts.begin() + (n_consts > 0 ? n_consts : 0));
+        for (const qmle_op &o : p->absorbed) p->absorbed_algo_bytes += algo_bytes(o, p->n);
+        c->extra_algo_last_stage = p->absorbed_algo_bytes;
+        if (compile_plan(c) == QMLE_OK) p->expval_child = c;
+        else delete c;
+        // Folding is not free any more (round 2): a folded CX tail turns <Z_w> into parities,
+        // which the last tile pass measures with the general-mask epilogue (per tile: full
+        // Walsh-Hadamard transform across the lanes) or, one-group passes on live input, with
+        // k_reg_measure -- while the fast tile path applies X / CX for nothing (LDS layout) and
+        // then takes the single-bit epilogue, whose sums stay in registers across a workgroup's
+        // tiles.  Measured (MI355X, HE circuits, us per state, folded vs applied): n = 24: 2
+        // layers 61.9 vs 45.5, 4 layers 115.8 vs 135.0; n = 22, 3 layers 25.4 vs 20.8; n = 20, 4
+        // layers 8.9 vs 11.2.  The pass-cost model plus 17 (general-mask epilogue) resp. 12
+        // (k_reg_measure on live input), in its units of 36 per read+write pass, picks the faster
+        // plan in all of them; plans whose folded form ends in a known-zero special kernel keep it.
+        static const bool always_fold = std::getenv("QMLE_ALWAYS_FOLD") != nullptr;
+        if (p->expval_child && !always_fold && !c->stages.empty() && !c->whole_state_lds) {
+          bool parity = false;
+          for (int w = 0; w < p->n; ++w) {
+            const uint32_t m = pull_back_z(p->absorbed, w);
+            if (m & (m - 1u)) parity = true;
+          }
+          const size_t last = c->stages.size() - 1;
+          const Stage &ls = c->stages[last];
+          const int kind = expval_kernel_of(c, last, plan_sparse(c));
+          double penalty = 0.0;
+          if (ls.kind == ST_TILE && parity) {
+            if (kind == 0) penalty = 17.0;
+            else if (kind == 1 && (!plan_sparse(c) || ls.zero_in == 0)) penalty = 12.0;
+          }
+          const double applied_cost = p->zero_variant ? p->zero_variant->model_cost : p->model_cost;
+          if (penalty > 0.0 && c->model_cost + penalty > applied_cost) {
+            delete c;
+            p->expval_child = nullptr;
+          }
+        }
+      }
+    }
+    if (!p->expval_child) p->absorbed.clear();
+  }
+  *out = p;
+  return QMLE_OK;
+}
+// (the plan QMLE_MEAS_EXPVAL_Z executes: the child when trailing gates were folded into the
+// observables, else the from-|0..0> variant of the plan when there is one)
+qmle_plan *qmle_plan_expval_child(qmle_plan *plan) {
+  return !plan ? nullptr : plan->expval_child ? plan->expval_child : plan->zero_variant;
+}
+
+int qmle_plan_destroy(qmle_plan *plan) {
+  if (!plan) return QMLE_OK;
+  if (plan->expval_child) (void)qmle_plan_destroy(plan->expval_child);
+  if (plan->zero_variant) (void)qmle_plan_destroy(plan->zero_variant);
+  if (plan->adj_blob) (void)hipFree(plan->adj_blob);
+  if (plan->adjf_blob) (void)hipFree(plan->adjf_blob);
+  if (plan->f64_blob) (void)hipFree(plan->f64_blob);
+  if (plan->dev.blob) (void)hipFree(plan->dev.blob);
+  delete plan;
+  return QMLE_OK;
+}
+
+int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap) {
+  if (!plan) return QMLE_ERR_INVALID_ARG;
+  const std::string s = describe_plan(plan);
+  if (buf && cap > 0) {
+    const size_t nc = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), nc);
+    buf[nc] = 0;
+  }
+  return (int)s.size();
+}
+
+int qmle_plan_stats(const qmle_plan *plan, int64_t stats[8]) {
+  if (!plan || !stats) return QMLE_ERR_INVALID_ARG;
+  int direct = 0;
+  for (const Stage &s : plan->stages) direct += s.kind == ST_DIRECT;
+  stats[0] = (int64_t)plan->ops.size();
+  stats[1] = (int64_t)plan->stages.size();
+  stats[2] = plan->whole_state_lds ? 1 : 0;
+  stats[3] = plan->tile_T;
+  stats[4] = plan->mat_floats;
+  stats[5] = direct;
+  stats[6] = (int64_t)plan->lowered.size();
+  stats[7] = (int64_t)plan->algo_bytes_per_state;
+  return QMLE_OK;
+}
+
+// workspace layout: [matrices: batch * mat_floats] [states: S * D (if needed)]
+//                   [expval partials]
+static size_t ws_matrix_bytes(const qmle_plan *p, int batch) {
+  return align_up((size_t)batch * (p->mat_floats ? p->mat_floats : 1) * sizeof(float), 256);
+}
+// per-sample gate matrices, then the product stages' group columns (k_fold_columns)
+size_t qmle::ws_mats_bytes(const qmle_plan *p, int batch) {
+  return ws_matrix_bytes(p, batch) +
+         align_up((size_t)batch * (size_t)p->fold_groups * 16 * sizeof(float2), 256) +
+         align_up((size_t)batch * 32 * sizeof(float), 256);  // k_mono_coef
+}
+
+static int default_states_in_flight(const qmle_plan *p, int batch) {
+  // states per launch: the tile passes are LDS/VALU-bound, so big launches (fewer tails)
+  // beat Infinity-Cache residency -- measured 3.4k -> 4.1k statevectors/s at n = 24 going
+  // from 1 to 32 states in flight, +1 % more at 128 (profiles/r01_in_flight_sweep.txt); runs
+  // that skip known zeros are launch-bound at 32 (11.5 M -> 14.3 M -> 15.2 M gate-applies/s at
+  // 32 / 128 / 512 states, K2).  32 GiB of state buffers = 256 states at n = 24.
+  // Round 2: a plan whose every pass streams the whole state (no known zeros left to skip) is
+  // not launch-bound, and its passes run faster on a 4 GiB than on a 32 GiB working set -- K2
+  // all-live at n = 24: 111.0 / 111.6 / 108.3 / 107.2 / 107.7 ms per 1024 states for 32 / 16 /
+  // 8 / 4 / 2 GiB per launch (the read+write pass: 56.6 vs 51.6 us per state at 256 vs 64
+  // states); the known-zero plans keep 32 GiB (3.0 vs 4.9 ms per step at 4 GiB).
+  const size_t sb = (size_t)8 << p->n;
+  static const long env_mib = [] {
+    const char *e = getenv("QMLE_IN_FLIGHT_MIB");  // tuning knob; default from measurements
+    return e ? atol(e) : 0L;
+  }();
+  bool whole_state_every_pass = p->stages.size() >= 2;
+  if (plan_sparse(p))
+    for (size_t si = 1; si < p->stages.size(); ++si)
+      if (p->stages[si].zero_in != 0) whole_state_every_pass = false;
+  const size_t budget_mib = env_mib > 0 ? (size_t)env_mib : whole_state_every_pass ? 4096 : 32768;
+  size_t s = (budget_mib << 20) / sb;
+  if (s < 1) s = 1;
+  if (s > (size_t)batch) s = (size_t)batch;
+  return (int)s;
+}
+
+static size_t expval_partial_rows(const qmle_plan *p) {
+  size_t rows = (size_t)expval_blocks(p->n);
+  if ((size_t)overlap_blocks(p->n) > rows) rows = (size_t)overlap_blocks(p->n);
+  if (!p->stages.empty() && p->stages.back().kind == ST_TILE && !p->whole_state_lds) {
+    const size_t tiles = (size_t)1 << (p->n - p->stages.back().T);
+    if (tiles > rows) rows = tiles;
+  }
+  return rows;
+}
+
+static size_t per_state_ws_bytes(const qmle_plan *p, int meas_type) {
+  size_t b = align_up((size_t)8 << p->n, 256);
+  if (meas_type == QMLE_MEAS_EXPVAL_Z)
+    b += align_up(expval_partial_rows(p) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+  return b;
+}
+
+size_t qmle::workspace_bytes_one(const qmle_plan *plan, int batch, int meas_type,
+                                 int states_in_flight) {
+  size_t total = ws_mats_bytes(plan, batch) + 512;  // + alignment slack
+  const bool lds_direct_meas =
+      plan->whole_state_lds && (meas_type == QMLE_MEAS_PROBS || meas_type == QMLE_MEAS_EXPVAL_Z);
+  if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
+    int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
+    if (s > batch) s = batch;
+    total += (size_t)s * per_state_ws_bytes(plan, meas_type);
+  }
+  return total;
+}
+
+size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type, int n_obs,
+                            int states_in_flight) {
+  (void)n_obs;
+  if (!plan || batch < 1) return 0;
+  size_t total = workspace_bytes_one(plan, batch, meas_type, states_in_flight);
+  if (plan->zero_variant) {
+    const size_t c = workspace_bytes_one(plan->zero_variant, batch, meas_type, states_in_flight);
+    if (c > total) total = c;
+  }
+  if (meas_type == QMLE_MEAS_EXPVAL_Z && plan->expval_child) {
+    const size_t c = workspace_bytes_one(plan->expval_child, batch, meas_type, states_in_flight);
+    if (c > total) total = c;
+  }
+  return total;
+}
+
+
+
+// <Z..Z> on wire masks (bit w = wire w), pulled back through the folded tail -> position masks
+static int build_obs_masks(qmle_plan *plan, qmle_plan **exec, const uint32_t *wire_masks, int n_obs,
+                           uint32_t *masks) {
+  const int n = plan->n;
+  *exec = plan->expval_child ? plan->expval_child : plan;
+  for (int k = 0; k < n_obs; ++k) {
+    const uint32_t in = wire_masks[k];
+    if (in == 0 || (n < 32 && (in >> n))) return QMLE_ERR_WIRE_RANGE;
+    uint32_t wm = 0;  // a product of Z's pulls back to the XOR of the factors' pull-backs
+    for (int w = 0; w < n; ++w)
+      if (in & (1u << w)) wm ^= *exec == plan ? 1u << w : pull_back_z(plan->absorbed, w);
+    uint32_t pm = 0;
+    for (int w = 0; w < n; ++w)
+      if (wm & (1u << w)) pm |= 1u << (n - 1 - w);
+    masks[k] = pm;  // (never 0: the pull-back is an invertible linear map)
+  }
+  return QMLE_OK;
+}
+
+int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                   const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
+                   size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || !d_out || !d_workspace) return QMLE_ERR_INVALID_ARG;
+  if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_DENSITY) return QMLE_ERR_MEAS_TYPE;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  uint32_t masks[QMLE_MAX_QUBITS];
+  qmle_plan *exec = plan;
+  if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+    if (n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !obs_wires) return QMLE_ERR_INVALID_ARG;
+    uint32_t wm[QMLE_MAX_QUBITS];
+    for (int k = 0; k < n_obs; ++k) {
+      if (obs_wires[k] < 0 || obs_wires[k] >= plan->n) return QMLE_ERR_WIRE_RANGE;
+      wm[k] = 1u << obs_wires[k];
+    }
+    const int rc = build_obs_masks(plan, &exec, wm, n_obs, masks);
+    if (rc != QMLE_OK) return rc;
+  }
+  return run_batch_masks(exec, d_angles, batch, meas_type, masks, n_obs, d_out, d_workspace,
+                         workspace_bytes, (hipStream_t)stream_);
+}
+
+int qmle_run_batch_parity(qmle_plan *plan, const float *d_angles, int batch,
+                          const uint32_t *wire_masks, int n_obs, float *d_out, void *d_workspace,
+                          size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || !d_out || !d_workspace || !wire_masks || n_obs < 1 ||
+      n_obs > QMLE_MAX_QUBITS)
+    return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  uint32_t masks[QMLE_MAX_QUBITS];
+  qmle_plan *exec = plan;
+  const int rc = build_obs_masks(plan, &exec, wire_masks, n_obs, masks);
+  if (rc != QMLE_OK) return rc;
+  return run_batch_masks(exec, d_angles, batch, QMLE_MEAS_EXPVAL_Z, masks, n_obs, d_out,
+                         d_workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+// Simulate + measure; <Z> observables arrive as bit-position parity masks.
+int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
+                          const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+  if (plan->zero_variant) plan = plan->zero_variant;  // every run_batch starts from |0..0>
+  const int n = plan->n;
+  bool single_bits = true;  // plain Z observables: the 33-sums epilogue serves them all
+  int8_t obs_bits[QMLE_MAX_QUBITS];
+  if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+    for (int k = 0; k < n_obs; ++k) {
+      const uint32_t m = obs_masks[k];
+      if (m == 0 || (m & (m - 1))) single_bits = false;
+      obs_bits[k] = (int8_t)(m ? __builtin_ctz(m) : 0);
+    }
+  }
+  // Parities that touch the LAST tile in at most one position (the rest are outer positions =
+  // bits of the tile index) also come out of the 33-sums epilogue: column of that position (or
+  // of the total) summed over the tile rows with the sign of the outer part; the general-mask
+  // epilogue costs 13 - 17 us per state at n = 24, this one 4 - 6.  (A CX tail that would make
+  // every folded parity of an HE ring meet the last tile in one position does not exist: the
+  // restrictions of those parities to T wires are T + 1 or T + 2 distinct ranges.)
+  bool semi_single = false;
+  uint32_t row_masks[QMLE_MAX_QUBITS];
+  static const bool no_semi = std::getenv("QMLE_NO_SEMI_SINGLE") != nullptr;
+  if (meas_type == QMLE_MEAS_EXPVAL_Z && !single_bits && !no_semi && !plan->stages.empty() &&
+      plan->stages.back().kind == ST_TILE && !plan->whole_state_lds) {
+    const Stage &ls = plan->stages.back();
+    uint32_t tile_mask = 0;
+    for (int j = 0; j < ls.T; ++j) tile_mask |= 1u << ls.tile_bits[j];
+    semi_single = true;
+    for (int k = 0; k < n_obs && semi_single; ++k) {
+      const uint32_t m = obs_masks[k], in = m & tile_mask;
+      if (m == 0 || (in & (in - 1u))) { semi_single = false; break; }
+      obs_bits[k] = (int8_t)(in ? __builtin_ctz(in) : QMLE_MAX_QUBITS);  // column 32: the tile's total
+      uint32_t rm = 0;
+      for (int i = 0; i < n - ls.T; ++i)
+        if ((m >> ls.outer_bits[i]) & 1u) rm |= 1u << i;
+      row_masks[k] = rm;
+    }
+  }
+  int rc = ensure_device_plan(plan);
+  if (rc != QMLE_OK) return rc;
+
+  char *ws = (char *)d_workspace;
+  {
+    const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+    ws += mis;
+    if (workspace_bytes < mis) return QMLE_ERR_WORKSPACE;
+    workspace_bytes -= mis;
+  }
+  const size_t mats_b = ws_mats_bytes(plan, batch);
+  if (workspace_bytes < mats_b) return QMLE_ERR_WORKSPACE;
+  float *d_mats = (float *)ws;
+  float2 *d_cols = plan->fold_groups ? (float2 *)(ws + ws_matrix_bytes(plan, batch)) : nullptr;
+  float *d_coef = (float *)(ws + ws_matrix_bytes(plan, batch) +
+                            align_up((size_t)batch * (size_t)plan->fold_groups * 16 * sizeof(float2), 256));
+  ws += mats_b;
+  workspace_bytes -= mats_b;
+
+  // per-sample gate matrices for the whole batch (tiny)
+  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream);
+  if (rc != QMLE_OK) return rc;
+
+  const size_t D = (size_t)1 << n;
+  const size_t sb = D * sizeof(float2);
+
+  // ---- whole state in LDS: one launch does simulate + measure ------------------
+  if (plan->whole_state_lds) {
+    const Stage &st = plan->stages[0];
+    if (meas_type == QMLE_MEAS_STATE || meas_type == QMLE_MEAS_PROBS ||
+        meas_type == QMLE_MEAS_EXPVAL_Z) {
+      for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
+        const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
+        const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
+        ProfScope prof_scope(plan, 0, stream);
+        if (meas_type == QMLE_MEAS_STATE)
+          rc = launch_tile(plan, st, (float2 *)d_out + (size_t)b0 * D, mats, ang, bc, true,
+                           TM_STORE, nullptr, nullptr, 0, stream);
+        else if (meas_type == QMLE_MEAS_PROBS)
+          rc = launch_tile(plan, st, nullptr, mats, ang, bc, true, TM_PROBS,
+                           (float *)d_out + (size_t)b0 * D, nullptr, 0, stream);
+        else
+          rc = launch_tile(plan, st, nullptr, mats, ang, bc, true, TM_EXPVAL,
+                           (float *)d_out + (size_t)b0 * n_obs, obs_masks, n_obs, stream);
+        if (rc != QMLE_OK) return rc;
+      }
+      return QMLE_OK;
+    }
+  }
+
+  // ---- general path: states resident in HBM, sample-major chunks ----------------
+  float2 *d_states;
+  int in_flight;
+  if (meas_type == QMLE_MEAS_STATE) {
+    d_states = (float2 *)d_out;
+    in_flight = default_states_in_flight(plan, batch);  // sample-major: stay cache-resident
+  } else {
+    in_flight = (int)(workspace_bytes / per_state_ws_bytes(plan, meas_type));
+    if (in_flight < 1) return QMLE_ERR_WORKSPACE;
+    if (in_flight > batch) in_flight = batch;
+    const int dflt = default_states_in_flight(plan, batch);
+    if (in_flight > dflt) in_flight = dflt;
+    d_states = (float2 *)ws;
+    ws += (size_t)in_flight * align_up(sb, 256);
+  }
+  if (in_flight > 65535) in_flight = 65535;
+  void *d_partial = ws;
+  const size_t partial_bytes =
+      (size_t)in_flight * expval_partial_rows(plan) * (QMLE_MAX_QUBITS + 1) * sizeof(float);
+  // <Z> straight out of the last tile pass (no store of the final state, no extra read)
+  const bool fuse_expval = meas_type == QMLE_MEAS_EXPVAL_Z && !plan->stages.empty() &&
+                           plan->stages.back().kind == ST_TILE;
+
+  for (int b0 = 0; b0 < batch; b0 += in_flight) {
+    const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
+    float2 *stc = meas_type == QMLE_MEAS_STATE ? d_states + (size_t)b0 * D : d_states;
+    const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
+    const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
+    bool initialised = false;
+    int reg_q = -1;  // >= 0: the last pass ran as k_reg_measure with 2^reg_q tiles per row
+    int tile_row_shift = 0;  // k_tile2's multi-tile measuring variant: 2^shift tiles per row
+    for (size_t si = 0; si < plan->stages.size(); ++si) {
+      const Stage &st = plan->stages[si];
+      ProfScope prof_scope(plan, (int)si, stream);
+      if (st.kind == ST_TILE) {
+        const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
+        const int tm = !last_fused ? TM_STORE : (single_bits || semi_single) ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
+        reg_q = -1;
+        int reg_kind = last_fused && initialised ? reg_measure_kind(plan, si, n_obs) : 0;
+        // (k_reg_measure on live input is the slowest way to take parities; its known-zero forms
+        // -- FOLD, mono -- keep priority)
+        if (reg_kind == 1 && semi_single) reg_kind = 0;
+        if (reg_kind) {
+          rc = launch_reg_measure(plan, st, reg_kind, stc, mats, ang, bc, d_partial, obs_masks,
+                                  n_obs, stream, &reg_q, d_coef + (size_t)b0 * 32);
+        } else
+        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, tm,
+                         last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
+                         last_fused ? n_obs : 0, stream, /*from_zero=*/true,
+                         d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr,
+                         last_fused && single_bits ? &tile_row_shift : nullptr);
+        initialised = true;
+      } else {
+        if (!initialised) {
+          launch_init_zero(stc, n, bc, stream);
+          initialised = true;
+        }
+        if (st.kind == ST_DIRECT) {
+          rc = launch_direct(plan, plan->dev_ops[st.op_begin], stc, mats, bc, stream);
+        } else {
+          const LoweredOp &o = plan->dev_ops[st.op_begin];
+          launch_diag_all(stc, n, bc, plan->dev.d_consts + o.mat_off, ang, plan->n_slots, o.slot, stream);
+          rc = QMLE_OK;
+        }
+      }
+      if (rc != QMLE_OK) return rc;
+    }
+    if (!initialised) launch_init_zero(stc, n, bc, stream);
+    // measure this chunk
+    if (meas_type == QMLE_MEAS_PROBS) {
+      const uint64_t tc = (uint64_t)bc * (D / 2);
+      launch_probs(stc, (float *)d_out + (size_t)b0 * D, tc, stream);
+    } else if (meas_type == QMLE_MEAS_EXPVAL_Z && fuse_expval) {
+      ObsBits ob;  // column of the 33-float row: the bit's sum, or (masks) the observable's own
+      const bool by_position = (single_bits || semi_single) && reg_q < 0;
+      for (int k = 0; k < QMLE_MAX_QUBITS; ++k) ob.row_mask[k] = 0u;
+      for (int k = 0; k < n_obs; ++k) {
+        ob.bits[k] = by_position ? obs_bits[k] : (int8_t)k;
+        if (by_position && semi_single) ob.row_mask[k] = row_masks[k];
+      }
+      const int tiles = (1 << (n - plan->stages.back().T)) >> (reg_q < 0 ? tile_row_shift : reg_q);
+      launch_expval_final((const float *)d_partial, tiles, bc, n_obs, ob, (float *)d_out + (size_t)b0 * n_obs, stream);
+    } else if (meas_type == QMLE_MEAS_EXPVAL_Z) {
+      rc = single_bits
+               ? run_expval(stc, n, bc, obs_bits, n_obs, (float *)d_out + (size_t)b0 * n_obs,
+                            d_partial, partial_bytes, stream)
+               : run_parity_pos(stc, n, bc, obs_masks, n_obs, (float *)d_out + (size_t)b0 * n_obs,
+                                d_partial, partial_bytes, stream);
+      if (rc != QMLE_OK) return rc;
+    } else if (meas_type == QMLE_MEAS_DENSITY) {
+      if (n > 15) return QMLE_ERR_UNSUPPORTED;
+      launch_density(stc, (float2 *)d_out + (size_t)b0 * D * D, n, bc, stream);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return QMLE_OK;
+}
+
+// Apply the plan's passes IN PLACE to resident states (no |0..0> initialisation, no
+// measurement): the gate-application hot loop on its own (simulation.py:102-103).
+// One stage of a plan applied in place to resident states.
+int qmle::run_stage_inplace(qmle_plan *plan, const Stage &st, float2 *d_states, const float *d_mats,
+                            const float *d_angles, int batch, hipStream_t stream) {
+  if (st.kind == ST_TILE)
+    return launch_tile(plan, st, d_states, d_mats, d_angles, batch, false, TM_STORE, nullptr,
+                       nullptr, 0, stream);
+  if (st.kind == ST_DIRECT)
+    return launch_direct(plan, plan->dev_ops[st.op_begin], d_states, d_mats, batch, stream);
+  const LoweredOp &o = plan->dev_ops[st.op_begin];
+  launch_diag_all(d_states, plan->n, batch, plan->dev.d_consts + o.mat_off, d_angles, plan->n_slots, o.slot, stream);
+  return QMLE_OK;
+}
+
+int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *d_states,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!plan || batch < 1 || batch > 65535 || !d_states || !d_workspace) return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = ensure_device_plan(plan);
+  if (rc != QMLE_OK) return rc;
+  char *ws = (char *)d_workspace;
+  const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+  if (workspace_bytes < mis + ws_mats_bytes(plan, batch)) return QMLE_ERR_WORKSPACE;
+  float *d_mats = (float *)(ws + mis);
+  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream);
+  if (rc != QMLE_OK) return rc;
+  int stage_idx = -1;
+  for (const Stage &st : plan->stages) {
+    ProfScope prof_scope(plan, ++stage_idx, stream);
+    rc = run_stage_inplace(plan, st, (float2 *)d_states, d_mats, d_angles, batch, stream);
+    if (rc != QMLE_OK) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+
+int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
+                      const int32_t *leaf_div, const int32_t *leaf_mod, int n_leaves,
+                      const int32_t *d_ptr, const int32_t *d_arg, const int32_t *d_idx,
+                      const float *d_coef, const float *d_const, const double *d_period,
+                      int n_slots, int64_t batch, int64_t batch_offset, float *d_out,
+                      qmle_stream stream) {
+  if (n_leaves < 0 || n_leaves > 8 || n_slots < 0 || batch < 1 || !d_out || !d_ptr || !d_const)
+    return QMLE_ERR_INVALID_ARG;
+  if (n_slots == 0) return QMLE_OK;
+  AngleLeaves lv;
+  std::memset(&lv, 0, sizeof(lv));
+  for (int k = 0; k < n_leaves; ++k) {
+    if (!d_leaves[k] || leaf_div[k] < 1 || leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
+    lv.ptr[k] = d_leaves[k];
+    lv.stride[k] = leaf_strides[k];
+    lv.div[k] = leaf_div[k];
+    lv.mod[k] = leaf_mod[k];
+  }
+  const uint64_t total = (uint64_t)batch * (uint64_t)n_slots;
+  hipLaunchKernelGGL(k_build_angles, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     lv, d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, (long long)batch,
+                     (long long)batch_offset, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+int qmle_profile_begin(qmle_plan *plan, int capacity) {
+  if (!plan || capacity < 1) return QMLE_ERR_INVALID_ARG;
+  StageProfile &pr = plan->prof;
+  while ((int)pr.start.size() < capacity) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    pr.start.push_back((void *)a);
+    pr.stop.push_back((void *)b);
+  }
+  pr.stage.assign(pr.start.size(), -1);
+  pr.used = 0;
+  pr.on = true;
+  return QMLE_OK;
+}
+
+int qmle_profile_end(qmle_plan *plan, double *stage_ms, int64_t *stage_launches, int n_stages) {
+  if (!plan || !stage_ms || !stage_launches || n_stages < (int)plan->stages.size())
+    return QMLE_ERR_INVALID_ARG;
+  StageProfile &pr = plan->prof;
+  pr.on = false;
+  for (int i = 0; i < n_stages; ++i) { stage_ms[i] = 0.0; stage_launches[i] = 0; }
+  for (size_t k = 0; k < pr.used; ++k) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)pr.stop[k]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)pr.start[k], (hipEvent_t)pr.stop[k]));
+    stage_ms[pr.stage[k]] += ms;
+    stage_launches[pr.stage[k]] += 1;
+  }
+  const int dropped = pr.used >= pr.start.size() ? 1 : 0;
+  for (size_t k = 0; k < pr.start.size(); ++k) {
+    (void)hipEventDestroy((hipEvent_t)pr.start[k]);
+    (void)hipEventDestroy((hipEvent_t)pr.stop[k]);
+  }
+  pr.start.clear(); pr.stop.clear(); pr.stage.clear(); pr.used = 0;
+  return dropped;  // 1 = the pool filled up (later launches were not timed)
+}
+

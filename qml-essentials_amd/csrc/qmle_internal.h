@@ -1,5 +1,5 @@
 // Internal structures shared by the host-side plan compiler (qmle_plan.cpp) and
-// the gfx950 kernels / C-ABI entry points (qmle_sv.hip).  Not part of the ABI.
+// the gfx950 kernels / C-ABI entry points (the qmle_*.hip units, see qmle_host.h).  Not part of the ABI.
 #pragma once
 #include <cstdint>
 #include <string>

@@ -215,7 +215,7 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
 //     group (its scatter stays in place);
 //   * only an X / CX sandwiched between the group's dense gates runs in registers (8 moves).
 // Layout map: logical tile index e lives at physical slot L(e) = XOR_{j in e} Lcol[j] ^ Lconst.
-static inline uint32_t swz(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }  // = sw() in qmle_sv.hip
+static inline uint32_t swz(uint32_t e) { return e ^ (((e >> 5) & 15u) << 1); }  // = sw() in qmle_dev.h
 
 static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<LoweredOp> &src,
                               uint32_t zin_local) {

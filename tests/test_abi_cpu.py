@@ -169,8 +169,8 @@ def test_xor_addressed_tile_kernels_have_no_static_lds():
     assert len(xor_kernels) >= 14
     for name, r in xor_kernels.items():
         assert r["LDS Size"] == 0, (name, r)
-    src = open(os.path.join(G.CSRC, "qmle_sv.hip")).read()
-    assert "__builtin_trap" not in src
+    for unit in G.UNITS:
+        assert "__builtin_trap" not in open(os.path.join(G.CSRC, unit)).read(), unit
     assert N.lib().qmle_status_string(-12).decode().startswith("internal invariant")
 
 
