@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 143 /* 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 144 /* 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -297,6 +297,10 @@ int qmle_philox_uniform_f32(const uint64_t key[2], uint64_t n, double low, doubl
  * host version's floats): what utils.uniform uses when a GPU is present. */
 int qmle_philox_uniform_f32_device(const uint64_t key[2], uint64_t n, double low, double high,
                                    float *d_out, qmle_stream stream);
+/* The same with the key read from DEVICE memory (d_key: two 64-bit words) when the kernel runs: a
+ * launch captured in a hipGraph is re-seeded by rewriting those words, not by re-capturing. */
+int qmle_philox_uniform_f32_device_key(const uint64_t *d_key, uint64_t n, double low, double high,
+                                       float *d_out, qmle_stream stream);
 /* numpy.histogram(values, bins=linspace(lo,hi,n_bins+1)) counts (last bin
  * right-inclusive) -- expressibility.py:104-108; d_counts int32[n_bins], zeroed
  * by the call */

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("qmle_meyer_wallach_reads", _I, [_I]),
     ("qmle_philox_uniform_f32", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP]),
     ("qmle_philox_uniform_f32_device", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP, _VP]),
+    ("qmle_philox_uniform_f32_device_key", _I, [_VP, C.c_uint64, C.c_double, C.c_double, _VP, _VP]),
     ("qmle_run_batch_f64", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_workspace_bytes_f64", _SZ, [_VP, _I, _I]),
     ("qmle_plan_set_consts_f64", _I, [_VP, C.POINTER(C.c_double), _I]),
@@ -312,7 +313,14 @@ class Plan:
         return list(ms), [int(c) for c in cnt], bool(rc)
 
     def workspace_bytes(self, batch: int, meas: str, n_obs: int = 0, states_in_flight: int = 0):
-        return int(lib().qmle_workspace_bytes(self._h, batch, MEAS[meas], n_obs, states_in_flight))
+        key = (batch, meas, n_obs, states_in_flight)  # (a pure function of the plan: memoised)
+        cache = self.__dict__.setdefault("_wsb", {})
+        v = cache.get(key)
+        if v is None:
+            if len(cache) > 256:
+                cache.clear()
+            v = cache[key] = int(lib().qmle_workspace_bytes(self._h, batch, MEAS[meas], n_obs, states_in_flight))
+        return v
 
     def _workspace(self, B: int, meas: str, n_obs: int, states_in_flight: int, workspace, dev):
         """Workspace tensor of the size the engine asks for.  The default asks for state buffers
@@ -347,7 +355,8 @@ class Plan:
         dev = current_device()
         if angles is None:
             angles = torch.zeros((1, max(1, self.n_slots)), dtype=torch.float32, device=dev)
-        angles = angles.to(device=dev, dtype=torch.float32).contiguous()
+        if angles.dtype != torch.float32 or not angles.is_cuda or not angles.is_contiguous():
+            angles = angles.to(device=dev, dtype=torch.float32).contiguous()
         if angles.dim() != 2 or (self.n_slots and angles.shape[1] != self.n_slots):
             raise ValueError(f"angles must be [B, {self.n_slots}], got {tuple(angles.shape)}")
         B = int(angles.shape[0])

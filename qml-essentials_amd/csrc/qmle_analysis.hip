@@ -215,6 +215,27 @@ k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
   im = block_sum_d(im, red);
   if (threadIdx.x == 0) out[pr] = (float)(re * re + im * im);
 }
+// Small states (n <= 16): ONE workgroup per pair, no partial rows -- the two-launch form spent 17 us
+// on 1024 pairs of 12-qubit states, most of it launch latency and the row round trip.  fp32 inside a
+// thread (<= 128 products each), fp64 across the workgroup.
+__global__ void __launch_bounds__(256)
+k_pair_fidelity_small(const float4 *__restrict__ states, int n, int n_pairs, float *__restrict__ out) {
+  __shared__ double red[16];
+  const int pr = blockIdx.x;
+  const uint32_t chunks = 1u << (n - 1);
+  const float4 *a = states + (size_t)pr * chunks;
+  const float4 *c = states + ((size_t)pr + n_pairs) * chunks;
+  float re = 0.f, im = 0.f;
+  for (uint32_t k = threadIdx.x; k < chunks; k += blockDim.x) {
+    const float4 x = a[k], y = c[k];  // conj(x) * y
+    re += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    im += x.x * y.y - x.y * y.x + x.z * y.w - x.w * y.z;
+  }
+  const double r = block_sum_d((double)re, red);
+  const double i = block_sum_d((double)im, red);
+  if (threadIdx.x == 0) out[pr] = (float)(r * r + i * i);
+}
+
 // Meyer-Wallach cross terms c_j = sum_{bit_j = 0} psi_i conj(psi_{i + 2^j}) plus the
 // populations a_j, d_j; one launch per bit (v1: n reads of the state).
 // ---- parameter sampler on the device ---------------------------------------------------------
@@ -223,8 +244,8 @@ k_overlap_final(const float2 *__restrict__ partial, int n_blocks, int n_pairs,
 // The arithmetic after the generator is numpy's, rounding for rounding: u = (x >> 11) * 2^-53
 // (exact), low + range * u as a rounded product and a rounded sum (no fused multiply-add), cast to
 // float32.  Expressibility(12 q, 1024 pairs) spent 0.4 of its 0.9 ms drawing parameters on the host.
-__global__ void __launch_bounds__(256)
-k_philox_uniform(uint64_t k0, uint64_t k1, uint64_t n, double low, double range, float *__restrict__ out) {
+__device__ __forceinline__ void philox_uniform_body(uint64_t k0, uint64_t k1, uint64_t n, double low, double range,
+                                                    float *__restrict__ out) {
   const uint64_t blocks = (n + 3) / 4;
   for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < blocks; b += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t c0 = b + 1, c1 = 0, c2 = 0, c3 = 0, a0 = k0, a1 = k1;
@@ -247,6 +268,15 @@ k_philox_uniform(uint64_t k0, uint64_t k1, uint64_t n, double low, double range,
       }
     }
   }
+}
+__global__ void __launch_bounds__(256)
+k_philox_uniform(uint64_t k0, uint64_t k1, uint64_t n, double low, double range, float *__restrict__ out) {
+  philox_uniform_body(k0, k1, n, low, range, out);
+}
+// the key read from device memory: a captured launch (hipGraph) is re-seeded by rewriting two words
+__global__ void __launch_bounds__(256)
+k_philox_uniform_devkey(const uint64_t *__restrict__ key, uint64_t n, double low, double range, float *__restrict__ out) {
+  philox_uniform_body(key[0], key[1], n, low, range, out);
 }
 // partial[b][bit][block] = (re c, im c, a, d)
 __global__ void __launch_bounds__(256)
@@ -308,23 +338,53 @@ k_mw_final(const float4 *__restrict__ partial, int n, int n_blocks, int batch,
   if (threadIdx.x == 0) out[b] = (float)(2.0 * (1.0 - sum / n));
 }
 
+// numpy.histogram's bin of v over linspace(lo, hi, n_bins + 1), last bin right-inclusive; -1 = dropped
+__device__ __forceinline__ int hist_bin(float v, int n_bins, float lo, float hi) {
+  if (!(v >= lo) || !(v <= hi)) return -1;  // numpy drops out-of-range and NaN
+  const float scale = (float)n_bins / (hi - lo);
+  int bin = (int)((v - lo) * scale);
+  if (bin >= n_bins) bin = n_bins - 1;     // right edge inclusive
+  // guard against rounding across an edge: edges are lo + k*(hi-lo)/n_bins
+  const float w = (hi - lo) / (float)n_bins;
+  if (bin > 0 && v < lo + bin * w) --bin;
+  else if (bin < n_bins - 1 && v >= lo + (bin + 1) * w) ++bin;
+  return bin;
+}
+
 __global__ void __launch_bounds__(256)
 k_histogram(const float *__restrict__ values, int64_t count, int n_bins, float lo, float hi,
             int *__restrict__ counts) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const float scale = (float)n_bins / (hi - lo);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const float v = values[i];
-    if (!(v >= lo) || !(v <= hi)) continue;  // numpy drops out-of-range and NaN
-    int bin = (int)((v - lo) * scale);
-    if (bin >= n_bins) bin = n_bins - 1;     // right edge inclusive
-    // guard against rounding across an edge: edges are lo + k*(hi-lo)/n_bins
-    const float w = (hi - lo) / (float)n_bins;
-    if (bin > 0 && v < lo + bin * w) --bin;
-    else if (bin < n_bins - 1 && v >= lo + (bin + 1) * w) ++bin;
-    atomicAdd(counts + bin, 1);
+    const int bin = hist_bin(values[i], n_bins, lo, hi);
+    if (bin >= 0) atomicAdd(counts + bin, 1);
   }
 }
+
+// <= 4096 bins: every workgroup bins its share in LDS (integer atomics on the LDS crossbar instead
+// of contended global ones: 1024 values into 75 bins took 13.8 us + a 5 us memset before).  ONE
+// workgroup (SOLO, counts up to 2^16 values): the bins are stored, not added -- no memset launch.
+template <bool SOLO>
+__global__ void __launch_bounds__(1024)
+k_histogram_lds(const float *__restrict__ values, int64_t count, int n_bins, float lo, float hi,
+                int *__restrict__ counts) {
+  extern __shared__ float4 smem4[];
+  int *bins = reinterpret_cast<int *>(smem4);
+  for (int k = threadIdx.x; k < n_bins; k += blockDim.x) bins[k] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const int bin = hist_bin(values[i], n_bins, lo, hi);
+    if (bin >= 0) atomicAdd(bins + bin, 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_bins; k += blockDim.x) {
+    if (SOLO) counts[k] = bins[k];
+    else if (bins[k]) atomicAdd(counts + k, bins[k]);
+  }
+}
+
+
 // ---- shot sampling (simulation.py:320-377) ------------------------------------------
 // Philox4x32-10 counter RNG: counter = (shot pair, 0, row lo, row hi), key = seed.
 struct Philox4 { uint32_t x[4]; };
@@ -995,6 +1055,13 @@ int qmle_pair_fidelity(const void *d_states, int n_qubits, int n_pairs, float *d
   if (workspace_bytes < (size_t)n_pairs * nb * sizeof(float2)) return QMLE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const uint64_t chunks = (uint64_t)1 << (n_qubits - 1);
+  if (n_qubits <= 16 && n_pairs >= 64) {  // enough pairs to fill the chip with one workgroup each
+    const int threads = chunks >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_pair_fidelity_small, dim3(n_pairs), dim3(threads), 0, stream,
+                       (const float4 *)d_states, n_qubits, n_pairs, d_out);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
   for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
     const int pc = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
     // pairs (i, i + n_pairs): shift both halves by p0
@@ -1268,14 +1335,36 @@ int qmle_philox_uniform_f32_device(const uint64_t key[2], uint64_t n, double low
   return QMLE_OK;
 }
 
+int qmle_philox_uniform_f32_device_key(const uint64_t *d_key, uint64_t n, double low, double high, float *d_out,
+                                       qmle_stream stream_) {
+  if (!d_key || (!d_out && n > 0) || n > (1ull << 40)) return QMLE_ERR_INVALID_ARG;
+  if (n == 0) return QMLE_OK;
+  hipLaunchKernelGGL(k_philox_uniform_devkey, dim3(grid_for((n + 3) / 4, 256, 1u << 16)), dim3(256), 0,
+                     (hipStream_t)stream_, d_key, n, low, high - low, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
 int qmle_histogram(const float *d_values, int64_t count, int n_bins, float lo, float hi,
                    int32_t *d_counts, qmle_stream stream_) {
   if (!d_values || !d_counts || count < 0 || n_bins < 1 || !(hi > lo)) return QMLE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
+  if (n_bins <= 4096 && count > 0 && count <= (1 << 16)) {  // one workgroup, one launch
+    const int threads = count >= 1024 ? 1024 : count >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(k_histogram_lds<true>, dim3(1), dim3(threads), (size_t)n_bins * sizeof(int), stream,
+                       d_values, count, n_bins, lo, hi, d_counts);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
   HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)n_bins * sizeof(int32_t), stream));
-  if (count > 0)
-    hipLaunchKernelGGL(k_histogram, dim3(grid_for((uint64_t)count, 256, 1024)), dim3(256), 0,
-                       stream, d_values, count, n_bins, lo, hi, d_counts);
+  if (count > 0) {
+    if (n_bins <= 4096)
+      hipLaunchKernelGGL(k_histogram_lds<false>, dim3(grid_for((uint64_t)count, 1024 * 16, 1024)), dim3(1024),
+                         (size_t)n_bins * sizeof(int), stream, d_values, count, n_bins, lo, hi, d_counts);
+    else
+      hipLaunchKernelGGL(k_histogram, dim3(grid_for((uint64_t)count, 256, 1024)), dim3(256), 0,
+                         stream, d_values, count, n_bins, lo, hi, d_counts);
+  }
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

@@ -43,10 +43,19 @@ class Entanglement:
                         "Consider 'concentratable entanglement' instead.")
         if scale:
             n_samples = (2**model.n_qubits) * n_samples
-        if n_samples is not None and n_samples > 0:
-            random_key = model.initialize_params(random_key, repeat=int(n_samples))
         kwargs.setdefault("inputs", None)
         kwargs.pop("execution_type", None)
+        if n_samples is not None and n_samples > 0:
+            # (the compiled call is resolved before the sampler is launched: expressibility.py)
+            prep = None
+            if not any(v is not None for v in kwargs.values()) and not distributed.enabled():
+                prep = model.prepared_state_call(int(n_samples))
+            random_key = model.initialize_params(random_key, repeat=int(n_samples))
+            if prep is not None and model.device_params() is not None:
+                cc, divs, mods, B = prep
+                ent = cls._compute_meyer_wallach_meas(cc.run([model.device_params()], divs, mods, B, 0),
+                                                      model.n_qubits)
+                return float(ent.mean(dtype=N.require_gpu().float64))
         # sampled parameters stay on the GPU (the reference's are jax device arrays,
         # entanglement.py:52-60); small draws / user-set parameters are host arrays
         params = model.device_params()
@@ -63,8 +72,9 @@ class Entanglement:
             b_i = model.batch_shape[0]
             ent = distributed.all_gather_rows(ent.reshape(b_i, -1).transpose(0, 1).contiguous(),
                                               total)
-        log.debug("Variance of measure: %s", float(ent.var()) if ent.numel() > 1 else 0.0)
-        return float(ent.double().mean())
+        if log.isEnabledFor(logging.DEBUG):  # (a variance costs a reduction and a device -> host sync)
+            log.debug("Variance of measure: %s", float(ent.var()) if ent.numel() > 1 else 0.0)
+        return float(ent.mean(dtype=N.require_gpu().float64))  # one reduction, one sync
 
     @classmethod
     def _compute_meyer_wallach_meas(cls, states, n_qubits: int):

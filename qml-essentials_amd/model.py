@@ -58,6 +58,7 @@ class Model:
         # ``utils.enable_x64`` switch (None = follow it) -- the reference's ``jax_enable_x64`` mode
         self.x64 = x64
         self._params, self._params_dev = None, None
+        self._fast_calls = {}  # fingerprint -> compiled device call (_forward_device)
         self.n_qubits = n_qubits
         self.output_qubit = output_qubit
         self.n_layers = n_layers
@@ -716,25 +717,133 @@ class Model:
     def _is_cuda(x) -> bool:
         return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
+    def _call_fingerprint(self, params, inputs, enc_params, et):
+        """Cheap key of everything that decides the compiled call of :meth:`_forward_device` when
+        the per-sample arguments are CUDA tensors (shapes only) and the rest are the model's own
+        small host arrays (their bytes): the sampling loops call with the same structure thousands
+        of times, and re-deriving it (validation, blake2b over float64 copies, batch bookkeeping)
+        cost more host time than the GPU needed for the circuits.  None: take the general path."""
+        if enc_params is not None:
+            return None
+        if self._is_cuda(params):
+            if params.dim() not in (2, 3):
+                return None
+            pk = ("d", tuple(params.shape[-2:]), params.dim() == 3 and int(params.shape[0]) > 1)
+        elif params is None and self._params is not None and self._params.shape[0] == 1:
+            pk = ("h", hash(self._params.tobytes()), self._params.shape)
+        else:
+            return None
+        if self._is_cuda(inputs):
+            if inputs.dim() != 2 or inputs.shape[1] != self.n_input_feat:
+                return None
+            xk = ("d", int(inputs.shape[0]) > 1)
+        elif inputs is None:
+            xk = ("z",)
+        else:
+            return None
+        return (et, pk, xk, hash(self._enc_params.tobytes()), hash(self._data_reupload.tobytes()),
+                self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key())
+
+    def prepared_state_call(self, n_param_sets: int):
+        """The compiled device call that turns a CUDA tensor of ``n_param_sets`` parameter sets
+        (inputs None) into statevectors, looked up BEFORE the parameters exist: the sampling loops
+        resolve it first, launch the sampler, and then have nothing left to do on the host between
+        the sampler's launch and the circuit's.  -> ``(cc, divs, mods, B)`` or None (no such call
+        has been compiled yet, noise / shots / complex128 mode: take the general path)."""
+        from .utils import x64_enabled
+
+        if self.noise_params is not None or self.shots is not None or self.gate_mode != "unitary":
+            return None
+        if (x64_enabled() if self.x64 is None else self.x64):
+            return None
+        fp = ("state", ("d", tuple(self._params_shape), n_param_sets > 1), ("z",),
+              hash(self._enc_params.tobytes()), hash(self._data_reupload.tobytes()),
+              self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key())
+        rec = self._fast_calls.get(fp)
+        if rec is None:
+            return None
+        cc, p_leaf, x_leaf, _b_i, _b_p, _cross, zero_inputs = rec
+        if not p_leaf or x_leaf:
+            return None
+        self._execution_type = "state"
+        self._zero_inputs = zero_inputs
+        self._batch_shape = (1, n_param_sets, 1)
+        return cc, [1], [n_param_sets if n_param_sets > 1 else 1], n_param_sets
+
+    def _oq_key(self):
+        oq = self.output_qubit
+        return tuple(oq) if oq and isinstance(oq[0], (int, np.integer)) else repr(oq)
+
     def _forward_device(self, params, inputs, enc_params, execution_type, force_mean,
                         _want_call: bool = False, raw: bool = False):
         """``__call__`` for CUDA-tensor ``params`` / ``inputs``: nothing per sample happens on
         the host and the result stays on the GPU (a ``torch`` tensor).  Falls back to the host
         path (returns ``NotImplemented``) for partial-wire density / probs or non-affine angles."""
-        import hashlib
-
         import torch
 
         from . import distributed
-        from .script import NotAffine
 
-        if execution_type is not None:
+        if execution_type is not None and execution_type != self._execution_type:
             self.execution_type = execution_type
         et = self.execution_type
         if et in ("density", "probs") and not self.all_qubit_measurement:
             return NotImplemented
+        fp = self._call_fingerprint(params, inputs, enc_params, et)
+        rec = self._fast_calls.get(fp) if fp is not None else None
+        if rec is not None:  # same structure as an earlier call: only the leaves are new
+            cc, p_leaf, x_leaf, B_I0, B_P0, cross, zero_inputs = rec
+            leaves, divs, mods = [], [], []
+            B_P, B_I = B_P0, B_I0
+            if p_leaf:
+                p = params.to(torch.float32)
+                p = (p.unsqueeze(0) if p.dim() == 2 else p).contiguous()
+                B_P = int(p.shape[0])
+                leaves.append(p); divs.append(1); mods.append(B_P if B_P > 1 else 1)
+            if x_leaf:
+                x = inputs.to(torch.float32).contiguous()
+                B_I = int(x.shape[0])
+                leaves.append(x); divs.append(B_P if cross else 1); mods.append(B_I if B_I > 1 else 1)
+            if B_I > 1 and B_P > 1 and not cross and B_I != B_P:
+                raise ValueError("zipped batch axes must have equal length")
+            self._zero_inputs = zero_inputs
+            self._batch_shape = (B_I, B_P, 1)
+            B = (B_I * B_P if cross else max(B_I, B_P))
+        else:
+            got = self._device_call(params, inputs, enc_params, et)
+            if got is NotImplemented:
+                return NotImplemented
+            cc, leaves, divs, mods, B, rec = got
+            if fp is not None and rec is not None:
+                if len(self._fast_calls) > 32:
+                    self._fast_calls.clear()
+                self._fast_calls[fp] = rec
+        if _want_call:  # (Model.vjp_device) hand the compiled call + its leaves to the caller
+            return cc, leaves, divs, mods, B
+        lo, hi, sharded = distributed.my_block(B, *leaves)
+        result = cc.run(leaves, divs, mods, hi - lo, lo)
+        if sharded:
+            result = distributed.all_gather_rows(result, B)
+        if raw:  # the analysis loops' (B, ...) device tensor, batch axis flat
+            return result
+        result = result.reshape((*[int(d) for d in self.eff_batch_shape], *self._result_shape))
+        result = result.squeeze()
+        if et in ("expval", "probs") and force_mean and result.dim() > 0 and self._result_shape[0] > 1:
+            result = result.mean(dim=-1)
+        return result
+
+    def _device_call(self, params, inputs, enc_params, et):
+        """The general derivation of a compiled device call: argument validation, batch
+        bookkeeping, cache key over the VALUES of every host argument, tape recording on a miss.
+        -> ``(cc, leaves, divs, mods, B, record for the fingerprint cache)`` or NotImplemented."""
+        import hashlib
+
+        import torch
+
+        from .script import NotAffine
+
         enc = self._enc_params_validation(enc_params)
         dev_params, dev_inputs = self._is_cuda(params), self._is_cuda(inputs)
+        uploaded = False
         # --- shapes (mirrors _params_validation / _inputs_validation, shapes only) ----------
         if dev_params:
             p = params.to(torch.float32)
@@ -746,6 +855,7 @@ class Model:
             B_P = 1 if 0 in p.shape else int(p.shape[0])
             if B_P > 1:
                 p, dev_params = torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).cuda(), True
+                uploaded = True
         if dev_inputs:
             x = inputs.to(torch.float32)
             if x.dim() <= 1:
@@ -768,10 +878,11 @@ class Model:
             B_I = int(x.shape[0])
             if B_I > 1:
                 x, dev_inputs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda(), True
+                uploaded = True
         self._batch_shape = (B_I, B_P, 1)
         B = int(np.prod(self.eff_batch_shape))
         rep_i, rep_p, _ = self.repeat_batch_axis
-        cross = B_I > 1 and B_P > 1 and rep_i and rep_p
+        cross = bool(B_I > 1 and B_P > 1 and rep_i and rep_p)
         if B_I > 1 and B_P > 1 and not cross and B_I != B_P:
             raise ValueError("zipped batch axes must have equal length")
         # --- compiled call ------------------------------------------------------------------
@@ -809,19 +920,9 @@ class Model:
             leaves.append(p); divs.append(1); mods.append(B_P if B_P > 1 else 1)
         if dev_inputs:
             leaves.append(x); divs.append(B_P if cross else 1); mods.append(B_I if B_I > 1 else 1)
-        if _want_call:  # (Model.vjp_device) hand the compiled call + its leaves to the caller
-            return cc, leaves, divs, mods, B
-        lo, hi, sharded = distributed.my_block(B, *leaves)
-        result = cc.run(leaves, divs, mods, hi - lo, lo)
-        if sharded:
-            result = distributed.all_gather_rows(result, B)
-        if raw:  # the analysis loops' (B, ...) device tensor, batch axis flat
-            return result
-        result = result.reshape((*[int(d) for d in self.eff_batch_shape], *self._result_shape))
-        result = result.squeeze()
-        if et in ("expval", "probs") and force_mean and result.dim() > 0 and self._result_shape[0] > 1:
-            result = result.mean(dim=-1)
-        return result
+        # (a call whose leaves were uploaded host batches is keyed by their values: no shape-only record)
+        rec = None if uploaded else (cc, dev_params, dev_inputs, B_I, B_P, cross, self._zero_inputs)
+        return cc, leaves, divs, mods, B, rec
 
     def vjp_device(self, params, inputs, cotangent, enc_params=None, force_mean: bool = False):
         """Device-resident adjoint gradient: ``params`` / ``inputs`` are CUDA tensors (as for

@@ -94,21 +94,36 @@ class CompiledCall:
 
     def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0):
         """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order."""
-        strides = [int(np.prod(t.shape[1:], dtype=np.int64)) for t in leaves]
+        strides = [t[0].numel() if t.shape[0] else 0 for t in leaves]
         angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
                                 self.d_coef, self.d_const, self.n_slots, batch, batch_offset,
                                 d_period=self.d_period)
         if self.n_slots == 0:
             import torch
             angles = torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device)
-        masks = [z_parity_mask(o) for o in self.obs]
         if self.type == "expval":
-            if self.obs and all(m is not None and len(m) == 1 for m in masks):
-                return self.plan.run(angles, "expval", [m[0] for m in masks])
-            if self.obs and all(m is not None for m in masks) and len(masks) <= 32:
-                return self.plan.run_parity(angles, masks)
+            kind, arg = self._measure()
+            if kind == "z":
+                return self.plan.run(angles, "expval", arg)
+            if kind == "parity":
+                return self.plan.run_parity(angles, arg)
             return simulation._general_expval(self.plan.run(angles, "state"), self.n_qubits, self.obs)
         return self.plan.run(angles, self.type)
+
+    def _measure(self):
+        """How the observables are measured (fixed per compiled call): ("z", wires) for plain Z's,
+        ("parity", wire groups) for Z-parities, ("general", None) otherwise."""
+        m = getattr(self, "_meas", None)
+        if m is None:
+            masks = [z_parity_mask(o) for o in self.obs]
+            if self.obs and all(k is not None and len(k) == 1 for k in masks):
+                m = ("z", [k[0] for k in masks])
+            elif self.obs and all(k is not None for k in masks) and len(masks) <= 32:
+                m = ("parity", masks)
+            else:
+                m = ("general", None)
+            self._meas = m
+        return m
 
     def _adjoint_setup(self):
         """Reverse tape, generator terms and the chain-rule matrices -- built once."""
