@@ -22,8 +22,8 @@ __global__ void k_build_matrices(const BuildOp *__restrict__ build,
                                  const BuildGroup *__restrict__ groups, int n_groups,
                                  const float *__restrict__ angles, int n_slots,
                                  const float *__restrict__ consts, float *__restrict__ mats,
-                                 uint32_t mat_floats) {
-  build_matrices_body<float, float, float>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats);
+                                 uint32_t mat_floats, int batch) {
+  build_matrices_body<float, float, float>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -133,12 +133,9 @@ bool plan_sparse(const qmle_plan *p) {
 int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream) {
   if (p->groups.empty()) return QMLE_OK;
   const int ng = (int)p->groups.size();
-  for (int b0 = 0; b0 < batch; b0 += 65535) {
-    const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
-    hipLaunchKernelGGL(k_build_matrices, dim3((ng + 63) / 64, bc), dim3(64), 0, stream, p->dev.d_build,
-                       p->dev.d_groups, ng, d_angles + (size_t)b0 * p->n_slots, p->n_slots, p->dev.d_consts,
-                       d_mats + (size_t)b0 * p->mat_floats, p->mat_floats);
-  }
+  const uint64_t items = (uint64_t)batch * (uint64_t)ng;  // one work item per (sample, group)
+  hipLaunchKernelGGL(k_build_matrices, dim3(grid_for(items, 64)), dim3(64), 0, stream, p->dev.d_build,
+                     p->dev.d_groups, ng, d_angles, p->n_slots, p->dev.d_consts, d_mats, p->mat_floats, batch);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

@@ -21,8 +21,8 @@ __global__ void k_build_matrices_f64(const BuildOp *__restrict__ build,
                                      const BuildGroup *__restrict__ groups, int n_groups,
                                      const double *__restrict__ angles, int n_slots,
                                      const double *__restrict__ consts, double *__restrict__ mats,
-                                     uint32_t mat_floats) {
-  build_matrices_body<double, double, double>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats);
+                                     uint32_t mat_floats, int batch) {
+  build_matrices_body<double, double, double>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,8 +288,8 @@ int qmle_apply_inplace_f64(qmle_plan *plan, const double *d_angles, int batch, v
   double *d_mats = (double *)ws;
   if (!plan->groups.empty()) {
     const int ng = (int)plan->groups.size();
-    hipLaunchKernelGGL(k_build_matrices_f64, dim3((ng + 63) / 64, batch), dim3(64), 0, stream, plan->dev.d_build,
-                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats);
+    hipLaunchKernelGGL(k_build_matrices_f64, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
+                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
   }
   const int n = plan->n;
   const unsigned gx = grid_for(((size_t)1 << n) / 2, 256, 1u << 16);
@@ -334,12 +334,8 @@ int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int m
   ws += align_up((size_t)batch * (plan->mat_floats ? plan->mat_floats : 1) * sizeof(double), 256);
   if (!plan->groups.empty()) {
     const int ng = (int)plan->groups.size();
-    for (int b0 = 0; b0 < batch; b0 += 65535) {
-      const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
-      hipLaunchKernelGGL(k_build_matrices_f64, dim3((ng + 63) / 64, bc), dim3(64), 0, stream, plan->dev.d_build,
-                         plan->dev.d_groups, ng, d_angles + (size_t)b0 * plan->n_slots, plan->n_slots, d_c64,
-                         d_mats + (size_t)b0 * plan->mat_floats, plan->mat_floats);
-    }
+    hipLaunchKernelGGL(k_build_matrices_f64, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
+                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
   }
   const size_t D = (size_t)1 << n;
   const int n_ops = (int)plan->lowered.size();

@@ -142,10 +142,13 @@ __device__ __forceinline__ void build_matrices_body(const BuildOp *__restrict__ 
                                                     const BuildGroup *__restrict__ groups, int n_groups,
                                                     const AT *__restrict__ angles, int n_slots,
                                                     const CT *__restrict__ consts, OT *__restrict__ mats,
-                                                    uint32_t mat_floats) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
-  if (g >= n_groups) return;
+                                                    uint32_t mat_floats, int batch) {
+  // one work item per (sample, group), samples and groups flattened: a grid of (groups / 64, samples)
+  // left 62 of the 192 lanes per sample idle at 130 groups (C4) -- a third of the kernel
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long b_ll = idx / n_groups;
+  if (b_ll >= batch) return;
+  const int b = (int)b_ll, g = (int)(idx - b_ll * n_groups);
   const BuildGroup grp = groups[g];
   const AT *ang = angles + (size_t)b * n_slots;
   const int dim = (int)grp.dim;

@@ -270,17 +270,61 @@ static void build_fast_groups(qmle_plan *p, Stage &st, const std::vector<Lowered
     if (o.c0 >= 0) m |= 1u << o.c0;
     return m;
   };
-  auto deposit = [&](uint32_t t, uint32_t G) {  // bits of t into the positions outside G
-    uint32_t e = 0;
-    int k = 0;
+  // Thread index bit k of a group's work items -> tile-local position pos_of[k] (outside the group's
+  // bits).  Any bijection is correct; WHICH one decides the LDS bank conflicts of the group's 32
+  // accesses: slot(thread, c) = P(thread) ^ Q(c) with P linear over GF(2), so a ds_write_b64's 16-lane
+  // groups are conflict-free iff thread bits 0..3 land on columns that are independent in slot bits
+  // 0..3 (16 slots = 32 banks), and a ds_read_b64's 32-lane groups iff bits 0..4 are independent in
+  // slot bits 0..4 (MI355X_MICROARCH.md, LDS table).  Ascending order -- the round-2 choice -- left
+  // 33-38 % of the LDS cycles of the whole-state kernels to conflicts (SQ_LDS_BANK_CONFLICT,
+  // profiles/r04_ws_sq_*.txt).  Only the lane bits are permuted: the wave index keeps the highest
+  // positions, where the known zeros of a run from |0..0> sit (whole waves of idle work items skip).
+  int pos_of[16];
+  static const bool no_bank_perm = std::getenv("QMLE_NO_BANK_PERM") != nullptr;
+  auto choose_thread_bits = [&](uint32_t G, bool keep_order) {
+    int freep[16], nf = 0;
     for (int j = 0; j < T; ++j)
-      if (!(G & (1u << j))) e |= ((t >> k++) & 1u) << j;
+      if (!(G & (1u << j))) freep[nf++] = j;
+    for (int k = 0; k < nf; ++k) pos_of[k] = freep[k];
+    const int lanes = nf < 6 ? nf : 6;
+    if (keep_order || no_bank_perm || lanes < 2) return;
+    uint32_t basis[8];
+    int nb = 0;
+    auto independent = [&](uint32_t v) {  // reduce v by the basis; keep it when something is left
+      for (int i = 0; i < nb; ++i)
+        if ((v ^ basis[i]) < v) v ^= basis[i];
+      if (!v) return false;
+      basis[nb++] = v;
+      for (int i = nb - 1; i > 0 && basis[i] > basis[i - 1]; --i) std::swap(basis[i], basis[i - 1]);
+      return true;
+    };
+    bool used[16] = {};
+    int order[16], no = 0;
+    for (int k = 0; k < lanes && no < 4; ++k)  // four columns independent in slot bits 0..3
+      if (independent(swz(Lcol[freep[k]]) & 0xFu)) { order[no++] = k; used[k] = true; }
+    nb = 0;
+    for (int i = 0; i < no; ++i) (void)independent(swz(Lcol[freep[order[i]]]) & 0x1Fu);
+    const int first4 = no;
+    for (int k = 0; k < lanes && no < first4 + 1; ++k)  // a fifth, independent in slot bits 0..4
+      if (!used[k] && independent(swz(Lcol[freep[k]]) & 0x1Fu)) { order[no++] = k; used[k] = true; }
+    // fewer than four independent columns exist: the group's own bits own those banks -- fill up
+    // (thread bits 4 / 5 only choose the lane group of a write, bit 5 that of a read)
+    for (int k = 0; k < lanes; ++k)
+      if (!used[k]) order[no++] = k;
+    for (int k = 0; k < lanes; ++k) pos_of[k] = freep[order[k]];
+  };
+  auto deposit = [&](uint32_t t, uint32_t G) {  // bits of t into the positions outside G
+    (void)G;
+    uint32_t e = 0;
+    for (int k = 0; k < T - 4; ++k) e |= ((t >> k) & 1u) << pos_of[k];
     return e;
   };
   auto emit_tables = [&](Group2 &g, uint32_t G) {
     int gb[4], k = 0;
     for (int j = 0; j < T; ++j)
       if (G & (1u << j)) gb[k++] = j;
+    // (the idle-work-item flags below are only read by tiled runs that track known zeros)
+    choose_thread_bits(G, (Z & ~G) != 0 && T < p->n && !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)));
     g.tbl = (uint32_t)p->tbl2.size();
     for (uint32_t t = 0; t < nt; ++t) {
       const uint32_t e = deposit(t, G);

@@ -377,8 +377,14 @@ __device__ __forceinline__ uint64_t tile2_base(const TileArgs &a, const Tile2Arg
 // walked by (unrolled) loops they become one <16 x i64> value early in the optimiser, a
 // 32-register tuple that was then copied whole around every gate (32 v_mov_b64 per dense gate,
 // a third of its instructions, until round 2's second profile pass found it).
+// KEEP (whole-state launches): the 16 slot addresses of a group stay in VGPRs from the gather to the
+// in-place scatter instead of being re-derived (16 v_xor per group); there the kernel has ~50 VGPRs
+// to spare, the HBM-regime instantiations live on a 96-VGPR budget.  solo: the workgroup is ONE wave
+// (10 qubits) -- its LDS operations execute in order, so a gather that follows a scatter needs no
+// barrier and no drain of the LDS queue, only the compiler kept from reordering them.
+template <bool KEEP>
 __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const Tile2Args &f,
-                                             const u64 QMLE_CONSTANT *mrow, int tid, bool use_skip) {
+                                             const u64 QMLE_CONSTANT *mrow, int tid, bool use_skip, bool solo) {
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   const Group2 QMLE_CONSTANT *grp = as_constant(f.groups);
   if (f.n_groups <= 0) return;
@@ -408,14 +414,21 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
     const bool busy = !use_skip || __builtin_amdgcn_ballot_w64(!(addr & 1u)) != 0ull;
     addr = (addr & ~7u) + sb;
     A16 r;
+    uint32_t ka[16];  // KEEP: the slot addresses (indexed with literals only)
     if (busy || relayout) {  // (a relayout stores every slot of the new layout, zeros included)
-#define QMLE_LD(c) r.v##c = lds_ld64(addr ^ QMLE_OFF(c, o1, o2, o4, o8));
-      QMLE_X16(QMLE_LD)
+      if (KEEP) {
+#define QMLE_LD(c) ka[c] = addr ^ QMLE_OFF(c, o1, o2, o4, o8); r.v##c = lds_ld64(ka[c]);
+        QMLE_X16(QMLE_LD)
 #undef QMLE_LD
+      } else {
+#define QMLE_LD(c) r.v##c = lds_ld64(addr ^ QMLE_OFF(c, o1, o2, o4, o8));
+        QMLE_X16(QMLE_LD)
+#undef QMLE_LD
+      }
     }
-    // the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
+    // (!KEEP) the 16 slot addresses are re-derived for the scatter (16 v_xor) instead of living in 16
     // VGPRs across the gates: the kernel stays within 96 VGPRs = 5 waves per SIMD
-    asm volatile("" : "+v"(addr));
+    if (!KEEP) asm volatile("" : "+v"(addr));
     const bool more = gi + 1 < f.n_groups;
     uint32_t addr_next = 0;
     if (relayout) addr_next = f.tbl[grp->tbl_out + tid];
@@ -444,7 +457,8 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
       M0 = Mn;
     }
     if (relayout) {
-      __syncthreads();  // every gather of the group is done: slots may change owners
+      if (solo) asm volatile("" ::: "memory");
+      else __syncthreads();  // every gather of the group is done: slots may change owners
       addr_next = (addr_next & ~7u) + sb;
       const uint32_t q1 = grp->off_out[1], q2 = grp->off_out[2], q4 = grp->off_out[4], q8 = grp->off_out[8];
 #define QMLE_ST(c) lds_st64(addr_next ^ QMLE_OFF(c, q1, q2, q4, q8), r.v##c);
@@ -452,14 +466,21 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
 #undef QMLE_ST
       if (more) addr_next = f.tbl[grp[1].tbl + tid];
     } else if (busy) {
-#define QMLE_ST(c) lds_st64(addr ^ QMLE_OFF(c, o1, o2, o4, o8), r.v##c);
-      QMLE_X16(QMLE_ST)
+      if (KEEP) {
+#define QMLE_ST(c) lds_st64(ka[c], r.v##c);
+        QMLE_X16(QMLE_ST)
 #undef QMLE_ST
+      } else {
+#define QMLE_ST(c) lds_st64(addr ^ QMLE_OFF(c, o1, o2, o4, o8), r.v##c);
+        QMLE_X16(QMLE_ST)
+#undef QMLE_ST
+      }
     }
     addr = addr_next;
     hdr = hdr_n;
     o1 = n1; o2 = n2; o4 = n4; o8 = n8;
-    __syncthreads();
+    if (solo) asm volatile("" ::: "memory");
+    else __syncthreads();
   }
 #undef QMLE_OFF
 }
@@ -599,7 +620,9 @@ __device__ __forceinline__ void whole_state_expval(const TileArgs &a, uint32_t s
 // MEASURE: a.meas is one of the TM_EXPVAL_* epilogues (own instantiation: the storing kernel keeps
 // a small register budget).  MULTI: several tiles per workgroup (f.tpw), plain all-live stages
 // with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
-template <bool NT, bool MEASURE, bool MULTI>
+// WS: the tile is the whole state (T == n, 10..13 qubits, launch_tile): the group loop keeps its slot
+// addresses in registers and a one-wave workgroup drops its barriers (tile2_groups).
+template <bool NT, bool MEASURE, bool MULTI, bool WS = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -759,7 +782,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
       load_tile(st);
     }
 
-    tile2_groups(sbo, addr, f, mrow, tid, a.zin_local != 0);  // known zeros: Stage::zero_in
+    tile2_groups<WS>(sbo, addr, f, mrow, tid, a.zin_local != 0, WS && nt <= kWave);  // known zeros: Stage::zero_in
 
     if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
@@ -1657,6 +1680,12 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       QMLE_T2_LDS(false, false, true); QMLE_T2_LDS(true, false, true);
       QMLE_T2_LDS(false, true, true); QMLE_T2_LDS(true, true, true);
 #undef QMLE_T2_LDS
+      QMLE_LDS_BASE_CHECK((k_tile2<false, false, false, true>));
+      QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, true>));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     Tile2Args f;
     f.groups = p->dev.d_groups2 + st.fast_begin;
@@ -1747,7 +1776,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
 #define QMLE_T2_GO(NT, ME, MU) \
   hipLaunchKernelGGL((k_tile2<NT, ME, MU>), grid, dim3(threads), lds2, stream, a, f)
     const bool multi = f.tpw > 1;
-    if (measure) {
+    static const bool no_ws = std::getenv("QMLE_NO_WS_KERNEL") != nullptr;  // (A/B: the generic instantiation)
+    if (st.T == p->n && !multi && !a.nt && !no_ws) {  // the whole state in one tile (10..13 qubits)
+      if (measure) hipLaunchKernelGGL((k_tile2<false, true, false, true>), grid, dim3(threads), lds2, stream, a, f);
+      else hipLaunchKernelGGL((k_tile2<false, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
+    } else if (measure) {
       if (multi) { if (a.nt) QMLE_T2_GO(true, true, true); else QMLE_T2_GO(false, true, true); }
       else { if (a.nt) QMLE_T2_GO(true, true, false); else QMLE_T2_GO(false, true, false); }
     } else {

@@ -17,7 +17,11 @@ def he_ops(n, layers):
     return ops, slots
 
 
-for n, layers, B in ((10, 6, 65536), (12, 3, 32768), (13, 3, 16384), (10, 6, 4096), (12, 3, 2048)):
+SHAPES = ((10, 6, 65536), (12, 3, 32768), (13, 3, 16384), (10, 6, 4096), (12, 3, 2048))
+if os.environ.get("WS_SHAPES"):  # e.g. WS_SHAPES=10:6:65536,12:3:32768
+    SHAPES = tuple(tuple(int(v) for v in t.split(":")) for t in os.environ["WS_SHAPES"].split(","))
+REPS = int(os.environ.get("WS_REPS", "20"))
+for n, layers, B in SHAPES:
     ops, slots = he_ops(n, layers)
     ang = torch.from_numpy(np.random.default_rng(0).uniform(0, 6.28, (B, slots)).astype(np.float32)).cuda()
     plan = N.Plan(ops, n, slots)
@@ -26,7 +30,7 @@ for n, layers, B in ((10, 6, 65536), (12, 3, 32768), (13, 3, 16384), (10, 6, 409
     for _ in range(3):
         plan.run(ang, "expval", obs, workspace=ws)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = REPS
     e0.record()
     for _ in range(reps):
         plan.run(ang, "expval", obs, workspace=ws)
