@@ -630,42 +630,87 @@ def k2_unfused_leg(n, B, steps=2):
             "max_abs_diff_vs_headline_expvals": None, "_out": run["out"]}
 
 
-def mw_28q_leg(n=28, reps=100, warmup=25):
-    """BASELINE config 5: Meyer-Wallach of ONE 2^28 statevector (2 GiB, HE layer applied to |0..0>),
-    HIP events around `reps` calls.  frac = the 8 D-byte single read of SURVEY 8-d / time / 8 TB/s;
-    moved_frac = bytes the reads of the call really fetch (reads_per_call x 8 D) / time / 8 TB/s."""
-    from qml_essentials_amd import _native as N
-    from oracle.circuits import bricks  # wire-pair generator only (test infrastructure, no compute)
+def _he_layer_ops(n):
+    """One Hardware_Efficient layer as native ops (RY RZ RY per wire + the two CX brick layers,
+    ansaetze.py:713-733) -- wire pairs from the product's own Topology."""
+    from qml_essentials_amd.topologies import Topology
 
     ops = [(g, [q], [i * n + q], -1) for i, g in enumerate(("RY", "RZ", "RY")) for q in range(n)]
-    ops += [("CX", [a, b], [], -1) for a, b in bricks(n, mirror=False) +
-            bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
-    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, 3 * n)).astype(np.float32)).cuda()
-    st = N.Plan(ops, n, 3 * n).run(ang, "state")
-    for _ in range(warmup):  # ~25 ms: past the clock transient that follows an idle period
-        q = N.meyer_wallach(st)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        q = N.meyer_wallach(st)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ops += [("CX", [a, b], [], -1) for a, b in Topology.bricks(n, mirror=False) +
+            Topology.bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
+    return ops, 3 * n
+
+
+def mw_28q_leg(n=28, reps=100, warmup=25):
+    """BASELINE config 5: Meyer-Wallach of ONE 2^28 statevector (2 GiB, HE layer applied to |0..0>),
+    HIP events around `reps` calls.  Two forms: `resident` -- qmle_meyer_wallach on a state that
+    already lies in HBM (three reads) -- and `fused` -- QMLE_MEAS_MEYER_WALLACH, where the circuit's
+    last pass reports the sums of its own tile from LDS and two reads remain; `fused_ms` is what
+    Entanglement.meyer_wallach spends after the circuit = (circuit + Meyer-Wallach) - (circuit alone).
+    frac = the 8 D-byte single read of SURVEY 8-d / time / 8 TB/s; moved_frac = bytes the reads of
+    the call really fetch / time / 8 TB/s."""
+    from qml_essentials_amd import _native as N
+
+    ops, slots = _he_layer_ops(n)
+    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots)
+    st = plan.run(ang, "state")
+
+    def timed(fn):
+        for _ in range(warmup):  # ~25 ms: past the clock transient that follows an idle period
+            out = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    ms, q = timed(lambda: N.meyer_wallach(st))
+    ws_s = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
+    ws_m = torch.empty(plan.workspace_bytes(1, "mw"), dtype=torch.uint8, device="cuda")
+    circ_ms, _ = timed(lambda: plan.run(ang, "state", out=st, workspace=ws_s))
+    dflt_ms, qd = timed(lambda: plan.run(ang, "mw", workspace=ws_m))  # tiled state: the stand-alone reads behind the circuit
+    os.environ["QMLE_MW_FUSE_TILED"] = "1"  # (read per call) the last pass reports its tile's sums, two reads remain
+    try:
+        both_ms, qf = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
+    finally:
+        del os.environ["QMLE_MW_FUSE_TILED"]
+    fused_ms = both_ms - circ_ms
     D8 = 8.0 * (1 << n)
     reads = N.mw_reads(n)
     traffic, source, _, terr = load_traffic(f"meyer_wallach:n{n}")
-    del st
+    f_traffic, f_source, _, f_terr = load_traffic(f"meyer_wallach_fused:n{n}")
+    if abs(float(qf[0, 0]) - float(q[0])) > 2e-6:
+        raise SystemExit(f"bench.py: fused Meyer-Wallach {float(qf[0, 0])} differs from the resident one {float(q[0])}")
+    del st, ws_s, ws_m
     torch.cuda.empty_cache()
     return {"ms": round(ms, 4), "Q": float(q[0]), "n_qubits": n, "state_bytes": int(D8),
             "reads_of_the_state_per_call": reads, "calls_timed": reps, "calls_warmup": warmup,
+            "fused_ms": round(fused_ms, 4), "circuit_ms": round(circ_ms, 4), "circuit_plus_mw_ms": round(both_ms, 4),
+            "after_circuit_ms_default_route": round(dflt_ms - circ_ms, 4), "Q_default_route": float(qd[0, 0]),
+            "fused_adopted_for_tiled_states": False,
+            "fused_note": "QMLE_MEAS_MEYER_WALLACH fuses by default only when the producing pass holds the whole state "
+                          "(n <= 14: no statevector is stored at all); for tiled states the epilogue's arithmetic costs "
+                          "the last pass what the saved read costs (fused_ms vs ms), so the default route is the three "
+                          "stand-alone reads; fused_ms = the fused tiled path, measured behind QMLE_MW_FUSE_TILED=1",
+            "fused_reads_after_the_circuit": reads - 1, "Q_fused": float(qf[0, 0]),
+            "fused_roofline": {"bound": "hbm", "kernel": "tile_mw_row in the circuit's last pass + 2 x k_mw_read_later",
+                               "achieved": round(D8 / fused_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(D8 / fused_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                               "moved_frac": round((reads - 1) * D8 / fused_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                               "traffic": f_traffic, "traffic_source": f_source, "traffic_error": f_terr,
+                               "note": "time after the circuit = (circuit + Meyer-Wallach) - (circuit alone), same plan, "
+                                       "HIP events over back-to-back calls; traffic = PMC bytes fetched by the two later reads"},
             "roofline": {"bound": "hbm", "kernel": "k_mw_read_first + 2 x k_mw_read_later", "achieved": round(D8 / ms / 1e6, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
                          "moved_GBps": round(reads * D8 / ms / 1e6, 1),
                          "moved_frac": round(reads * D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": source, "traffic_error": terr,
-                         "note": "frac counts ONE read of the state (8 D bytes, SURVEY 8-d) per call; the call "
-                                 "reads it reads_of_the_state_per_call times (moved_frac); traffic = PMC bytes "
+                         "note": "resident state: frac counts ONE read of the state (8 D bytes, SURVEY 8-d) per call; the "
+                                 "call reads it reads_of_the_state_per_call times (moved_frac); traffic = PMC bytes "
                                  "fetched per call"}}
 
 
@@ -674,17 +719,18 @@ def mw_cpu_baseline(n_small=24, n_full=28):
     (oracle/analysis.py, one thread) on the same kind of state at n_small qubits -- one 2^28 state
     costs the oracle minutes -- extrapolated by the state size, and compared with the GPU's
     purities of that very state."""
-    from oracle import analysis as OA
-    from oracle.circuits import bricks
+    from oracle import analysis as OA  # the checker (cpu_baseline leg)
     from qml_essentials_amd import _native as N
 
     n = n_small
-    ops = [(g, [q], [i * n + q], -1) for i, g in enumerate(("RY", "RZ", "RY")) for q in range(n)]
-    ops += [("CX", [a, b], [], -1) for a, b in bricks(n, mirror=False) +
-            bricks(n, offset=-1, modulo=True, wrap=True, mirror=False)]
-    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, 3 * n)).astype(np.float32)).cuda()
-    st = N.Plan(ops, n, 3 * n).run(ang, "state")
+    ops, slots = _he_layer_ops(n)
+    ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots)
+    st = plan.run(ang, "state")
     q, pur = N.meyer_wallach(st, return_purities=True)
+    fused = plan.run(ang, "mw")  # the same purities out of the producing pass
+    if float((fused[0, 1:] - pur[0]).abs().max()) > 2e-6:
+        raise SystemExit("bench.py: fused and resident Meyer-Wallach purities differ")
     psi = st[0].cpu().numpy()
     t0 = time.perf_counter()
     OA.qubit_purities_pure(psi, n)  # complex64, like the reference's default: the timed run

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 144 /* 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 145 /* 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -118,8 +118,16 @@ typedef enum qmle_meas {
   QMLE_MEAS_PROBS = 1,    /* out: [B][2^n] float32  |psi|^2                    */
   QMLE_MEAS_EXPVAL_Z = 2, /* out: [B][n_obs] float32, PauliZ on obs_wires[k]
                              (fast path simulation.py:241-261, all in ONE pass) */
-  QMLE_MEAS_DENSITY = 3   /* out: [B][2^n][2^n] complex64 = |psi><psi|
+  QMLE_MEAS_DENSITY = 3,  /* out: [B][2^n][2^n] complex64 = |psi><psi|
                              (simulation.py:183-189)                           */
+  QMLE_MEAS_MEYER_WALLACH = 4 /* out: [B][n + 1] float32 = (Q, Tr rho_w^2 of wire 0 .. n-1):
+                             Meyer-Wallach of the state the plan produces
+                             (entanglement.py:56-103 + jaqsi.py:60-103).  The plan's last tile
+                             pass reports the sums of its own tile from LDS -- for n <= 14 that
+                             is everything and no state is stored; above, the state is stored
+                             and the remaining positions cost ceil((n - T) / 8) further reads
+                             (2 at n = 28) instead of qmle_meyer_wallach's 3.  batch chunks of
+                             <= 65535 states are handled inside. */
 } qmle_meas;
 
 /* plan flags */

@@ -46,7 +46,7 @@ OPCODES = {
     "RXX": 18, "RYY": 19, "RZZ": 20, "RZX": 21, "CCX": 22, "CSWAP": 23,
     "MAT1": 24, "MAT2": 25, "DIAG_ALL": 26, "MAT4": 27,
 }
-MEAS = {"state": 0, "probs": 1, "expval": 2, "density": 3}
+MEAS = {"state": 0, "probs": 1, "expval": 2, "density": 3, "mw": 4}
 
 PLAN_DEFAULT = 0
 PLAN_NO_FUSION = 1
@@ -369,6 +369,8 @@ class Plan:
                 out = torch.empty((B, D), dtype=torch.float32, device=dev)
             elif meas == "expval":
                 out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
+            elif meas == "mw":  # (Q, purity of wire 0 .. n-1) per state: QMLE_MEAS_MEYER_WALLACH
+                out = torch.empty((B, self.n_qubits + 1), dtype=torch.float32, device=dev)
             else:
                 out = torch.empty((B, D, D), dtype=torch.complex64, device=dev)
         workspace = self._workspace(B, meas, n_obs, states_in_flight, workspace, dev)

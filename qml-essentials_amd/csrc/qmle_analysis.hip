@@ -651,11 +651,7 @@ struct MwReadArgs {
   int n, lo, lo2, q;  // tile = bits 0..3 + lo..lo+3 + lo2..lo2+3; 2^q tiles per workgroup
 };
 
-// x conj(y) accumulated into (re, im): two packed fmas
-__device__ __forceinline__ void mw_cross(v2f &s, v2f x, v2f y) {
-  s = __builtin_elementwise_fma(x, y.xx, s);
-  s = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, s);
-}
+// (mw_cross: qmle_dev.h -- the tile kernels' fused Meyer-Wallach epilogue uses it too)
 // cross terms of the 4 bits a 16-amplitude register gather spans
 template <int B0>
 __device__ __forceinline__ void mw_cross16(v2f (&cr)[12], const v2f (&r)[16]) {
@@ -863,6 +859,103 @@ __global__ void k_mw_tile_q(const float *__restrict__ pur, int n, int batch,
   }
   out[b] = (float)(2.0 * (1.0 - sum / n));
 }
+// ---- Meyer-Wallach behind a producing pass (QMLE_MEAS_MEYER_WALLACH) -------------------------
+// The circuit's last tile pass left one row of kMwFusedRowA floats per tile (tile_mw_row in
+// qmle_tile_dev.h: cross terms and signed populations of the tile's T local bits + the tile's total);
+// positions outside that tile take their cross terms from `later` reads of the stored state and their
+// populations from the totals signed by the matching bit of the tile index.
+constexpr int kMwFusedRowA = 48;  // = kMwFusedRow (qmle_tile_dev.h)
+struct MwFusedArgs {
+  const float *first;       // [batch][rows_first][kMwFusedRowA]
+  const float *later[8];    // [batch][rows_later[r]][kMwRowLater]
+  uint32_t rows_first, rows_later[8];
+  int T, n;
+  int lg;                   // a row covers 2^lg consecutive tiles (the producing workgroup's walk): outer index
+                            // bits < lg come with their own signed totals at [3T + 1 + i]
+  int8_t loc[QMLE_MAX_QUBITS];        // position p -> local bit of the producing tile, or -1
+  int8_t outer_idx[QMLE_MAX_QUBITS];  // position p -> bit of the tile index, or -1
+  int8_t src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];  // outer positions: later read (from 0) and its column
+};
+// gridDim.z = 1: the purity itself; > 1: slice z of the rows -> partial[b][p][z] = (cr, ci, z, tot) in
+// fp64, summed by k_mw_purity_final (one block per (state, position) walking 32768 rows -- n = 28, one
+// row per tile -- took 0.21 ms: only 28 workgroups were at it)
+__global__ void __launch_bounds__(1024)
+k_mw_purity_fused(const MwFusedArgs a, float *__restrict__ pur_out /* [batch][n] by bit position */,
+                  double *__restrict__ partial) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, p = blockIdx.y;
+  const int T = a.T, j = a.loc[p], oi = a.outer_idx[p], lg = a.lg;
+  const float *fr = a.first + (size_t)b * a.rows_first * kMwFusedRowA;
+  const uint32_t per = (a.rows_first + gridDim.z - 1) / gridDim.z;
+  const uint32_t r_lo = blockIdx.z * per, r_hi = r_lo + per < a.rows_first ? r_lo + per : a.rows_first;
+  double cr = 0, ci = 0, z = 0, tot = 0;
+  for (uint32_t i = r_lo + threadIdx.x; i < r_hi; i += blockDim.x) {
+    const float *row = fr + (size_t)i * kMwFusedRowA;
+    const float t = row[3 * T];
+    tot += t;
+    if (j >= 0) { cr += row[2 * j]; ci += row[2 * j + 1]; z += row[2 * T + j]; }
+    else if (oi < lg) z += row[3 * T + 1 + oi];  // a bit of the tile's index inside the workgroup's walk
+    else z += ((i >> (oi - lg)) & 1u) ? -(double)t : (double)t;
+  }
+  if (j < 0) {
+    const int r = a.src_read[p], col = a.src_col[p];
+    const float *lr = a.later[r] + (size_t)b * a.rows_later[r] * kMwRowLater;
+    const uint32_t perl = (a.rows_later[r] + gridDim.z - 1) / gridDim.z;
+    const uint32_t l_lo = blockIdx.z * perl, l_hi = l_lo + perl < a.rows_later[r] ? l_lo + perl : a.rows_later[r];
+    for (uint32_t i = l_lo + threadIdx.x; i < l_hi; i += blockDim.x) {
+      cr += lr[(size_t)i * kMwRowLater + 2 * col];
+      ci += lr[(size_t)i * kMwRowLater + 2 * col + 1];
+    }
+  }
+  cr = block_sum_d(cr, red);
+  ci = block_sum_d(ci, red);
+  z = block_sum_d(z, red);
+  tot = block_sum_d(tot, red);
+  if (threadIdx.x == 0) {
+    if (gridDim.z > 1) {
+      double *o = partial + (((size_t)b * a.n + p) * gridDim.z + blockIdx.z) * 4;
+      o[0] = cr; o[1] = ci; o[2] = z; o[3] = tot;
+    } else {
+      const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
+      pur_out[(size_t)b * a.n + p] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
+    }
+  }
+}
+__global__ void __launch_bounds__(64)
+k_mw_purity_final(const double *__restrict__ partial, int n, int batch, int slices, float *__restrict__ pur_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (state, position)
+  if (i >= batch * n) return;
+  double cr = 0, ci = 0, z = 0, tot = 0;
+  for (int s = 0; s < slices; ++s) {
+    const double *o = partial + ((size_t)i * slices + s) * 4;
+    cr += o[0]; ci += o[1]; z += o[2]; tot += o[3];
+  }
+  const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
+  pur_out[i] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
+}
+// (Q [batch], purities by wire [batch][n]) -> out[b] = (Q, purities by wire)
+__global__ void k_mw_pack_wires(const float *__restrict__ q, const float *__restrict__ pur, int n, int batch,
+                                float *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  float *o = out + (size_t)b * (n + 1);
+  o[0] = q[b];
+  for (int w = 0; w < n; ++w) o[1 + w] = pur[(size_t)b * n + w];
+}
+// out[b] = (Q, purity of wire 0, ..., purity of wire n-1)
+__global__ void k_mw_pack(const float *__restrict__ pur, int n, int batch, float *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double sum = 0.0;
+  float *o = out + (size_t)b * (n + 1);
+  for (int p = 0; p < n; ++p) {
+    const float v = pur[(size_t)b * n + p];
+    sum += v;
+    o[1 + (n - 1 - p)] = v;  // index by wire
+  }
+  o[0] = (float)(2.0 * (1.0 - sum / n));
+}
+
 // vec(rho) measurements: rho[i][j] at flat index i * D + j (ket bits first)
 __global__ void __launch_bounds__(256)
 k_density_probs(const float2 *__restrict__ rho, int n, float *__restrict__ out) {
@@ -1218,6 +1311,173 @@ static MwPlan mw_plan(int n, int batch) {
   }
   return pl;
 }
+
+namespace qmle {
+
+// Later reads that cover the positions outside the producing tile (`tile_mask`: bit p set <=> position p
+// is a local bit of that tile; it holds positions 0..3).  A later read reports the cross terms of two
+// runs of four positions [lo, lo + 4), [lo2, lo2 + 4) with 4 <= lo, lo + 4 <= lo2, lo2 + 4 <= n.
+struct MwCover {
+  int n_later = 0;
+  int lo[8], lo2[8], q[8];
+  uint32_t rows_later[8];
+  int src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];
+  bool ok = true;
+};
+static MwCover mw_cover(int n, uint32_t tile_mask, int batch) {
+  MwCover cv;
+  for (int p = 0; p < n; ++p) cv.src_read[p] = cv.src_col[p] = -1;
+  if ((tile_mask & 0xFu) != 0xFu || n < kMwT) { cv.ok = false; return cv; }
+  int chunks[8], nc = 0, covered_to = 0;
+  for (int p = 4; p < n; ++p) {
+    if ((tile_mask >> p) & 1u) continue;
+    if (p < covered_to) continue;
+    if (nc == 8) { cv.ok = false; return cv; }
+    const int c = p + 4 <= n ? p : n - 4;
+    chunks[nc++] = c;
+    covered_to = c + 4;
+  }
+  const uint32_t tiles = 1u << (n - kMwT);
+  auto pick_q = [&](int want) {
+    int q = 0;
+    while (q < want && (((uint64_t)batch * tiles) >> (q + 1)) >= 2048) ++q;
+    return q;
+  };
+  int i = 0, j = nc - 1;
+  while (i <= j) {
+    int a = chunks[i], b = i < j ? chunks[j] : -1;
+    if (b < 0) {  // odd one out: any other run completes the read
+      b = a;
+      a = b >= 16 ? 8 : b >= 8 ? b - 4 : -1;
+      if (a < 0) { a = b; b = a + 4; if (b + 4 > n) { cv.ok = false; return cv; } }
+    }
+    if (a > b) std::swap(a, b);
+    if (b < a + 4) a = b - 4;  // overlapping runs (the last one is clamped to n - 4): shift the lower one down
+    if (a < 4) { cv.ok = false; return cv; }
+    const int r = cv.n_later++;
+    cv.lo[r] = a;
+    cv.lo2[r] = b;
+    cv.q[r] = pick_q(2);
+    cv.rows_later[r] = tiles >> cv.q[r];
+    for (int k = 0; k < 8; ++k) {
+      const int p = k < 4 ? a + k : b + k - 4;
+      if (p < n && !((tile_mask >> p) & 1u) && cv.src_read[p] < 0) { cv.src_read[p] = r; cv.src_col[p] = k; }
+    }
+    ++i;
+    --j;
+  }
+  for (int p = 0; p < n; ++p)
+    if (!((tile_mask >> p) & 1u) && cv.src_read[p] < 0) cv.ok = false;
+  return cv;
+}
+
+static uint32_t stage_tile_mask(const Stage &st) {
+  uint32_t m = 0;
+  for (int j = 0; j < st.T; ++j) m |= 1u << st.tile_bits[j];
+  return m;
+}
+
+// Can stage `last` (the plan's last one) report its tile's Meyer-Wallach sums, and do fewer reads
+// than the stand-alone kernel's remain?  (16 amplitudes per work item: T >= 10.)
+bool mw_fusable(int n, const Stage &last) {
+  if (last.kind != ST_TILE || last.T < 10 || last.T > 14) return false;
+  if (last.T == n) return true;
+  const MwCover cv = mw_cover(n, stage_tile_mask(last), 1);
+  return cv.ok && cv.n_later < qmle_meyer_wallach_reads(n);
+}
+
+size_t mw_fused_ws_bytes(int n, int batch, const Stage &last) {
+  size_t fl = ((size_t)1 << (n - last.T)) * kMwFusedRowA;  // one row per tile
+  if (last.T < n) {
+    const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
+    for (int r = 0; r < cv.n_later; ++r) fl += (size_t)cv.rows_later[r] * kMwRowLater;
+  }
+  return ((size_t)batch * fl + (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) +
+         (size_t)8192 * 4 * sizeof(double) + 1024;  // + the purity kernel's slices (< 8192 (state, position, slice) sums)
+}
+
+// rows_first = ws (filled by the producing pass: [batch][tiles][kMwFusedRowA]); the later reads' rows and
+// the purities follow it.  d_out [batch][n + 1] = (Q, purities by wire).
+int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int row_shift, void *ws_,
+                 size_t ws_bytes, float *d_out, hipStream_t stream) {
+  if (batch < 1 || batch > 65535) return QMLE_ERR_INVALID_ARG;
+  if (ws_bytes < mw_fused_ws_bytes(n, batch, last) - 512) return QMLE_ERR_WORKSPACE;
+  float *ws = (float *)ws_;
+  MwFusedArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.first = ws;
+  pa.rows_first = (1u << (n - last.T)) >> row_shift;
+  pa.lg = row_shift;
+  pa.T = last.T;
+  pa.n = n;
+  for (int p = 0; p < QMLE_MAX_QUBITS; ++p) pa.loc[p] = pa.outer_idx[p] = pa.src_read[p] = pa.src_col[p] = -1;
+  for (int j = 0; j < last.T; ++j) pa.loc[(int)last.tile_bits[j]] = (int8_t)j;
+  for (int i = 0; i < n - last.T; ++i) pa.outer_idx[(int)last.outer_bits[i]] = (int8_t)i;
+  ws += (size_t)batch * ((size_t)1 << (n - last.T)) * kMwFusedRowA;  // (one row per tile)
+  if (last.T < n) {
+    const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
+    if (!cv.ok) return QMLE_ERR_INTERNAL;
+    if (first_use_on_device(6)) {
+      QMLE_LDS_BASE_CHECK(k_mw_read_later<true>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_later<false>);
+    }
+    const uint32_t tiles = 1u << (n - kMwT);
+    const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
+    for (int r = 0; r < cv.n_later; ++r) {
+      MwReadArgs a;
+      a.states = states;
+      a.n = n;
+      a.rows = ws;
+      a.lo = cv.lo[r];
+      a.lo2 = cv.lo2[r];
+      a.q = cv.q[r];
+      pa.later[r] = ws;
+      pa.rows_later[r] = cv.rows_later[r];
+      ws += (size_t)batch * cv.rows_later[r] * kMwRowLater;
+      const dim3 grid(tiles >> a.q, batch);
+      if (nt) hipLaunchKernelGGL(k_mw_read_later<true>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
+      else hipLaunchKernelGGL(k_mw_read_later<false>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
+    }
+    for (int p = 0; p < n; ++p) { pa.src_read[p] = (int8_t)cv.src_read[p]; pa.src_col[p] = (int8_t)cv.src_col[p]; }
+  }
+  float *d_pur = ws;
+  ws += (size_t)batch * QMLE_MAX_QUBITS;
+  // enough workgroups for the row sums: slices of >= 256 rows, <= 64 per (state, position)
+  uint32_t most = pa.rows_first;
+  for (int r = 0; r < 8; ++r) most = std::max(most, pa.rows_later[r]);
+  int slices = 1;
+  while (slices < 64 && (most >> 8) > (uint32_t)slices && (uint64_t)batch * n * slices < 4096) slices *= 2;
+  const int threads = most / slices >= 1024 ? 1024 : most / slices >= 256 ? 256 : 64;
+  double *d_part = (double *)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(k_mw_purity_fused, dim3(batch, n, slices), dim3(threads), 0, stream, pa, d_pur, d_part);
+  if (slices > 1)
+    hipLaunchKernelGGL(k_mw_purity_final, dim3((batch * n + 63) / 64), dim3(64), 0, stream, (const double *)d_part, n,
+                       batch, slices, d_pur);
+  hipLaunchKernelGGL(k_mw_pack, dim3((batch + 63) / 64), dim3(64), 0, stream, (const float *)d_pur, n, batch, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+// resident states, no producing pass to lean on: qmle_meyer_wallach, packed like run_mw_fused
+int run_mw_resident(const float2 *states, int n, int batch, void *ws, size_t ws_bytes, float *d_out,
+                    hipStream_t stream) {
+  const size_t need = qmle_meyer_wallach_workspace_bytes(n, batch);
+  if (ws_bytes < need + (size_t)batch * (n + 1) * sizeof(float)) return QMLE_ERR_WORKSPACE;
+  float *q = (float *)((char *)ws + ((need + 255) & ~(size_t)255));
+  float *pur = q + batch;
+  const int rc = qmle_meyer_wallach(states, n, batch, q, pur, ws, need, (qmle_stream)stream);
+  if (rc != QMLE_OK) return rc;
+  hipLaunchKernelGGL(k_mw_pack_wires, dim3((batch + 63) / 64), dim3(64), 0, stream, (const float *)q,
+                     (const float *)pur, n, batch, d_out);
+  HIPCHK(hipGetLastError());
+  return QMLE_OK;
+}
+
+size_t mw_resident_ws_bytes(int n, int batch) {
+  return ((qmle_meyer_wallach_workspace_bytes(n, batch) + 255) & ~(size_t)255) + (size_t)batch * (n + 2) * sizeof(float) + 256;
+}
+
+}  // namespace qmle
 
 extern "C" {
 

@@ -110,6 +110,12 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void *p) {  // low half 
   return (uint32_t)(uintptr_t)p;
 }
 
+// x conj(y) accumulated into (re, im): two packed fmas
+__device__ __forceinline__ void mw_cross(v2f &s, v2f x, v2f y) {
+  s = __builtin_elementwise_fma(x, y.xx, s);
+  s = __builtin_elementwise_fma((v2f){x.y, -x.x}, y.yy, s);
+}
+
 // LDS layout of a tile: amplitude e lives in slot sw(e).  XOR-ing bits 1..4 with bits
 // 5..8 keeps (even, odd) pairs adjacent (float4 staging) and spreads the 16-amplitude
 // register gathers of low-bit groups over the banks (<= 2-way instead of 16-way).

@@ -361,10 +361,30 @@ static size_t expval_partial_rows(const qmle_plan *p) {
   return rows;
 }
 
+// Meyer-Wallach measurement: can the plan's last pass report its tile's sums (tile_mw_row)?
+// Policy (measured on MI355X): when the last pass holds the WHOLE state (n <= 14) the sums cost
+// one epilogue and no statevector is ever stored -- always taken.  For tiled states the epilogue's
+// arithmetic (208 packed fmas + a 41-value wave reduction per work item and tile, the pass without the
+// next-tile prefetch) costs the pass as much as the read it saves: n = 28, 0.68 ms instead of 0.47 for the
+// pass + two reads = 1.01 ms after the circuit against 0.99 ms for the three reads of the stand-alone
+// kernels -- so tiled plans keep the stand-alone reads unless QMLE_MW_FUSE_TILED=1 (read per call: A/B, tests).
+static bool plan_mw_fusable(const qmle_plan *p) {
+  if (std::getenv("QMLE_NO_MW_FUSION") != nullptr || p->stages.empty()) return false;
+  const Stage &last = p->stages.back();
+  if (last.T < p->n && std::getenv("QMLE_MW_FUSE_TILED") == nullptr) return false;
+  return mw_fusable(p->n, last);
+}
+// rows + purities of `batch` states (conservative per state: the rows per state shrink with the batch)
+static size_t mw_ws_bytes(const qmle_plan *p, int batch) {
+  const size_t one = plan_mw_fusable(p) ? mw_fused_ws_bytes(p->n, 1, p->stages.back()) : mw_resident_ws_bytes(p->n, 1);
+  return align_up(one, 256) * (size_t)batch;
+}
+
 static size_t per_state_ws_bytes(const qmle_plan *p, int meas_type) {
   size_t b = align_up((size_t)8 << p->n, 256);
   if (meas_type == QMLE_MEAS_EXPVAL_Z)
     b += align_up(expval_partial_rows(p) * (QMLE_MAX_QUBITS + 1) * sizeof(float), 256);
+  if (meas_type == QMLE_MEAS_MEYER_WALLACH) b += mw_ws_bytes(p, 1);
   return b;
 }
 
@@ -373,6 +393,8 @@ size_t qmle::workspace_bytes_one(const qmle_plan *plan, int batch, int meas_type
   size_t total = ws_mats_bytes(plan, batch) + 512;  // + alignment slack
   const bool lds_direct_meas =
       plan->whole_state_lds && (meas_type == QMLE_MEAS_PROBS || meas_type == QMLE_MEAS_EXPVAL_Z);
+  if (meas_type == QMLE_MEAS_MEYER_WALLACH && plan->whole_state_lds && plan_mw_fusable(plan))
+    return total + mw_ws_bytes(plan, batch);  // the sums come out of the LDS tile: no state is stored
   if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
     int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
     if (s > batch) s = batch;
@@ -422,7 +444,7 @@ int qmle_run_batch(qmle_plan *plan, const float *d_angles, int batch, int meas_t
                    const int32_t *obs_wires, int n_obs, void *d_out, void *d_workspace,
                    size_t workspace_bytes, qmle_stream stream_) {
   if (!plan || batch < 1 || !d_out || !d_workspace) return QMLE_ERR_INVALID_ARG;
-  if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_DENSITY) return QMLE_ERR_MEAS_TYPE;
+  if (meas_type < QMLE_MEAS_STATE || meas_type > QMLE_MEAS_MEYER_WALLACH) return QMLE_ERR_MEAS_TYPE;
   if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
   uint32_t masks[QMLE_MAX_QUBITS];
   qmle_plan *exec = plan;
@@ -522,6 +544,22 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
   const size_t sb = D * sizeof(float2);
 
   // ---- whole state in LDS: one launch does simulate + measure ------------------
+  if (plan->whole_state_lds && meas_type == QMLE_MEAS_MEYER_WALLACH && plan_mw_fusable(plan)) {
+    // circuit + Meyer-Wallach sums in one launch per chunk: the state never leaves the LDS
+    const Stage &st = plan->stages[0];
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+      const int bc = batch - b0 < 65535 ? batch - b0 : 65535;
+      if (workspace_bytes < mw_ws_bytes(plan, bc)) return QMLE_ERR_WORKSPACE;
+      ProfScope prof_scope(plan, 0, stream);
+      rc = launch_tile(plan, st, nullptr, d_mats + (size_t)b0 * plan->mat_floats,
+                       d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr, bc, true, TM_MW_ONLY, ws,
+                       nullptr, 0, stream);
+      if (rc == QMLE_OK)
+        rc = run_mw_fused(nullptr, n, bc, st, 0, ws, workspace_bytes, (float *)d_out + (size_t)b0 * (n + 1), stream);
+      if (rc != QMLE_OK) return rc;
+    }
+    return QMLE_OK;
+  }
   if (plan->whole_state_lds) {
     const Stage &st = plan->stages[0];
     if (meas_type == QMLE_MEAS_STATE || meas_type == QMLE_MEAS_PROBS ||
@@ -568,6 +606,8 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
   // <Z> straight out of the last tile pass (no store of the final state, no extra read)
   const bool fuse_expval = meas_type == QMLE_MEAS_EXPVAL_Z && !plan->stages.empty() &&
                            plan->stages.back().kind == ST_TILE;
+  const bool fuse_mw = meas_type == QMLE_MEAS_MEYER_WALLACH && plan_mw_fusable(plan);
+  const size_t mw_bytes = meas_type == QMLE_MEAS_MEYER_WALLACH ? mw_ws_bytes(plan, in_flight) : 0;
 
   for (int b0 = 0; b0 < batch; b0 += in_flight) {
     const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
@@ -580,7 +620,13 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
     for (size_t si = 0; si < plan->stages.size(); ++si) {
       const Stage &st = plan->stages[si];
       ProfScope prof_scope(plan, (int)si, stream);
-      if (st.kind == ST_TILE) {
+      if (st.kind == ST_TILE && fuse_mw && si + 1 == plan->stages.size()) {
+        // the last pass stores the state AND reports its tile's Meyer-Wallach sums (one row per tile)
+        rc = launch_tile(plan, st, stc, mats, ang, bc, !initialised, TM_STORE_MW, d_partial, nullptr, 0, stream,
+                         /*from_zero=*/true, d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr,
+                         &tile_row_shift);
+        initialised = true;
+      } else if (st.kind == ST_TILE) {
         const bool last_fused = fuse_expval && si + 1 == plan->stages.size();
         const int tm = !last_fused ? TM_STORE : (single_bits || semi_single) ? TM_EXPVAL_PARTIAL : TM_EXPVAL_MASKS;
         reg_q = -1;
@@ -634,6 +680,11 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
                             d_partial, partial_bytes, stream)
                : run_parity_pos(stc, n, bc, obs_masks, n_obs, (float *)d_out + (size_t)b0 * n_obs,
                                 d_partial, partial_bytes, stream);
+      if (rc != QMLE_OK) return rc;
+    } else if (meas_type == QMLE_MEAS_MEYER_WALLACH) {
+      rc = fuse_mw ? run_mw_fused(stc, n, bc, plan->stages.back(), tile_row_shift, d_partial, mw_bytes,
+                                  (float *)d_out + (size_t)b0 * (n + 1), stream)
+                   : run_mw_resident(stc, n, bc, d_partial, mw_bytes, (float *)d_out + (size_t)b0 * (n + 1), stream);
       if (rc != QMLE_OK) return rc;
     } else if (meas_type == QMLE_MEAS_DENSITY) {
       if (n > 15) return QMLE_ERR_UNSUPPORTED;

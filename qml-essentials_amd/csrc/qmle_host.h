@@ -34,6 +34,8 @@ enum TileMeas : int {
                           // -> out[b][tile][33] (k_expval_final reduces); state not stored
   TM_EXPVAL_MASKS = 4,    // same, for Z-parity observables (obs_mask): per-tile Walsh-Hadamard
                           // transform of |psi|^2 -> out[b][tile][k < n_obs]
+  TM_STORE_MW = 5,        // TM_STORE + the tile's Meyer-Wallach sums -> out[b][tile][kMwFusedRow] (tile_mw_row)
+  TM_MW_ONLY = 6,         // whole-state tiles: the Meyer-Wallach row alone, no state is stored
 };
 
 struct ProfScope {  // records a start/stop event pair around one stage launch
@@ -98,5 +100,14 @@ void launch_expval_final(const float *partial, int n_rows, int batch, int n_obs,
                          float *d_out, hipStream_t stream);
 void launch_probs(const float2 *states, float *d_out, uint64_t total_chunks, hipStream_t stream);
 void launch_density(const float2 *states, float2 *d_out, int n, int batch, hipStream_t stream);
+// Meyer-Wallach behind the pass that produced the state (QMLE_MEAS_MEYER_WALLACH): `last` left one
+// row per tile at the start of `ws` (TM_STORE_MW / TM_MW_ONLY); d_out [batch][n + 1] = (Q, purities by wire)
+bool mw_fusable(int n, const Stage &last);
+size_t mw_fused_ws_bytes(int n, int batch, const Stage &last);
+int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int row_shift, void *ws,
+                 size_t ws_bytes, float *d_out, hipStream_t stream);  // a row covers 2^row_shift tiles
+size_t mw_resident_ws_bytes(int n, int batch);
+int run_mw_resident(const float2 *states, int n, int batch, void *ws, size_t ws_bytes, float *d_out,
+                    hipStream_t stream);
 
 }  // namespace qmle

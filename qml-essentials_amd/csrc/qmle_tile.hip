@@ -43,7 +43,8 @@
 namespace {
 
 // One tile per workgroup: load -> gate groups -> store / measure.
-template <bool DENSE4>
+// MW: a.meas is TM_STORE_MW / TM_MW_ONLY (tile_mw_row behind the store; T >= 10, 2^(T-4) work items)
+template <bool DENSE4, bool MW = false>
 __global__ void k_tile(const TileArgs a) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -77,7 +78,11 @@ __global__ void k_tile(const TileArgs a) {
     // stays exactly zero -- write the zeros (state / probabilities / partial sums), skip the gates
     __syncthreads();
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.meas == TM_STORE) {
+    if (MW) {
+      float *po = reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + tile) * kMwFusedRow;
+      if (tid < kMwFusedRow) po[tid] = 0.f;
+    }
+    if (a.meas == TM_STORE || a.meas == TM_STORE_MW) {
       for (uint32_t jc = tid; jc < half; jc += nt) {
         const uint32_t j = jc * 2u;
         *reinterpret_cast<float4 *>(st + (base | lut[j >> L] | (j & lowmask))) = z;
@@ -88,7 +93,7 @@ __global__ void k_tile(const TileArgs a) {
         const uint32_t j = jc * 2u;
         *reinterpret_cast<float2 *>(po + (base | lut[j >> L] | (j & lowmask))) = make_float2(0.f, 0.f);
       }
-    } else {  // TM_EXPVAL_PARTIAL / TM_EXPVAL_MASKS rows (TM_EXPVAL has a single tile)
+    } else if (!MW) {  // TM_EXPVAL_PARTIAL / TM_EXPVAL_MASKS rows (TM_EXPVAL has a single tile)
       float *po = reinterpret_cast<float *>(a.out) +
                   ((size_t)b * gridDim.x + tile) * (QMLE_MAX_QUBITS + 1);
       if (tid <= QMLE_MAX_QUBITS) po[tid] = 0.f;
@@ -142,7 +147,13 @@ __global__ void k_tile(const TileArgs a) {
   __syncthreads();
 
   tile_compute<DENSE4, false>(a, s, slots, b);
-  tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
+  if (MW) {
+    if (a.meas == TM_STORE_MW) tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);  // (its TM_STORE branch)
+    tile_mw_row(lds_offset_of(s), T, (uint32_t)tid, reinterpret_cast<float *>(s),
+                reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + tile) * kMwFusedRow);
+  } else {
+    tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
+  }
 }
 
 // ---- fast tile kernel (k_tile2) --------------------------------------------------------------
@@ -622,7 +633,10 @@ __device__ __forceinline__ void whole_state_expval(const TileArgs &a, uint32_t s
 // with the TM_STORE / TM_PROBS / TM_EXPVAL_PARTIAL epilogues only.
 // WS: the tile is the whole state (T == n, 10..13 qubits, launch_tile): the group loop keeps its slot
 // addresses in registers and a one-wave workgroup drops its barriers (tile2_groups).
-template <bool NT, bool MEASURE, bool MULTI, bool WS = false>
+// MW (with MEASURE, without MULTI): a.meas is TM_STORE_MW / TM_MW_ONLY -- the tile's Meyer-Wallach
+// row (tile_mw_row) behind the store; its own instantiations, so that the 40 sums it keeps per work item
+// do not enter the register budget of the others.
+template <bool NT, bool MEASURE, bool MULTI, bool WS = false, bool MW = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
@@ -684,7 +698,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   if (!MULTI && (a.init_zero ? base != 0 : (tile & a.zin_outer) != 0)) {
     // |0..0> lives in tile 0 alone and gates are linear: a tile that holds only known zeros
     // (Stage::zero_in) stays exactly zero -- write the zeros, skip the gates
-    if (!MEASURE && a.meas == TM_STORE) {
+    if (MW) {  // a zero tile contributes a zero row (and, TM_STORE_MW, its zeros to the state)
+      if (a.meas == TM_STORE_MW) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), z4);
+      }
+      float *po = reinterpret_cast<float *>(a.out) + ((size_t)b * n_tiles + tile) * kMwFusedRow;
+      if (tid < kMwFusedRow) po[tid] = 0.f;
+    } else if (!MEASURE && a.meas == TM_STORE) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) st4<NT>(reinterpret_cast<float4 *>(st + uoff[u] + goff8), z4);
     } else if (!MEASURE) {
@@ -740,6 +761,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   if (plain) load_tile(st);
   const uint32_t sl_outer = sl;
   float zacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // MEASURE && MULTI: tile_z_accumulate
+  MwAcc macc;                                                 // MW: tile_mw_accumulate
+  if (MW) tile_mw_clear(macc);
   for (int i = 0; i < tpw; ++i) {
     uint32_t sl = sl_outer;  // (opaque per tile: keeps the 8 staging addresses out of loop-carried registers)
     if (MULTI) asm volatile("" : "+v"(sl));
@@ -784,7 +807,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
 
     tile2_groups<WS>(sbo, addr, f, mrow, tid, a.zin_local != 0, WS && nt <= kWave);  // known zeros: Stage::zero_in
 
-    if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
+    if (MW) {
+      if (a.meas == TM_STORE_MW) {
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {  // (two batches of four: the sums of the walk are live)
+          float4 w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = lds_ld128(sl ^ soff[h + u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[h + u] + goff8), w[u]);
+        }
+      }
+      tile_mw_accumulate(sbo, T, (uint32_t)tid, (uint32_t)i, macc);
+    } else if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
     } else if (MEASURE) {
       if (!(f.dbg & 2)) {
@@ -819,7 +854,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
     }
     if (i + 1 < tpw) __syncthreads();  // the tile buffer (and the epilogue's scratch in it) is reused
   }
-  if (MEASURE && MULTI && !(f.dbg & 2))
+  if (MW)  // one row per workgroup (= per tile: launch_tile keeps these stages at one tile per workgroup)
+    tile_mw_finish(macc, T, (uint32_t)tid, reinterpret_cast<float *>(s),
+                   reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + blockIdx.x) * kMwFusedRow);
+  else if (MEASURE && MULTI && !(f.dbg & 2))
     tile_z_finish(reinterpret_cast<float *>(a.out), red, zacc, qsrc, tid, nt, 31 - __builtin_clz((unsigned)tpw),
                   blockIdx.x, gridDim.x, b);
 }
@@ -1531,9 +1569,15 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   if (first_use_on_device(0)) {
     QMLE_LDS_BASE_CHECK(k_tile<false>);
     QMLE_LDS_BASE_CHECK(k_tile<true>);
+    QMLE_LDS_BASE_CHECK((k_tile<false, true>));
+    QMLE_LDS_BASE_CHECK((k_tile<true, true>));
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_tile<false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)k_tile<true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   bool has_dense4 = false;  // 16x16 Kraus superoperators: separate instantiation, so that the
@@ -1682,6 +1726,15 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
 #undef QMLE_T2_LDS
       QMLE_LDS_BASE_CHECK((k_tile2<false, false, false, true>));
       QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, true>));
+      QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, false, true>));
+      QMLE_LDS_BASE_CHECK((k_tile2<true, true, false, false, true>));
+      QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, true, true>));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, false, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, true, false, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, false, true, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, false, false, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, false, true>,
@@ -1736,7 +1789,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     // (default 4 for storing passes, 8 for the measuring pass, whose per-workgroup reduction is
     // then shared by 8 tiles: K2 pass 3 29.2 / 24.5 / 23.8 / 23.6 us per state at 1 / 2 / 4 / 8)
     static const int tpw_env = std::getenv("QMLE_T2_TPW") ? atoi(std::getenv("QMLE_T2_TPW")) : 0;
+    // (Meyer-Wallach rows keep one tile per workgroup: a walk of 4-16 tiles that carries the ~40 sums in
+    // registers and reduces once was built and measured at n = 28 -- 128 VGPRs + 64 B of scratch, no room
+    // for the next tile's prefetch: 792 us for the pass against 678 with a row per tile, 473 without sums)
     const int tpw_max = tpw_env > 0 ? tpw_env : meas == TM_EXPVAL_PARTIAL ? 8 : 4;
+    const uint64_t min_wgs = 5120;
     f.tpw = 1;
     f.tile_stride = 0;
     // (known zeros inside the tile are fine -- the walk's loads skip them; known-zero TILES are not)
@@ -1748,7 +1805,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       while (run0 < p->n - st.T && st.outer_bits[run0] == st.outer_bits[0] + run0) ++run0;
       f.tile_stride = 1u << st.outer_bits[0];
       while (f.tpw * 2 <= tpw_max && f.tpw * 2 <= (1 << run0) && grid.x % 2u == 0 &&
-             (uint64_t)(grid.x / 2u) * grid.y >= 5120) {
+             (uint64_t)(grid.x / 2u) * grid.y >= min_wgs) {
         f.tpw *= 2;
         grid.x /= 2u;
       }
@@ -1777,7 +1834,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   hipLaunchKernelGGL((k_tile2<NT, ME, MU>), grid, dim3(threads), lds2, stream, a, f)
     const bool multi = f.tpw > 1;
     static const bool no_ws = std::getenv("QMLE_NO_WS_KERNEL") != nullptr;  // (A/B: the generic instantiation)
-    if (st.T == p->n && !multi && !a.nt && !no_ws) {  // the whole state in one tile (10..13 qubits)
+    if (meas == TM_STORE_MW || meas == TM_MW_ONLY) {
+      if (st.T == p->n) hipLaunchKernelGGL((k_tile2<false, true, false, true, true>), grid, dim3(threads), lds2, stream, a, f);
+      else if (a.nt) hipLaunchKernelGGL((k_tile2<true, true, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
+      else hipLaunchKernelGGL((k_tile2<false, true, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
+    } else if (st.T == p->n && !multi && !a.nt && !no_ws) {  // the whole state in one tile (10..13 qubits)
       if (measure) hipLaunchKernelGGL((k_tile2<false, true, false, true>), grid, dim3(threads), lds2, stream, a, f);
       else hipLaunchKernelGGL((k_tile2<false, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
     } else if (measure) {
@@ -1791,7 +1852,11 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }
-  if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(threads), lds, stream, a);
+  if (meas == TM_STORE_MW || meas == TM_MW_ONLY) {
+    if (st.T < 10 || threads != (1 << (st.T - 4))) return QMLE_ERR_UNSUPPORTED;  // (callers check mw_fusable)
+    if (has_dense4) hipLaunchKernelGGL((k_tile<true, true>), grid, dim3(threads), lds, stream, a);
+    else hipLaunchKernelGGL((k_tile<false, true>), grid, dim3(threads), lds, stream, a);
+  } else if (has_dense4) hipLaunchKernelGGL(k_tile<true>, grid, dim3(threads), lds, stream, a);
   else hipLaunchKernelGGL(k_tile<false>, grid, dim3(threads), lds, stream, a);
   HIPCHK(hipGetLastError());
   return QMLE_OK;

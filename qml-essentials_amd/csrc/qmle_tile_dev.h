@@ -368,7 +368,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
   const uint32_t half = 1u << (T - 1);
   const uint32_t lowmask = (1u << L) - 1u;
   float2 *st = a.states + (size_t)b * D;
-  if (!PARTIAL_ONLY && a.meas == TM_STORE) {
+  if (!PARTIAL_ONLY && (a.meas == TM_STORE || a.meas == TM_STORE_MW)) {
     if ((half % (8u * nt)) == 0) {
       for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
         float4 v[8];
@@ -584,6 +584,131 @@ __device__ __forceinline__ void reg_apply_group(float2 (&v)[16], const OpGroup &
     else if (op.flags & LF_DIAG) reg_dispatch<1>(v, m, cb, op.t0);
     else reg_dispatch<0>(v, m, cb, op.t0);
   }
+}
+
+// ---- Meyer-Wallach sums out of a finished tile (TM_STORE_MW / TM_MW_ONLY) --------------------
+// The pass that produces the state has its 2^T amplitudes in LDS anyway: instead of re-reading them
+// from HBM (the stand-alone first read of qmle_meyer_wallach), it reports what Tr rho_j^2 needs from
+// this tile -- for every tile-local bit j the cross term c_j = sum_{bit_j = 0} psi_e conj(psi_{e + 2^j})
+// and the signed population sum_e (-1)^{bit_j(e)} |psi_e|^2, plus the tile's total, from which the
+// populations of every OUTER position follow (sign of a tile = a bit of its index).  One row of
+// kMwFusedRow floats per tile (layout: tile_mw_finish_t).
+// Work items: nt = 2^(T-4), 16 amplitudes per register gather, (T + 3) / 4 gathers over 4 local bits
+// each (the last one overlaps its predecessor when T is not a multiple of 4); the populations come
+// from the first gather (bits 0..3 in registers, bit j >= 4 = bit j - 4 of the thread index).
+constexpr int kMwFusedRow = 48;
+
+// the sums a work item carries across the tiles its workgroup walks (indexed with literals only)
+struct MwAcc {
+  v2f cr[14];
+  float h0, h1, h2, h3, tot;
+  float zw[4];  // the total signed by bit k of the tile's index inside the walk
+};
+__device__ __forceinline__ void tile_mw_clear(MwAcc &m) {
+  static_for<14>([&](auto j) { m.cr[j] = (v2f){0.f, 0.f}; });
+  m.h0 = m.h1 = m.h2 = m.h3 = m.tot = 0.f;
+  static_for<4>([&](auto k) { m.zw[k] = 0.f; });
+}
+
+// one tile (in LDS, identity layout) into the work item's sums; `it` = index of the tile in the walk
+template <int T>
+__device__ __forceinline__ void tile_mw_accumulate_t(uint32_t sbo, uint32_t tid, uint32_t it, MwAcc &m) {
+  static_assert(T >= 10 && T <= 14, "16 amplitudes per work item, at most 1024 work items");
+  constexpr int G = (T + 3) / 4;
+  uint32_t tg = tid;
+  asm volatile("" : "+v"(tg));  // (the gather addresses are not worth keeping across the gate loop)
+  static_for<G>([&](auto k) {
+    constexpr int B = (4 * (int)k <= T - 4) ? 4 * (int)k : T - 4;
+    constexpr int first_new = 4 * (int)k - B;  // bits [B, B + first_new) were reported by the previous gather
+    const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, B), B + 1), B + 2), B + 3)) << 3) + sbo;
+    v2f r[16];
+    static_for<16>([&](auto c) {
+      const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << B) << 3));
+      r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+    });
+    static_for<4>([&](auto t) {
+      if constexpr ((int)t >= first_new) {
+        static_for<8>([&](auto pq) {
+          constexpr int lowm = (1 << t) - 1;
+          constexpr int c = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+          mw_cross(m.cr[B + (int)t], r[c], r[c | (1 << t)]);
+        });
+      }
+    });
+    if constexpr ((int)k == 0) {  // populations: pruned Walsh-Hadamard butterfly over the four register bits
+      float pr[16], s1[8], s2[4], s3[2], h0 = 0.f, h1 = 0.f, h2 = 0.f;
+      static_for<16>([&](auto c) { const v2f q = r[c] * r[c]; pr[c] = q.x + q.y; });
+      static_for<8>([&](auto i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; });
+      static_for<4>([&](auto i) { s2[i] = s1[2 * i] + s1[2 * i + 1]; h1 += s1[2 * i] - s1[2 * i + 1]; });
+      static_for<2>([&](auto i) { s3[i] = s2[2 * i] + s2[2 * i + 1]; h2 += s2[2 * i] - s2[2 * i + 1]; });
+      const float tt = s3[0] + s3[1];
+      m.h0 += h0; m.h1 += h1; m.h2 += h2; m.h3 += s3[0] - s3[1];
+      m.tot += tt;
+      static_for<4>([&](auto b) { m.zw[b] += __uint_as_float(__float_as_uint(tt) ^ (((it >> b) & 1u) << 31)); });
+    }
+  });
+}
+// one reduction and one row per workgroup: [0, 2T) cross terms, [2T, 3T) signed populations of the
+// local bits, [3T] total, [3T + 1 + k] total signed by walk bit k.  `red`: LDS scratch (may be the tile:
+// the first barrier below makes sure every gather has read it).  (One row per WAVE straight from lane 63
+// -- no barrier, no scratch -- was measured too: the pass no faster, 8 x the rows for the purity kernel.)
+template <int T>
+__device__ __forceinline__ void tile_mw_finish_t(const MwAcc &m, uint32_t tid, float *red, float *row_out) {
+  constexpr int NV = 2 * T + 15, NW = 1 << (T - 10);
+  float v[NV];
+  static_for<T>([&](auto j) { v[2 * j] = m.cr[j].x; v[2 * j + 1] = m.cr[j].y; });
+  v[2 * T] = m.h0; v[2 * T + 1] = m.h1; v[2 * T + 2] = m.h2; v[2 * T + 3] = m.h3; v[2 * T + 4] = m.tot;
+  static_for<6>([&](auto b) { v[2 * T + 5 + b] = ((tid >> b) & 1u) ? -m.tot : m.tot; });
+  static_for<4>([&](auto k) { v[2 * T + 11 + k] = m.zw[k]; });
+  wave_sums_dpp63(v);
+  __syncthreads();  // every gather (and the store before it) has read the tile: it becomes scratch
+  const uint32_t lane = tid & (kWave - 1), w = tid / kWave;
+  if (lane == kWave - 1) static_for<NV>([&](auto i) { red[w * NV + i] = v[i]; });
+  __syncthreads();
+  if (tid < 3u * T + 5u) {
+    // column of the per-wave sums this row entry reads, or (local bits >= 10) the totals signed by a wave-index bit
+    int col, wbit = -1;
+    if (tid < 2u * T + 4u) col = (int)tid;                 // cross terms, populations of bits 0..3
+    else if (tid < 3u * T) {
+      const int j = (int)tid - 2 * T;                      // local bit j >= 4 = thread-index bit j - 4
+      if (j - 4 < 6) col = 2 * T + 5 + (j - 4);
+      else { col = 2 * T + 4; wbit = j - 10; }
+    } else if (tid == 3u * T) col = 2 * T + 4;             // the total
+    else col = 2 * T + 11 + ((int)tid - 3 * T - 1);        // walk-bit signed totals
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float x = red[i * NV + col];
+      s += (wbit >= 0 && ((i >> wbit) & 1)) ? -x : x;
+    }
+    row_out[tid] = s;
+  }
+}
+// (T is wave-uniform: a kernel argument)
+__device__ __forceinline__ void tile_mw_accumulate(uint32_t sbo, int T, uint32_t tid, uint32_t it, MwAcc &m) {
+  switch (T) {
+    case 10: tile_mw_accumulate_t<10>(sbo, tid, it, m); break;
+    case 11: tile_mw_accumulate_t<11>(sbo, tid, it, m); break;
+    case 12: tile_mw_accumulate_t<12>(sbo, tid, it, m); break;
+    case 13: tile_mw_accumulate_t<13>(sbo, tid, it, m); break;
+    default: tile_mw_accumulate_t<14>(sbo, tid, it, m); break;
+  }
+}
+__device__ __forceinline__ void tile_mw_finish(const MwAcc &m, int T, uint32_t tid, float *red, float *row_out) {
+  switch (T) {
+    case 10: tile_mw_finish_t<10>(m, tid, red, row_out); break;
+    case 11: tile_mw_finish_t<11>(m, tid, red, row_out); break;
+    case 12: tile_mw_finish_t<12>(m, tid, red, row_out); break;
+    case 13: tile_mw_finish_t<13>(m, tid, red, row_out); break;
+    default: tile_mw_finish_t<14>(m, tid, red, row_out); break;
+  }
+}
+// one tile, one row
+__device__ __forceinline__ void tile_mw_row(uint32_t sbo, int T, uint32_t tid, float *red, float *row_out) {
+  MwAcc m;
+  tile_mw_clear(m);
+  tile_mw_accumulate(sbo, T, tid, 0u, m);
+  tile_mw_finish(m, T, tid, red, row_out);
 }
 
 // Host side: the kernel arguments of stage `st` (positions, known-zero masks, <Z> row sources).

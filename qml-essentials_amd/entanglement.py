@@ -45,6 +45,7 @@ class Entanglement:
             n_samples = (2**model.n_qubits) * n_samples
         kwargs.setdefault("inputs", None)
         kwargs.pop("execution_type", None)
+        torch = N.require_gpu()
         if n_samples is not None and n_samples > 0:
             # (the compiled call is resolved before the sampler is launched: expressibility.py)
             prep = None
@@ -53,9 +54,10 @@ class Entanglement:
             random_key = model.initialize_params(random_key, repeat=int(n_samples))
             if prep is not None and model.device_params() is not None:
                 cc, divs, mods, B = prep
-                ent = cls._compute_meyer_wallach_meas(cc.run([model.device_params()], divs, mods, B, 0),
-                                                      model.n_qubits)
-                return float(ent.mean(dtype=N.require_gpu().float64))
+                # Meyer-Wallach out of the pass that produces the state (QMLE_MEAS_MEYER_WALLACH): for
+                # n <= 14 no statevector is ever stored, above the first of the three reads is saved
+                out = cc.run([model.device_params()], divs, mods, B, 0, meas="mw")
+                return float(out[:, 0].mean(dtype=torch.float64))
         # sampled parameters stay on the GPU (the reference's are jax device arrays,
         # entanglement.py:52-60); small draws / user-set parameters are host arrays
         params = model.device_params()
@@ -63,18 +65,47 @@ class Entanglement:
             params = np.asarray(model.params)
         total = params.shape[0]
         lo, hi, sharded = distributed.my_block(total, params, kwargs.get("inputs"))
-        with distributed.local_only():
-            states = model._forward(params=params[lo:hi] if sharded else params,
-                                    execution_type="state", as_tensor=True, **kwargs)
+        local = params[lo:hi] if sharded else params
+        ent = cls._fused_meyer_wallach(model, local, kwargs)
+        if ent is None:  # noisy / shot / complex128 models: states first, then the stand-alone kernels
+            with distributed.local_only():
+                states = model._forward(params=local, execution_type="state", as_tensor=True, **kwargs)
+            ent = cls._compute_meyer_wallach_meas(states, model.n_qubits)
         model.params = params
-        ent = cls._compute_meyer_wallach_meas(states, model.n_qubits)
         if sharded:
             b_i = model.batch_shape[0]
             ent = distributed.all_gather_rows(ent.reshape(b_i, -1).transpose(0, 1).contiguous(),
                                               total)
         if log.isEnabledFor(logging.DEBUG):  # (a variance costs a reduction and a device -> host sync)
             log.debug("Variance of measure: %s", float(ent.var()) if ent.numel() > 1 else 0.0)
-        return float(ent.mean(dtype=N.require_gpu().float64))  # one reduction, one sync
+        return float(ent.mean(dtype=torch.float64))  # one reduction, one sync
+
+    @staticmethod
+    def _fused_meyer_wallach(model: Model, params, kwargs):
+        """Q per sample through ``QMLE_MEAS_MEYER_WALLACH`` (the circuit's last pass reports the sums
+        of its own tile; no first read of the state).  None when the model has no compiled device
+        call (noise, shots, complex128 mode, non-affine angles): the caller takes the state route."""
+        from .utils import _gpu_present, x64_enabled
+
+        if not model.host_arrays_via_device or not _gpu_present():
+            return None
+        if set(kwargs) - {"inputs", "enc_params"} or model.noise_params is not None \
+                or model.shots is not None or (x64_enabled() if model.x64 is None else model.x64):
+            return None
+        torch = N.require_gpu()
+        if not hasattr(params, "is_cuda"):
+            params = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float32)).cuda()
+        inputs = kwargs.get("inputs")
+        if inputs is not None and not hasattr(inputs, "is_cuda"):
+            x = np.asarray(inputs, dtype=np.float32)
+            inputs = torch.from_numpy(np.ascontiguousarray(x.reshape(-1, model.n_input_feat))).cuda()
+        with distributed.local_only():
+            got = model._forward_device(params, inputs, kwargs.get("enc_params"), "state", False,
+                                        _want_call=True)
+        if got is NotImplemented:
+            return None
+        cc, leaves, divs, mods, B = got
+        return cc.run(leaves, divs, mods, B, 0, meas="mw")[:, 0]
 
     @classmethod
     def _compute_meyer_wallach_meas(cls, states, n_qubits: int):

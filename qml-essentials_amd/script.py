@@ -92,8 +92,10 @@ class CompiledCall:
         self._leaf_sizes = {order[k]: int(np.prod(np.shape(args[k]))) for k in leaf_ids}
         self._adj = None
 
-    def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0):
-        """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order."""
+    def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0, meas: Optional[str] = None):
+        """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order.  ``meas``
+        overrides the call's measurement with another one of the same circuit ("mw": Meyer-Wallach
+        out of the producing pass, for a call compiled for "state")."""
         strides = [t[0].numel() if t.shape[0] else 0 for t in leaves]
         angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
                                 self.d_coef, self.d_const, self.n_slots, batch, batch_offset,
@@ -101,6 +103,8 @@ class CompiledCall:
         if self.n_slots == 0:
             import torch
             angles = torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device)
+        if meas is not None and meas != self.type:
+            return self.plan.run(angles, meas)
         if self.type == "expval":
             kind, arg = self._measure()
             if kind == "z":

@@ -284,6 +284,57 @@ def test_meyer_wallach_lds_tile_path(n):
     assert np.abs(q.cpu().numpy() - want_q).max() < 2e-6
 
 
+@pytest.mark.parametrize("n", [3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_meyer_wallach_out_of_the_producing_pass(n, monkeypatch):
+    """QMLE_MEAS_MEYER_WALLACH: the plan's last tile pass reports its own tile's sums from LDS
+    (tile_mw_row), the remaining positions come from later reads -- every wire's purity against the
+    oracle's purities of the state the SAME plan stores (the state path has its own oracle tests), for
+    Hardware-Efficient layers (fast tile kernel) and random tapes with controlled rotations / two-qubit
+    Pauli rotations (generic tile kernel, streaming last stages that cannot be fused), with and
+    without known-zero tracking, whole-state regime (n <= 14: no state is stored) and tiled."""
+    from qml_essentials_amd import _native as N
+    from tests.helpers import random_tape, tape_to_native
+    from tests.test_abi_cpu import he_layer_ops
+
+    # (tiled states take the stand-alone reads by default -- the fused epilogue costs a tiled pass what
+    # the saved read costs, DESIGN 9d; the fused tiled path stays in the library behind this switch)
+    monkeypatch.setenv("QMLE_MW_FUSE_TILED", "1")
+    rng = np.random.default_rng(100 + n)
+    B = 3 if n <= 16 else 1
+    cases = []
+    for layers in (1, 2):
+        ops, slots = [], 0
+        for _ in range(layers):
+            o, sl = he_layer_ops(n) if n >= 3 else ([], 0)
+            ops += [(g, w, [x + slots for x in k], m) for g, w, k, m in o]
+            slots += sl
+        cases.append(("he%d" % layers, ops, slots, None))
+    tape = random_tape(n, 3 * n, rng, three_q=n <= 12)
+    r_ops, r_values, r_consts = tape_to_native(tape, n)
+    cases.append(("random", r_ops, len(r_values), (r_consts, r_values)))
+    for name, ops, slots, extra in cases:
+        for flags in (0, N.PLAN_NO_SPARSE):
+            consts = extra[0] if extra else None
+            plan = N.Plan(ops, n, slots, consts=consts, flags=flags)
+            if extra:
+                ang = torch.from_numpy(np.tile(np.asarray(extra[1], dtype=np.float32), (B, 1))).cuda()
+                ang = ang + torch.from_numpy(rng.uniform(0, 0.5, ang.shape).astype(np.float32)).cuda()
+            else:
+                ang = torch.from_numpy(rng.uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
+            got = plan.run(ang, "mw").cpu().numpy()
+            assert got.shape == (B, n + 1)
+            st = plan.run(ang, "state").cpu().numpy().astype(np.complex128)
+            want_p = np.stack([OA.qubit_purities_pure(v, n) for v in st])
+            want_q = 2 * (1 - want_p.mean(axis=1))
+            assert np.abs(got[:, 1:] - want_p).max() < 2e-6, (name, flags, np.abs(got[:, 1:] - want_p).max())
+            assert np.abs(got[:, 0] - want_q).max() < 2e-6, (name, flags)
+            if n > 14:  # the default route (stand-alone reads of the stored state): the same numbers
+                monkeypatch.delenv("QMLE_MW_FUSE_TILED")
+                dflt = plan.run(ang, "mw").cpu().numpy()
+                monkeypatch.setenv("QMLE_MW_FUSE_TILED", "1")
+                assert np.abs(dflt - got).max() < 2e-6, (name, flags)
+
+
 def test_dense_4wire_operator_and_density_measurements():
     """QMLE_OP_MAT4 (16x16 on 4 wires, any wire order) against the dense oracle, in the
     whole-state and the tiled regime; diag / <Z> of a vectorised density matrix."""
