@@ -61,7 +61,7 @@ def test_n28_single_gates_streaming_path_closed_form_and_tile_path():
     base = _product_state(n, theta)
     assert base.shape == (1, 1 << n)
     ez = N.expval_z(base, list(range(n))).cpu().numpy()[0]
-    assert np.abs(ez - c).max() < 2e-6  # the product state itself, every wire
+    assert np.abs(ez - c).max() < 1e-6  # the product state itself, every wire
     phi, alpha = 0.9, 1.7
     for w in (0, 1, 13, 26, 27):
         c2 = (w + 1) % n  # control wire of the two-qubit kinds (control = target + 1)
@@ -88,7 +88,7 @@ def test_n28_single_gates_streaming_path_closed_form_and_tile_path():
             want = c.copy()
             for q, v in expect.items():
                 want[q] = v
-            assert np.abs(got - want).max() < 3e-6, (kind, w, np.abs(got - want).max())
+            assert np.abs(got - want).max() < 1e-6, (kind, w, np.abs(got - want).max())
             # the LDS-tile path on the same input: same amplitudes to rounding
             st2 = base.clone()
             for g, wires, ang in gates:
@@ -122,24 +122,27 @@ def test_n28_meyer_wallach_product_ghz_and_he_layer():
         pytest.skip("needs ~8 GiB of free HBM")
     st = _product_state(n, np.random.default_rng(5).uniform(0, 6.28, n))
     q, pur = N.meyer_wallach(st, return_purities=True)
-    assert abs(float(q[0])) < 1e-4 and float((pur - 1).abs().max()) < 1e-4
+    # (2e-6: the float32 product state's own norm is off by 2.5e-7 -- 28 rounded factors per amplitude --
+    # and a purity is quadratic in it; the reductions themselves agree with float64 sums of the same
+    # state to 4e-8, tools/accum_probe.py)
+    assert abs(float(q[0])) < 2e-6 and float((pur - 1).abs().max()) < 2e-6
     del st
     ghz = N.Plan([("H", [0], [], -1)] + [("CX", [k, k + 1], [], -1) for k in range(n - 1)], n, 0)
     st = ghz.run(None, "state")
     q, pur = N.meyer_wallach(st, return_purities=True)
-    assert abs(float(q[0]) - 1) < 1e-5 and float((pur - 0.5).abs().max()) < 1e-5
+    assert abs(float(q[0]) - 1) < 1e-6 and float((pur - 0.5).abs().max()) < 1e-6
     del st
     from tests.test_abi_cpu import he_layer_ops
     ops, slots = he_layer_ops(n)
     ang = torch.from_numpy(np.random.default_rng(6).uniform(0, 6.28, (1, slots)).astype(np.float32)).cuda()
     st = N.Plan(ops, n, slots).run(ang, "state")
-    assert abs(float((st.abs() ** 2).sum()) - 1) < 1e-4
+    assert abs(float((st.abs() ** 2).sum()) - 1) < 1e-6
     q, pur = N.meyer_wallach(st, return_purities=True)
     pur = pur.cpu().numpy()[0]
     for j in (0, 13, 27):
         x, y, z = _xyz_of_wire(st, n, j)
-        assert abs(pur[j] - (1 + x * x + y * y + z * z) / 2) < 2e-5, (j, pur[j], x, y, z)
-    assert abs(float(q[0]) - 2 * (1 - pur.mean())) < 1e-5
+        assert abs(pur[j] - (1 + x * x + y * y + z * z) / 2) < 2e-6, (j, pur[j], x, y, z)  # (three float32 states' <Z>)
+    assert abs(float(q[0]) - 2 * (1 - pur.mean())) < 1e-6
     del st
     torch.cuda.empty_cache()
 
@@ -163,7 +166,7 @@ def test_k2_one_gib_launch_default_vs_all_live_vs_c_port():
     assert all(s["fast"] for s in dense.describe()["stages"])
     e_live = dense.run(ang, "expval", obs).cpu().numpy()
     e_fold = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE).run(ang, "expval", obs).cpu().numpy()
-    assert np.abs(e_def - e_live).max() < 2e-6 and np.abs(e_fold - e_live).max() < 2e-6
+    assert np.abs(e_def - e_live).max() < 1e-6 and np.abs(e_fold - e_live).max() < 1e-6
     # the state itself, all-live vs default engine
     s_live = dense.run(ang[:2], "state")
     s_def = N.Plan(ops, n, slots).run(ang[:2], "state")
@@ -176,7 +179,7 @@ def test_k2_one_gib_launch_default_vs_all_live_vs_c_port():
             tape.append((name, wires, tuple(float(ang_h[b, s]) for s in sl)))
         psi = c_port.simulate(tape, n)
         ez = c_port.expval_z(psi, n, obs)
-        assert np.abs(ez - e_live[b]).max() < 2e-6, (b, np.abs(ez - e_live[b]).max())
+        assert np.abs(ez - e_live[b]).max() < 1e-6, (b, np.abs(ez - e_live[b]).max())
 
 
 def test_multi_tile_workgroups_state_and_probs_vs_c_port():
@@ -289,21 +292,21 @@ def test_fast_tile_kernel_equals_generic_kernel_on_cx_rich_tapes():
             a = fast.run(ang, meas, list(range(n)) if meas == "expval" else ())
             b = slow.run(ang, meas, list(range(n)) if meas == "expval" else ())
             assert float((torch.view_as_real(a) if a.is_complex() else a).sub(
-                torch.view_as_real(b) if b.is_complex() else b).abs().max()) < 2e-6, (trial, meas)
+                torch.view_as_real(b) if b.is_complex() else b).abs().max()) < 1e-6, (trial, meas)
         got = fast.run(ang, "state").cpu().numpy()[0]
-        assert np.abs(got - want).max() < 2e-6, (trial, np.abs(got - want).max())
+        assert np.abs(got - want).max() < 1e-6, (trial, np.abs(got - want).max())
         # the same kernel with known-zero tracking on (partial loads, zero tiles, compacted grids,
         # idle work items): default engine against the oracle, state and <Z>
         geo = N.plan_flags(tile_bits=T, low_bits=L)
         for extra in (0, N.PLAN_NO_ABSORB):
             sp = N.Plan(ops, n, max(1, len(angles)), consts, geo | extra)
             got = sp.run(ang, "state").cpu().numpy()[0]
-            assert np.abs(got - want).max() < 2e-6, (trial, extra, np.abs(got - want).max())
+            assert np.abs(got - want).max() < 1e-6, (trial, extra, np.abs(got - want).max())
             ez = sp.run(ang, "expval", list(range(n))).cpu().numpy()[0]
             p = np.abs(want) ** 2
             idx = np.arange(1 << n)
             wz = np.array([np.sum(p * (1 - 2 * ((idx >> (n - 1 - q)) & 1))) for q in range(n)])
-            assert np.abs(ez - wz).max() < 2e-6, (trial, extra, np.abs(ez - wz).max())
+            assert np.abs(ez - wz).max() < 1e-6, (trial, extra, np.abs(ez - wz).max())
 
 
 def test_n29_falls_back_to_64_bit_addressing():
@@ -319,15 +322,15 @@ def test_n29_falls_back_to_64_bit_addressing():
     theta = np.random.default_rng(29).uniform(0.2, 2.9, n)
     st = _product_state(n, theta)
     ez = N.expval_z(st, list(range(n))).cpu().numpy()[0]
-    assert np.abs(ez - np.cos(theta)).max() < 3e-6
+    assert np.abs(ez - np.cos(theta)).max() < 1e-6
     q = N.meyer_wallach(st)
-    assert abs(float(q[0])) < 2e-4
+    assert abs(float(q[0])) < 2e-6
     # one gate on the top and on the bottom wire through the streaming kernel
     _apply(st, n, "RX", [0], 0.7)
     _apply(st, n, "RX", [n - 1], 0.4)
     ez = N.expval_z(st, [0, n - 1]).cpu().numpy()[0]
-    assert abs(ez[0] - np.cos(theta[0]) * np.cos(0.7)) < 3e-6
-    assert abs(ez[1] - np.cos(theta[n - 1]) * np.cos(0.4)) < 3e-6
+    assert abs(ez[0] - np.cos(theta[0]) * np.cos(0.7)) < 1e-6
+    assert abs(ez[1] - np.cos(theta[n - 1]) * np.cos(0.4)) < 1e-6
     del st
     torch.cuda.empty_cache()
 
@@ -356,7 +359,10 @@ def test_registers_beyond_28_qubits(n):
     from qml_essentials_amd import _native as N
 
     rng = np.random.default_rng(n)
-    tol = 2e-6 if n <= 30 else 4e-6  # (float32 sums over 2^32 amplitudes)
+    # 1.5e-6: the float32 STATE, not the sums -- every amplitude is a product of n rounded factors (measured
+    # 1.0e-6 at n = 29, 1.25e-6 at n = 32); the reductions agree with float64 sums of the same float32
+    # amplitudes to 7e-8 at n = 28 (tools/accum_probe.py): block partials in fp32 over <= 512 terms, fp64 above
+    tol = 1.5e-6
     th = rng.uniform(0, np.pi, n).astype(np.float32)
     th[[0, n - 2]], th[[1, n - 1]] = np.pi / 2, np.pi / 3
     ops = [("RY", [q], [q], -1) for q in range(n)] + [("CX", [0, 1], [], -1), ("CX", [n - 2, n - 1], [], -1),
@@ -369,7 +375,7 @@ def test_registers_beyond_28_qubits(n):
         z = N.Plan(ops, n, n + 2, flags=flags).run(ang, "expval", list(range(n))).cpu().numpy()[0]
         assert np.abs(z - want).max() < tol, flags
     st = N.Plan(ops, n, n + 2).run(ang, "state")
-    assert abs(float((st.abs() ** 2).sum()) - 1.0) < 1e-5
+    assert abs(float((st.abs() ** 2).sum()) - 1.0) < 2e-6  # (the norm of a float32 state after n + 4 rounded gates: 1.0e-6 .. 1.3e-6)
     assert np.abs(N.expval_z(st, list(range(n))).cpu().numpy()[0] - want).max() < tol
     q, pur = N.meyer_wallach(st, return_purities=True)
     pur = pur.cpu().numpy()[0].astype(np.float64)
