@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 145 /* 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 146 /* 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -160,6 +160,20 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
                      const float *consts, int n_consts, unsigned flags,
                      qmle_plan **out);
 int qmle_plan_destroy(qmle_plan *plan);
+/* Opt-in plan autotuner (the default schedule is the pass-cost model's choice, deterministically).
+ * Times the model's best `top_k` schedule candidates (x both paddings of the last stage) for THIS
+ * measurement and batch size on the current device -- `reps` runs each, zero angles, its own scratch
+ * (hipMalloc'ed and freed inside: a one-off step, not part of a hot loop) -- and re-schedules the plan
+ * that qmle_run_batch executes to the fastest (it must win by 1 %).  Candidates are the same tape under
+ * another tile geometry / order of commuting gates: results agree to float32 rounding.  meas_type:
+ * QMLE_MEAS_STATE or QMLE_MEAS_EXPVAL_Z.  chosen[2] (optional) <- candidate index, padding; ms_before /
+ * ms_after (optional) <- per-call times of the old and the new schedule.  Plans with a single schedule
+ * (whole state in LDS, forced geometry, QMLE_PLAN_NO_FUSION) return QMLE_OK untouched.  A choice is
+ * remembered per (tape, flags, measurement, device) for the life of the process.  Callers that cached
+ * qmle_workspace_bytes must ask again afterwards. */
+int qmle_plan_autotune(qmle_plan *plan, int meas_type, int n_obs, int batch, int top_k, int reps,
+                       qmle_stream stream, int32_t *chosen, double *ms_before, double *ms_after);
+
 /* The plan QMLE_MEAS_EXPVAL_Z actually executes: trailing gates that permute basis states
  * linearly (CX, SWAP) or are diagonal are folded into the Z observables (Z_t -> Z_c Z_t),
  * the remaining gates form this child plan (owned by `plan`; NULL if nothing was folded).

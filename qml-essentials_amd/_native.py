@@ -85,6 +85,17 @@ class QmleOp(C.Structure):
 
 _lib = None
 
+# Opt-in plan autotuner (QMLE_AUTOTUNE=1 or set_autotune(True)): a plan's first "state" / "expval" run on
+# the GPU times the cost model's best schedules for that batch size and keeps the fastest
+# (Plan.autotune / qmle_plan_autotune).  Off by default: the default schedule is deterministic.
+_AUTOTUNE = os.environ.get("QMLE_AUTOTUNE", "0") not in ("", "0")
+
+
+def set_autotune(on: bool = True) -> None:
+    global _AUTOTUNE
+    _AUTOTUNE = bool(on)
+
+
 # every symbol include/qmle_sv.h declares: (name, restype, argtypes)
 _VP, _I, _SZ, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 SYMBOLS = [
@@ -97,6 +108,8 @@ SYMBOLS = [
     ("qmle_plan_expval_child", _VP, [_VP]),
     ("qmle_plan_describe", _I, [_VP, C.c_char_p, _SZ]),
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
+    ("qmle_plan_autotune", _I, [_VP, _I, _I, _I, _I, _I, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
     ("qmle_workspace_bytes", _SZ, [_VP, _I, _I, _I, _I]),
     ("qmle_run_batch", _I, [_VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_run_batch_parity", _I, [_VP, _VP, _I, C.POINTER(C.c_uint32), _I, _VP, _VP, _SZ, _VP]),
@@ -299,6 +312,20 @@ class Plan:
                 "direct_passes", "n_lowered", "algo_bytes_per_state"]
         return dict(zip(keys, [int(v) for v in arr]))
 
+    def autotune(self, meas: str, n_obs: int = 0, batch: int = 32, top_k: int = 4, reps: int = 3) -> dict:
+        """Opt-in (``qmle_plan_autotune``): time the cost model's best ``top_k`` schedules for this
+        measurement ("state" / "expval") and batch size on the current GPU and keep the fastest.
+        -> ``{"candidate", "padding", "ms_before", "ms_after"}`` (candidate -1: nothing to tune)."""
+        require_gpu()
+        chosen = (C.c_int32 * 2)(-1, -1)
+        before, after = C.c_double(0.0), C.c_double(0.0)
+        check(lib().qmle_plan_autotune(self._h, MEAS[meas], int(n_obs), int(batch), int(top_k), int(reps),
+                                       _stream_ptr(), chosen, C.byref(before), C.byref(after)),
+              "qmle_plan_autotune")
+        self.__dict__.pop("_wsb", None)  # the schedule may have changed: workspace sizes are asked for again
+        return {"candidate": int(chosen[0]), "padding": int(chosen[1]), "ms_before": before.value,
+                "ms_after": after.value}
+
     def profile_begin(self, capacity: int) -> None:
         check(lib().qmle_profile_begin(self._h, int(capacity)), "qmle_profile_begin")
 
@@ -373,6 +400,12 @@ class Plan:
                 out = torch.empty((B, self.n_qubits + 1), dtype=torch.float32, device=dev)
             else:
                 out = torch.empty((B, D, D), dtype=torch.complex64, device=dev)
+        if _AUTOTUNE and meas in ("state", "expval"):
+            tuned = self.__dict__.setdefault("_tuned", set())
+            if meas not in tuned:
+                tuned.add(meas)
+                self.autotune(meas, n_obs, batch=B)
+                workspace = None  # (sized for the old schedule)
         workspace = self._workspace(B, meas, n_obs, states_in_flight, workspace, dev)
         rc = lib().qmle_run_batch(
             self._h, C.c_void_p(angles.data_ptr()), B, MEAS[meas], _i32(obs_wires), n_obs,

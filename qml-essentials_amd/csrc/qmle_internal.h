@@ -176,6 +176,12 @@ struct qmle_plan {
   int fold_groups = 0;                    // most gate groups of any Stage::product_ok stage
   double model_cost = 0.0;                // pass-cost model of the chosen schedule (us per state at n = 24 scale)
   int chosen_candidate = -1;              // index of the schedule candidate the model picked (compile_plan)
+  // plan autotuner (qmle_plan_autotune): a forced candidate / last-stage padding for this compile (-1: the
+  // cost model resp. the QMLE_FORCE_CAND / QMLE_PAD_HIGH tuning switches), and every allowed candidate with
+  // its model cost, cheapest first
+  int force_candidate = -1, pad_high = -1;
+  std::vector<std::pair<double, int>> cand_ranking;
+  bool autotuned = false;
   // The same tape compiled for runs from |0..0> only (qmle_run_batch): its first stage may stage a
   // wider tile (it computes one tile per state whatever the size).  Owned; used by run_batch_masks
   // in place of this plan; qmle_apply_inplace / the adjoint sweep keep using this plan's stages.

@@ -860,7 +860,8 @@ int compile_plan(qmle_plan *p) {
         st.kind = ST_TILE;
         // pad the tile with the lowest free bit positions
         // (tuning: QMLE_PAD_HIGH=1 pads the LAST stage from the top instead)
-        const int pad_high_env = std::getenv("QMLE_PAD_HIGH") ? atoi(std::getenv("QMLE_PAD_HIGH")) : 0;
+        const int pad_high_env = p->pad_high >= 0 ? p->pad_high
+                                 : std::getenv("QMLE_PAD_HIGH") ? atoi(std::getenv("QMLE_PAD_HIGH")) : 0;
         if (pad_high_env && !p->stages.empty() && n_done + members.size() == nl) {
           if (carry >= stageL && carry < n && (Q & bit(carry))) {  // the carried position serves read+write passes
             uint64_t need = 0;
@@ -1054,15 +1055,19 @@ int compile_plan(qmle_plan *p) {
       if (v >= 2 && (no_carry || cand[g][1] != 4 || n < 16)) return false;
       return true;
     };
+    p->cand_ranking.clear();
     for (int k = 0; k < 48; ++k) {
       if (!allowed(k)) continue;
       run_cand(k);
       const double c = cost();
+      p->cand_ranking.push_back({c, k});
       // (the round-3 variants must win by 2 %: the model knows their effect from two circuits)
       if (c < best_cost * (k >= 12 && best < 12 ? 0.98 : 1.0) - 1e-9) { best_cost = c; best = k; }
     }
     // (tuning only: force one of the candidates to measure it against the model's choice)
-    const int force = std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;  // (read per compile: tools/cand_sweep.py)
+    std::sort(p->cand_ranking.begin(), p->cand_ranking.end());
+    const int force = p->force_candidate >= 0 ? p->force_candidate
+                      : std::getenv("QMLE_FORCE_CAND") ? atoi(std::getenv("QMLE_FORCE_CAND")) : -1;  // (read per compile: tools/cand_sweep.py)
     if (force >= 0 && force < 48 && cand[force % 6][0] < n && (force < 12 || zero_run)) best = force;
     run_cand(best);
     p->chosen_candidate = best;
@@ -1133,6 +1138,7 @@ std::string describe_plan(const qmle_plan *p) {
      << ",\"n_lowered\":" << p->lowered.size()
      << ",\"whole_state_lds\":" << (p->whole_state_lds ? "true" : "false")
      << ",\"model_cost\":" << p->model_cost << ",\"candidate\":" << p->chosen_candidate
+     << ",\"autotuned\":" << (p->autotuned ? "true" : "false")
      << ",\"zero_run\":" << ((p->flags & QMLE_PLAN_INTERNAL_ZERO_RUN) ? "true" : "false") << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
      << ",\"mat_floats\":" << p->mat_floats
      << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state

@@ -335,6 +335,43 @@ def test_meyer_wallach_out_of_the_producing_pass(n, monkeypatch):
                 assert np.abs(dflt - got).max() < 1e-6, (name, flags)
 
 
+@pytest.mark.parametrize("n,layers,flags", [(16, 2, 0), (18, 2, 128 | 32), (20, 1, 128 | 32)])
+def test_plan_autotuner_keeps_results_and_reports_its_choice(n, layers, flags):
+    """qmle_plan_autotune (opt-in): the model's best schedules timed on the device, the fastest kept.
+    Whatever it picks, <Z> and the state stay what they were (the candidates are the same tape), the
+    plan says so (`autotuned`), a second plan of the same tape adopts the remembered choice without
+    timing, and plans with a single schedule come back untouched."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    ops, slots = [], 0
+    for _ in range(layers):
+        o, sl = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in k], m) for g, w, k, m in o]
+        slots += sl
+    ang = torch.from_numpy(np.random.default_rng(n).uniform(0, 2 * np.pi, (4, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots, flags=flags)
+    z0 = plan.run(ang, "expval", list(range(n)))
+    s0 = plan.run(ang, "state")
+    rep = plan.autotune("expval", n, batch=4, top_k=4, reps=2)
+    assert rep["candidate"] >= 0 and rep["ms_after"] <= rep["ms_before"] * 1.0 + 1e-9
+    exe = plan.expval_child() or plan
+    assert exe.describe()["autotuned"] is True and exe.describe()["candidate"] == rep["candidate"]
+    z1 = plan.run(ang, "expval", list(range(n)))
+    assert float((z0 - z1).abs().max()) < 1e-6
+    rep_s = plan.autotune("state", 0, batch=4, top_k=4, reps=2)
+    s1 = plan.run(ang, "state")
+    assert float((torch.view_as_real(s0) - torch.view_as_real(s1)).abs().max()) < 1e-6
+    again = N.Plan(ops, n, slots, flags=flags)
+    rep2 = again.autotune("expval", n, batch=4, top_k=4, reps=2)
+    assert rep2["candidate"] == rep["candidate"] and rep2["padding"] == rep["padding"] and rep2["ms_before"] == 0.0
+    assert float((again.run(ang, "expval", list(range(n))) - z0).abs().max()) < 1e-6
+    ops12, slots12 = he_layer_ops(12)
+    small = N.Plan(ops12, 12, slots12)
+    assert small.autotune("expval", 12, batch=4)["candidate"] == -1   # whole state in LDS: one schedule
+    assert rep_s["candidate"] >= -1
+
+
 def test_dense_4wire_operator_and_density_measurements():
     """QMLE_OP_MAT4 (16x16 on 4 wires, any wire order) against the dense oracle, in the
     whole-state and the tiled regime; diag / <Z> of a vectorised density matrix."""
