@@ -286,7 +286,14 @@ class Script:
         # all-gather returns the full result everywhere (script.py:443-453)
         lo, hi, sharded = distributed.my_block(batch_size, *args)
         local = hi - lo
-        chunk = memory.compute_chunk_size(n_qubits, local, type, use_density, n_obs, n_ops=n_ops)
+        from .utils import x64_enabled
+
+        x64 = x64_enabled() and shots is None
+        # (complex128 mode: 16-byte amplitudes, and observables the engine does not measure itself --
+        # anything but Z / Z-parities -- keep every sample's state for the contraction)
+        general = x64 and type == "expval" and any(z_parity_mask(o) is None for o in (obs or []))
+        chunk = memory.compute_chunk_size(n_qubits, local, type, use_density, n_obs, n_ops=n_ops,
+                                          x64=x64, general_obs=general)
         if chunk >= local:
             res = run(lo, hi)[0]
         else:

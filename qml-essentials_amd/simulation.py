@@ -504,7 +504,7 @@ def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], 
         if not parity:
             raise NotImplementedError("parameter shift in x64 mode needs Z / Z-parity observables")
         chunk = max(1, memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]), "expval", False,
-                                                 len(obs), n_ops=plan.n_ops) // 2)
+                                                 len(obs), n_ops=plan.n_ops, x64=True))
         for r0 in range(0, table.shape[0], chunk):
             ang = torch.from_numpy(np.ascontiguousarray(table[r0:r0 + chunk])).cuda()
             out.append(plan.run64(ang, "expval", masks).cpu().numpy())

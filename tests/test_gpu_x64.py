@@ -246,3 +246,43 @@ def test_shots_in_x64_draw_from_the_complex128_probabilities():
         assert exact.dtype == np.float64
         assert np.abs(np.asarray(a) - np.asarray(b)).sum() * shots <= 8  # a few boundary shots
         assert np.abs(np.asarray(b) - exact).max() < 5 / np.sqrt(shots)
+
+
+def test_x64_calls_chunk_instead_of_running_out_of_memory(monkeypatch):
+    """the batch chunker sized x64 calls with the complex64 model.  With free HBM
+    'shrunk' to 40 MiB a complex128 batch of 64 x 2^15 amplitudes (32 MiB of states + as much again
+    for a general observable) must go through execute_chunked -- and give the unchunked numbers."""
+    from qml_essentials_amd import memory, utils
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd.script import Script
+
+    n = 15
+
+    def circuit(theta):
+        for q in range(n):
+            op.RY(theta * (q + 1) / n, wires=q)
+        for q in range(n - 1):
+            op.CX(wires=[q, q + 1])
+
+    th = np.linspace(0.1, 2.0, 64)
+    obs_z = [op.PauliZ(q, record=False) for q in (0, 7, 14)]
+    obs_g = [op.PauliX(3, record=False)]
+    with utils.x64_scope(True):
+        full_state = Script(circuit, n).execute(type="state", args=(th,), in_axes=(0,))
+        full_z = Script(circuit, n).execute(type="expval", obs=obs_z, args=(th,), in_axes=(0,))
+        full_g = Script(circuit, n).execute(type="expval", obs=obs_g, args=(th,), in_axes=(0,))
+        calls = []
+        real = memory.execute_chunked
+        monkeypatch.setattr(memory, "execute_chunked", lambda run, b, c: (calls.append((b, c)), real(run, b, c))[1])
+        monkeypatch.setattr(memory, "available_memory_bytes", lambda: 40 << 20)
+        got_state = Script(circuit, n).execute(type="state", args=(th,), in_axes=(0,))
+        got_z = Script(circuit, n).execute(type="expval", obs=obs_z, args=(th,), in_axes=(0,))
+        got_g = Script(circuit, n).execute(type="expval", obs=obs_g, args=(th,), in_axes=(0,))
+    assert len(calls) == 3 and all(c < b for b, c in calls), calls
+    assert calls[2][1] < calls[0][1] or calls[2][1] <= calls[1][1]   # the general observable keeps the states
+    assert np.asarray(got_state).dtype == np.complex128
+    assert np.array_equal(np.asarray(got_state), np.asarray(full_state))
+    assert np.array_equal(np.asarray(got_z), np.asarray(full_z))
+    assert np.allclose(np.asarray(got_g), np.asarray(full_g), atol=1e-12)
+    # and the float32 model would have let the state call through whole: 64 x 2^15 x 8 B = 16 MiB < 32 MiB
+    assert memory.compute_chunk_size(n, 64, "state", False) == 64

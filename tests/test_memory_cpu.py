@@ -45,3 +45,21 @@ def test_execute_chunked_concatenates_uneven_chunks():
     out = memory.execute_chunked(run, 7, 3)          # chunks of 3, 3, 1
     assert calls == [(0, 3), (3, 6), (6, 7)] and out.shape == (7, 3)
     assert np.array_equal(out[:, 0], np.arange(7))
+
+
+def test_complex128_mode_doubles_the_model(monkeypatch):
+    """in x64 mode the engine holds 16-byte amplitudes, float64 matrix rows and (above 13
+    qubits) 4 GiB of states in flight; observables it does not measure itself keep every state."""
+    for meas in ("state", "probs", "density"):
+        a = memory.estimate_peak_bytes(20, 8, meas, False, 4, n_ops=50)
+        b = memory.estimate_peak_bytes(20, 8, meas, False, 4, n_ops=50, x64=True)
+        assert 1.9 < b / a < 2.1, (meas, a, b)
+    # expval at 14 qubits: LDS-resident in complex64, streaming (states in HBM) in complex128
+    assert memory.estimate_peak_bytes(14, 1000, "expval", False, 14, x64=True) > \
+        100 * memory.estimate_peak_bytes(14, 1000, "expval", False, 14)
+    g = memory.estimate_peak_bytes(12, 64, "expval", False, 2, x64=True, general_obs=True)
+    assert g > 64 * (1 << 12) * 16 * 2
+    monkeypatch.setattr(memory, "available_memory_bytes", lambda: 1 << 30)
+    c32 = memory.compute_chunk_size(20, 512, "state", False)
+    c64 = memory.compute_chunk_size(20, 512, "state", False, x64=True)
+    assert 1 <= c64 <= c32 // 2 + 4 and c32 < 512  # (the constant megabyte of slack is not doubled)
