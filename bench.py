@@ -171,7 +171,7 @@ def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, prof
         low = simulation.LoweredTape(tape, n)
         top = simulation.get_plan(low)
         folded = top.describe().get("absorbed_ops", 0)
-        plan = top.expval_child() or top
+        plan = top.executed("expval")
         desc = plan.describe()
         params_dev = torch.from_numpy(params).cuda()  # resident in HBM before the timed region
         x_dev = None if inputs is None else torch.from_numpy(inputs).cuda()
@@ -552,7 +552,7 @@ def lds_regime_leg(n, layers, dru, batch, meas, reps=10):
     tape, _ = model.record_tape(params=params[:2], inputs=x)
     low = simulation.LoweredTape(tape, n)
     top = simulation.get_plan(low)
-    plan = (top.expval_child() or top) if meas == "expval" else top
+    plan = top.executed(meas)
     desc = plan.describe()
     pd = torch.from_numpy(params).cuda()
     xd = None if x is None else torch.from_numpy(x).cuda()

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 146 /* 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 147 /* 0.1.4.7: qmle_plan_executed (qmle_plan_expval_child = the folded child only); 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -179,6 +179,12 @@ int qmle_plan_autotune(qmle_plan *plan, int meas_type, int n_obs, int batch, int
  * the remaining gates form this child plan (owned by `plan`; NULL if nothing was folded).
  * For introspection / profiling only. */
 qmle_plan *qmle_plan_expval_child(qmle_plan *plan);
+/* The plan object qmle_run_batch really executes for `meas_type` (owned by `plan`, never NULL for a
+ * valid plan): the folded child above for QMLE_MEAS_EXPVAL_Z, and of that / of the plan itself the
+ * schedule compiled for runs from |0..0> when there is one (wider first tile; such a handle is refused
+ * by qmle_apply_inplace and qmle_adjoint_gradient, which apply stages to LIVE states:
+ * QMLE_ERR_UNSUPPORTED).  Describe, count stages of and profile THIS handle. */
+qmle_plan *qmle_plan_executed(qmle_plan *plan, int meas_type);
 /* JSON description of the compiled passes (for tests / DESIGN.md); returns the
  * number of bytes needed (excluding NUL); writes at most cap-1 bytes + NUL. */
 int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap);

@@ -106,6 +106,7 @@ SYMBOLS = [
                                C.POINTER(_VP)]),
     ("qmle_plan_destroy", _I, [_VP]),
     ("qmle_plan_expval_child", _VP, [_VP]),
+    ("qmle_plan_executed", _VP, [_VP, _I]),
     ("qmle_plan_describe", _I, [_VP, C.c_char_p, _SZ]),
     ("qmle_plan_stats", _I, [_VP, C.POINTER(C.c_int64)]),
     ("qmle_plan_autotune", _I, [_VP, _I, _I, _I, _I, _I, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_double),
@@ -285,9 +286,20 @@ class Plan:
             self._h = None
 
     def expval_child(self) -> Optional["Plan"]:
-        """The plan ``run(..., "expval")`` executes when trailing CX / SWAP / diagonal gates were
-        folded into the Z observables (non-owning view; None if nothing was folded)."""
-        h = lib().qmle_plan_expval_child(self._h)
+        """The child plan that runs when trailing CX / SWAP / diagonal gates were folded into the Z
+        observables (non-owning view; None if nothing was folded)."""
+        return self._view(lib().qmle_plan_expval_child(self._h))
+
+    def executed(self, meas: str = "expval") -> "Plan":
+        """The plan object ``run(..., meas)`` really executes (``qmle_plan_executed``): the folded
+        child for "expval", and of that / of this plan the schedule compiled for runs from |0..0>
+        when there is one.  Describe and profile THIS view; it is ``self`` when nothing differs."""
+        h = lib().qmle_plan_executed(self._h, MEAS[meas])
+        if not h or h == self._h.value:
+            return self
+        return self._view(h)
+
+    def _view(self, h) -> Optional["Plan"]:
         if not h:
             return None
         child = Plan.__new__(Plan)
@@ -331,7 +343,8 @@ class Plan:
 
     def profile_end(self):
         """-> (ms per pass, launches per pass, pool_overflowed)."""
-        n = max(1, self.stats()["n_passes"])
+        # (the engine times the plan it executes -- executed() -- whose pass count may differ from this one's)
+        n = max(1, self.stats()["n_passes"], self.executed("state").stats()["n_passes"])
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()
         rc = lib().qmle_profile_end(self._h, ms, cnt, n)

@@ -417,6 +417,8 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     return QMLE_ERR_INVALID_ARG;
   if ((fwd->n_slots > 0 && !d_angles_fwd) || (rev->n_slots > 0 && !d_angles_rev))
     return QMLE_ERR_INVALID_ARG;
+  // (the sweep applies stages to LIVE states: a schedule compiled for runs from |0..0> only is refused)
+  if ((fwd->flags | rev->flags) & QMLE_PLAN_INTERNAL_ZERO_RUN) return QMLE_ERR_UNSUPPORTED;
   const int n = fwd->n;
   // rev is either a NO_FUSION plan (one streaming pass per gate) or a NO_MERGE plan (fused tile
   // passes); both keep one source gate per lowered operator
@@ -509,11 +511,12 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     for (int k = 0; k < n_obs; ++k) a.zmask[k] = wires_to_pos(obs_wire_masks[k], n);
     a.grad = d_grad;
     a.n_grad_slots = n_grad_slots;
-    if (first_use_on_device(3)) {
+    if (FirstUse once{3}; once.first) {
       HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_adjoint_lds<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      once.done();
     }
     bool has_dense4 = false;
     for (int g = fst.grp_begin; g < fst.grp_end; ++g) has_dense4 |= fwd->op_groups[g].kind == GK_DENSE4;
@@ -617,9 +620,10 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
     d_gtype = (const int32_t *)((char *)rev->adjf_blob + o1);
     d_slot_of = (const int32_t *)((char *)rev->adjf_blob + o2);
     d_coef_of = (const float *)((char *)rev->adjf_blob + o3);
-    if (first_use_on_device(4)) {
+    if (FirstUse once{4}; once.first) {
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_adj,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      once.done();
     }
   }
   float *tile_partial = (float *)(ws + L.tile_partial);

@@ -1417,9 +1417,10 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
   if (last.T < n) {
     const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
     if (!cv.ok) return QMLE_ERR_INTERNAL;
-    if (first_use_on_device(6)) {
+    if (FirstUse once{6}; once.first) {
       QMLE_LDS_BASE_CHECK(k_mw_read_later<true>);
       QMLE_LDS_BASE_CHECK(k_mw_read_later<false>);
+      once.done();
     }
     const uint32_t tiles = 1u << (n - kMwT);
     const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
@@ -1509,11 +1510,12 @@ int qmle_meyer_wallach(const void *d_states, int n_qubits, int batch, float *d_o
   hipStream_t stream = (hipStream_t)stream_;
   const int n = n_qubits;
   if (n >= kMwT) {  // LDS-staged tiles: 1 + ceil((n - 12) / 8) reads of the state
-    if (first_use_on_device(5)) {
+    if (FirstUse once{5}; once.first) {
       QMLE_LDS_BASE_CHECK(k_mw_read_first<true>);
       QMLE_LDS_BASE_CHECK(k_mw_read_first<false>);
       QMLE_LDS_BASE_CHECK(k_mw_read_later<true>);
       QMLE_LDS_BASE_CHECK(k_mw_read_later<false>);
+      once.done();
     }
     const MwPlan pl = mw_plan(n, batch);
     for (int p = 0; p < n; ++p)

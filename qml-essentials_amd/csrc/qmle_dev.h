@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <utility>
 
@@ -271,14 +272,40 @@ static inline int current_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
   return dev;
 }
-static inline bool first_use_on_device(int slot) {
-  static std::atomic<bool> done[8][kMaxDevices] = {};
-  int dev = -1;
-  // a device index beyond the table has no slot of its own: its attributes are simply set on
-  // every call (idempotent) instead of sharing -- and trusting -- slot 0's flag
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;
-  return !done[slot][dev].exchange(true);
-}
+// `if (FirstUse once{slot}; once.first) { ...set attributes, may return an error...; once.done(); }`:
+// the slot is marked done only AFTER the guarded work succeeded (an early error return leaves it to the
+// next call instead of latching a half-configured device: ADVICE r3), and a second thread that arrives
+// meanwhile waits on the slot's mutex instead of launching before the attributes are set.
+struct FirstUse {
+  std::atomic<bool> *flag = nullptr;
+  std::mutex *mu = nullptr;
+  bool first = true;
+  explicit FirstUse(int slot) {
+    static std::atomic<bool> done_[8][kMaxDevices] = {};
+    static std::mutex mu_[8][kMaxDevices];
+    int dev = -1;
+    // a device index beyond the table has no slot of its own: its attributes are simply set on
+    // every call (idempotent) instead of sharing -- and trusting -- slot 0's flag
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
+    flag = &done_[slot][dev];
+    if (flag->load(std::memory_order_acquire)) { first = false; return; }
+    mu = &mu_[slot][dev];
+    mu->lock();
+    if (flag->load(std::memory_order_acquire)) {  // somebody else finished while we waited
+      first = false;
+      mu->unlock();
+      mu = nullptr;
+    }
+  }
+  FirstUse(const FirstUse &) = delete;
+  FirstUse &operator=(const FirstUse &) = delete;
+  void done() {
+    if (flag) flag->store(true, std::memory_order_release);
+  }
+  ~FirstUse() {
+    if (mu) mu->unlock();
+  }
+};
 
 // The tile kernels address their LDS tile by XOR (swizzle + gather offsets folded into one
 // `base ^ offset`), which is only an addition while the tile starts at a multiple of its size.

@@ -272,10 +272,15 @@ int qmle_plan_create(const qmle_op *ops, int n_ops, int n_qubits, int n_slots,
   *out = p;
   return QMLE_OK;
 }
-// (the plan QMLE_MEAS_EXPVAL_Z executes: the child when trailing gates were folded into the
-// observables, else the from-|0..0> variant of the plan when there is one)
-qmle_plan *qmle_plan_expval_child(qmle_plan *plan) {
-  return !plan ? nullptr : plan->expval_child ? plan->expval_child : plan->zero_variant;
+// the child that runs when trailing gates were folded into the Z observables (NULL: nothing was folded)
+qmle_plan *qmle_plan_expval_child(qmle_plan *plan) { return plan ? plan->expval_child : nullptr; }
+// the plan qmle_run_batch really executes for `meas_type`: the folded child for QMLE_MEAS_EXPVAL_Z when
+// there is one, and of that (or of the plan) the schedule compiled for runs from |0..0> when the
+// pass-cost model preferred it.  Never NULL for a valid plan; describe / profile THIS handle.
+qmle_plan *qmle_plan_executed(qmle_plan *plan, int meas_type) {
+  if (!plan) return nullptr;
+  qmle_plan *p = (meas_type == QMLE_MEAS_EXPVAL_Z && plan->expval_child) ? plan->expval_child : plan;
+  return p->zero_variant ? p->zero_variant : p;
 }
 
 int qmle_plan_destroy(qmle_plan *plan) {
@@ -718,6 +723,8 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
   if (!plan || batch < 1 || batch > 65535 || !d_states || !d_workspace) return QMLE_ERR_INVALID_ARG;
   if (plan->n_slots > 0 && !d_angles) return QMLE_ERR_INVALID_ARG;
+  // (a schedule compiled for runs from |0..0> -- qmle_plan_executed's handle -- is not one for live states)
+  if (plan->flags & QMLE_PLAN_INTERNAL_ZERO_RUN) return QMLE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   int rc = ensure_device_plan(plan);
   if (rc != QMLE_OK) return rc;
@@ -959,6 +966,11 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
 
 int qmle_profile_begin(qmle_plan *plan, int capacity) {
   if (!plan || capacity < 1) return QMLE_ERR_INVALID_ARG;
+  // (qmle_run_batch executes the from-|0..0> variant when there is one: its launches are the ones to time)
+  if (plan->zero_variant) {
+    const int rc = qmle_profile_begin(plan->zero_variant, capacity);
+    if (rc != QMLE_OK) return rc;
+  }
   StageProfile &pr = plan->prof;
   while ((int)pr.start.size() < capacity) {
     hipEvent_t a, b;
@@ -974,8 +986,23 @@ int qmle_profile_begin(qmle_plan *plan, int capacity) {
 }
 
 int qmle_profile_end(qmle_plan *plan, double *stage_ms, int64_t *stage_launches, int n_stages) {
-  if (!plan || !stage_ms || !stage_launches || n_stages < (int)plan->stages.size())
-    return QMLE_ERR_INVALID_ARG;
+  if (!plan || !stage_ms || !stage_launches) return QMLE_ERR_INVALID_ARG;
+  if (plan->zero_variant && plan->zero_variant->prof.on) {
+    // the variant ran (qmle_run_batch) unless the plan itself recorded launches (qmle_apply_inplace)
+    if (plan->prof.used == 0) {
+      plan->prof.on = false;
+      for (size_t k = 0; k < plan->prof.start.size(); ++k) {
+        (void)hipEventDestroy((hipEvent_t)plan->prof.start[k]);
+        (void)hipEventDestroy((hipEvent_t)plan->prof.stop[k]);
+      }
+      plan->prof.start.clear(); plan->prof.stop.clear(); plan->prof.stage.clear();
+      return qmle_profile_end(plan->zero_variant, stage_ms, stage_launches, n_stages);
+    }
+    std::vector<double> ms(plan->zero_variant->stages.size() + 1);
+    std::vector<int64_t> cnt(plan->zero_variant->stages.size() + 1);
+    (void)qmle_profile_end(plan->zero_variant, ms.data(), cnt.data(), (int)ms.size());
+  }
+  if (n_stages < (int)plan->stages.size()) return QMLE_ERR_INVALID_ARG;
   StageProfile &pr = plan->prof;
   pr.on = false;
   for (int i = 0; i < n_stages; ++i) { stage_ms[i] = 0.0; stage_launches[i] = 0; }

@@ -225,15 +225,23 @@ static int ensure_f64(qmle_plan *p) {
   const size_t b_c = align_up(nc * sizeof(double) + 16, 256);
   char *blob = nullptr;
   HIPCHK(hipMalloc((void **)&blob, b_low + b_c));
-  p->f64_blob = blob;
-  p->f64_device = current_device();
+  // (the plan takes the blob only once BOTH uploads have succeeded: a failed copy must not leave a
+  // plan that looks initialised and runs on garbage operators)
+  hipError_t err = hipSuccess;
   if (!p->lowered.empty())
-    HIPCHK(hipMemcpy(blob, p->lowered.data(), p->lowered.size() * sizeof(LoweredOp), hipMemcpyHostToDevice));
-  if (nc) {
+    err = hipMemcpy(blob, p->lowered.data(), p->lowered.size() * sizeof(LoweredOp), hipMemcpyHostToDevice);
+  if (err == hipSuccess && nc) {
     std::vector<double> c64(nc);
     for (size_t i = 0; i < nc; ++i) c64[i] = i < p->consts64.size() ? p->consts64[i] : (double)p->consts[i];
-    HIPCHK(hipMemcpy(blob + b_low, c64.data(), nc * sizeof(double), hipMemcpyHostToDevice));
+    err = hipMemcpy(blob + b_low, c64.data(), nc * sizeof(double), hipMemcpyHostToDevice);
   }
+  if (err != hipSuccess) {
+    (void)hipFree(blob);
+    g_last_hip_error = (int)err;
+    return QMLE_ERR_HIP;
+  }
+  p->f64_blob = blob;
+  p->f64_device = current_device();
   return QMLE_OK;
 }
 
@@ -341,8 +349,10 @@ int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int m
   const int n_ops = (int)plan->lowered.size();
   double2 *d_states = (double2 *)ws;
   if (n <= 13) {
-    if (first_use_on_device(6))
+    if (FirstUse once{6}; once.first) {
       HIPCHK(hipFuncSetAttribute((const void *)k64_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      once.done();
+    }
     void *target = meas_type == QMLE_MEAS_DENSITY ? (void *)d_states : d_out;
     hipLaunchKernelGGL(k64_lds, dim3(batch), dim3(256), D * sizeof(double2), stream, d_low, n_ops, n, d_mats,
                        plan->mat_floats, d_c64, d_angles, plan->n_slots, meas_type, obs, n_obs, target);

@@ -1566,7 +1566,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                  ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)
              ? 1 : 0;
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
-  if (first_use_on_device(0)) {
+  if (FirstUse once{0}; once.first) {
     QMLE_LDS_BASE_CHECK(k_tile<false>);
     QMLE_LDS_BASE_CHECK(k_tile<true>);
     QMLE_LDS_BASE_CHECK((k_tile<false, true>));
@@ -1579,6 +1579,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)k_tile<true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    once.done();
   }
   bool has_dense4 = false;  // 16x16 Kraus superoperators: separate instantiation, so that the
                             // common kernel keeps its register budget
@@ -1608,13 +1609,14 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                      wg_per_cu >= 1 && total < (1ull << 31) &&
                      total >= 4ull * n_cu * wg_per_cu;
   if (pf_ok) {
-    if (first_use_on_device(1)) {
+    if (FirstUse once{1}; once.first) {
       QMLE_LDS_BASE_CHECK(k_tile_pf<false>);
       QMLE_LDS_BASE_CHECK(k_tile_pf<true>);
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile_pf<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      once.done();
     }
     const unsigned wgs = (unsigned)n_cu * wg_per_cu;
     const uint32_t chunk = (uint32_t)((total + wgs - 1) / wgs);
@@ -1714,7 +1716,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   static const bool no_fast_whole = std::getenv("QMLE_NO_FAST_WHOLE") != nullptr;
   if (!no_fast && st.fast_ok && p->n <= 28 && threads == (1 << (st.T - 4)) &&
       (st.T < p->n ? meas != TM_EXPVAL : !no_fast_whole)) {
-    if (first_use_on_device(2)) {
+    if (FirstUse once{2}; once.first) {
 #define QMLE_T2_LDS(NT, ME, MU)                                                   \
   QMLE_LDS_BASE_CHECK((k_tile2<NT, ME, MU>));                                      \
   HIPCHK(hipFuncSetAttribute((const void *)k_tile2<NT, ME, MU>,                    \
@@ -1739,6 +1741,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, false, true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      once.done();
     }
     Tile2Args f;
     f.groups = p->dev.d_groups2 + st.fast_begin;

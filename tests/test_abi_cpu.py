@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_header_symbols():
     lib = N.lib()
-    assert lib.qmle_sv_version() == 146
+    assert lib.qmle_sv_version() == 147
     header = open(os.path.join(ROOT, "include", "qmle_sv.h")).read()
     declared = set(re.findall(r"\b(qmle_[a-z_0-9]+)\s*\(", header))
     declared -= {"qmle_op", "qmle_plan"}
@@ -185,7 +185,7 @@ def test_xor_addressed_tile_kernels_have_no_static_lds():
 def test_from_zero_variant_of_the_all_live_k2_plan():
     """Plan compiler, host only (round 3).  qmle_run_batch always starts from |0..0>, where the
     first stage computes ONE tile per state whatever the tile size: the plan it executes (the
-    from-zero variant, reported by expval_child() when nothing was folded) may stage 2^14
+    from-zero variant, reported by executed()) may stage 2^14
     amplitudes first, and carries bit position 6 so that the read+write pass's tile is {0-3, 6,
     13-19} -- the shape that streams 15 % faster.  The plan's own stages, which
     qmle_apply_inplace and the adjoint sweep apply to LIVE states, keep the round-2 schedule."""
@@ -194,8 +194,9 @@ def test_from_zero_variant_of_the_all_live_k2_plan():
     own = top.describe()
     assert own["zero_run"] is False and [s["T"] for s in own["stages"]] == [12, 12, 12]
     assert [sum(g["n_ops"] for g in s["fast_groups"]) for s in own["stages"]] == [12, 8, 4]
-    var = top.expval_child()
-    assert var is not None
+    assert top.expval_child() is None   # NO_ABSORB: nothing folded; executed() names the variant
+    var = top.executed("expval")
+    assert var is not top
     d = var.describe()
     assert d["zero_run"] is True and d["model_cost"] < own["model_cost"]
     st = d["stages"]
@@ -211,9 +212,11 @@ def test_from_zero_variant_of_the_all_live_k2_plan():
     dflt = N.Plan(ops, 24, slots).expval_child().describe()
     assert [s["T"] for s in dflt["stages"]] == [12, 12, 12] and dflt["stages"][1]["product"]
     # forced geometries, one-pass-per-gate plans and whole-state plans have no variant
-    assert N.Plan(ops, 24, slots, flags=N.PLAN_NO_ABSORB | N.PLAN_NO_FUSION).expval_child() is None
+    unf = N.Plan(ops, 24, slots, flags=N.PLAN_NO_ABSORB | N.PLAN_NO_FUSION)
+    assert unf.expval_child() is None and unf.executed("expval") is unf and unf.executed("state") is unf
     ops12, slots12 = he_layer_ops(12)
-    assert N.Plan(ops12, 12, slots12, flags=N.PLAN_NO_ABSORB).expval_child() is None
+    small = N.Plan(ops12, 12, slots12, flags=N.PLAN_NO_ABSORB)
+    assert small.expval_child() is None and small.executed("expval") is small
 
 
 def test_meyer_wallach_read_count():
@@ -352,7 +355,7 @@ def test_every_schedule_candidate_places_every_gate_exactly_once(monkeypatch):
         for k in range(48):
             monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
             top = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
-            d = (top.expval_child() or top).describe()
+            d = top.executed("expval").describe()
             placed = sorted(s for st in d["stages"] for s in st["src_ops"])
             assert placed == list(range(len(ops))), (k, pad)
             for st in d["stages"]:

@@ -68,10 +68,13 @@ def test_from_zero_variant_equals_the_plans_own_schedule_and_the_oracle(n, layer
     ang = np.random.default_rng(n).uniform(0, 2 * np.pi, (2, slots)).astype(np.float32)
     angd = torch.from_numpy(ang).cuda()
     plan = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
-    var = plan.expval_child()
-    assert var is None or var.describe()["zero_run"]
+    assert plan.expval_child() is None          # (nothing folded under NO_ABSORB)
+    var = plan.executed("state")                # the from-|0..0> variant when the model preferred one
+    assert var is plan or var.describe()["zero_run"]
     if n >= 18:   # (small registers may keep the plain schedule: the pass-cost model decides)
-        assert var is not None and var.describe()["stages"][0]["T"] == 14
+        assert var is not plan and var.describe()["stages"][0]["T"] == 14
+        with pytest.raises(NotImplementedError):  # a from-zero schedule is not one for live states
+            N.apply_inplace(var, angd, torch.zeros((2, 1 << n), dtype=torch.complex64, device="cuda"))
     got = plan.run(angd, "state")                      # from |0..0>: the variant
     st = torch.zeros((2, 1 << n), dtype=torch.complex64, device="cuda")
     st[:, 0] = 1
@@ -355,7 +358,7 @@ def test_plan_autotuner_keeps_results_and_reports_its_choice(n, layers, flags):
     s0 = plan.run(ang, "state")
     rep = plan.autotune("expval", n, batch=4, top_k=4, reps=2)
     assert rep["candidate"] >= 0 and rep["ms_after"] <= rep["ms_before"] * 1.0 + 1e-9
-    exe = plan.expval_child() or plan
+    exe = plan.executed("expval")
     assert exe.describe()["autotuned"] is True and exe.describe()["candidate"] == rep["candidate"]
     z1 = plan.run(ang, "expval", list(range(n)))
     assert float((z0 - z1).abs().max()) < 1e-6
@@ -774,11 +777,11 @@ def test_last_stage_padding_switch_changes_the_tile_not_the_result(monkeypatch):
     for v in ("1", "8"):
         monkeypatch.setenv("QMLE_PAD_HIGH", v)
         p = N.Plan(ops, n, slots, flags=flags)
-        tiles[v] = (p.expval_child() or p).describe()["stages"][-1]["bits"]
+        tiles[v] = p.executed("expval").describe()["stages"][-1]["bits"]
         got = p.run(ang, "expval", list(range(n))).cpu().numpy()
         assert np.allclose(got, want, atol=2e-6), (v, np.abs(got - want).max())
     monkeypatch.delenv("QMLE_PAD_HIGH")
-    default_tile = (base.expval_child() or base).describe()["stages"][-1]["bits"]
+    default_tile = base.executed("expval").describe()["stages"][-1]["bits"]
     assert tiles["1"] != default_tile or tiles["8"] != default_tile
     tape = [(g, w, [float(ang[0, s]) for s in sl]) for g, w, sl, _ in ops]
     psi = OE.simulate_pure(oracle_tape(tape, n), n, dtype=np.complex128)
@@ -852,7 +855,7 @@ def test_every_schedule_candidate_gives_the_same_result(monkeypatch):
         for k in range(48):
             monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
             p = N.Plan(ops, n, slots, flags=flags)
-            d = (p.expval_child() or p).describe()
+            d = p.executed("expval").describe()
             shapes.add(tuple(tuple(st["bits"]) for st in d["stages"]))
             assert (p.run(ang, "state") - want_s).abs().max().item() < 1e-6, (k, pad)
             assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 1e-6, (k, pad)

@@ -56,7 +56,7 @@ for label, n, layers, dru, flags, B in SHAPES:
     tune_s = time.perf_counter() - t0
     ws = torch.empty(plan.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
     after, z1 = per_state_us(plan, ang, obs, ws)
-    d = (plan.expval_child() or plan).describe()
+    d = plan.executed("expval").describe()
     print(f"{label}: {before:.1f} -> {after:.1f} us per state ({(after / before - 1) * 100:+.1f} %), tuner {rep}, "
           f"{tune_s:.2f} s, max |d<Z>| {float((z0 - z1).abs().max()):.1e}, stages now "
           f"{[(s['T'], s['bits'][:2] + ['..'] + s['bits'][-2:]) for s in d['stages']]}", flush=True)

@@ -12,7 +12,7 @@ tape, _ = m.record_tape(params=P[:2], inputs=np.array([0.5], dtype=np.float32))
 low = simulation.LoweredTape(tape, n)
 for label, flags in (("auto", 0), ("dense", N.PLAN_NO_SPARSE), ("tape order", N.PLAN_TAPE_ORDER)):
     top = N.Plan(low.ops, n, low.n_slots, low.consts, flags)
-    plan = top.expval_child() or top
+    plan = top.executed("expval")
     d = plan.describe()
     ang = torch.from_numpy(np.ascontiguousarray(low.angle_table(2)[:1].repeat(B, 0))).cuda()
     ang = torch.from_numpy(rng.uniform(0, 6.28, (B, low.n_slots)).astype(np.float32)).cuda()

@@ -23,7 +23,7 @@ obs = list(range(n))
 
 def run(tag):
     top = N.Plan(ops, n, slots, flags=flags)
-    plan = top.expval_child() or top
+    plan = top.executed("expval")
     d = plan.describe()
     ws = torch.empty(top.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
     for _ in range(2):

@@ -18,7 +18,7 @@ x = np.full((1, 1), 0.5, dtype=np.float32)
 tape, _ = model.record_tape(params=params[:2], inputs=x)
 low = simulation.LoweredTape(tape, n)
 top = simulation.get_plan(low)
-plan = top.expval_child() or top
+plan = top.executed("expval")
 d = plan.describe()
 pd, xd = torch.from_numpy(params).cuda(), torch.from_numpy(x).cuda()
 for _ in range(2):

@@ -18,7 +18,7 @@ for _ in range(layers):
 ang = torch.from_numpy(np.random.default_rng(1000).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
 flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
 top = N.Plan(ops, n, slots, flags=flags)
-plan = top.expval_child() or top
+plan = top.executed("expval")
 d = plan.describe()
 ws = torch.empty(top.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
 obs = list(range(n))

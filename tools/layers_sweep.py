@@ -16,7 +16,7 @@ def run(n, B, flags, label, layers, reps=3):
     rng = np.random.default_rng(1000)
     ang = torch.from_numpy(rng.uniform(0, 2 * np.pi, (B, layers * slots)).astype(np.float32)).cuda()
     top = N.Plan(allops, n, layers * slots, flags=flags)
-    plan = top.expval_child() or top
+    plan = top.executed("expval")
     d = plan.describe()
     ws = torch.empty(top.workspace_bytes(B, "expval", n), dtype=torch.uint8, device="cuda")
     obs = list(range(n))

@@ -36,7 +36,7 @@ for n, layers, B in SHAPES:
         plan.run(ang, "expval", obs, workspace=ws)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    d = (plan.expval_child() or plan).describe()["stages"][0]
+    d = plan.executed("expval").describe()["stages"][0]
     print(f"n={n} layers={layers} B={B}: {ms*1e3:.1f} us per launch = {B/ms/1e3:.2f} M states/s, "
           f"{len(ops)} gates, fast={d['fast']} groups={len(d['fast_groups']) if d['fast'] else len(d['groups'])} "
           f"(generic grouping: {len(d['groups'])})", flush=True)
