@@ -426,12 +426,12 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
                                shots, key, row_offset)
         return res if as_tensor else res.cpu().numpy()
     low = LoweredTape(tape, n_qubits)
-    plan = get_plan(low)
     from .utils import x64_enabled
 
     if x64_enabled():
         # gate by gate, like the reference (no products of neighbouring 1-qubit gates): the
         # accuracy mode keeps the reference's operation order as well as its precision
+        # (ONE compile: the default-flag plan of the complex64 engine is not built here)
         plan = get_plan(low, (PLAN_FLAGS or 0) | N.PLAN_NO_MERGE)
         if sampled:  # shots: drawn from the complex128 probabilities, rounded once to float32
             res = sample_shots(_simulate_x64(plan, low, B, n_qubits, "probs", []).float(), n_qubits, type,
@@ -439,6 +439,7 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
         else:
             res = _simulate_x64(plan, low, B, n_qubits, type, list(obs))
         return res if as_tensor else res.cpu().numpy()
+    plan = get_plan(low)
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if sampled:
         res = sample_shots(plan.run(angles, "probs"), n_qubits, type, obs, shots, key, row_offset)
@@ -475,11 +476,28 @@ def _simulate_x64(plan: N.Plan, low: "LoweredTape", B: int, n_qubits: int, type:
     masks = [z_parity_mask(o) for o in obs]
     if all(m is not None for m in masks) and len(obs) <= 32:
         return plan.run64(angles, "expval", masks)
-    psi = plan.run64(angles, "state").reshape((B,) + (2,) * n_qubits)
+    return _x64_observables(plan.run64(angles, "state"), n_qubits, obs, masks)
+
+
+def _x64_observables(states, n_qubits: int, obs, masks):
+    """<psi|O|psi> of complex128 states [B, 2^n] that are already in hand: Z / Z-parity observables as
+    signed sums of |psi|^2 (no second run of the circuit per observable), anything else as a dense
+    contraction over the observable's wires."""
+    torch = N.require_gpu()
+    B = states.shape[0]
+    psi = states.reshape((B,) + (2,) * n_qubits)
+    prob = None
     cols = []
     for ob, m in zip(obs, masks):
         if m is not None:
-            cols.append(plan.run64(angles, "expval", [m])[:, 0])
+            if prob is None:
+                prob = (states.real ** 2 + states.imag ** 2).reshape((B,) + (2,) * n_qubits)
+            # (-1)^(bit_w) along every wire of the parity: contract those axes with (1, -1)
+            sgn = torch.tensor([1.0, -1.0], dtype=torch.float64, device=states.device)
+            t = prob
+            for w in sorted(m, reverse=True):
+                t = torch.tensordot(t, sgn, dims=([1 + w], [0]))
+            cols.append(t.reshape(B, -1).sum(dim=1))
             continue
         k = len(ob.wires)
         M = torch.from_numpy(np.asarray(ob.matrix, dtype=np.complex128)).to(psi.device).reshape((2,) * (2 * k))
@@ -500,14 +518,15 @@ def run_expval_table(plan: N.Plan, table: np.ndarray, obs: Sequence[Operation], 
     parity = bool(obs) and all(m is not None for m in masks) and len(obs) <= 32
     out = []
     from . import memory
-    if table.dtype == np.float64:  # the complex128 engine (x64 mode): Z / Z-parity observables only
-        if not parity:
-            raise NotImplementedError("parameter shift in x64 mode needs Z / Z-parity observables")
+    if table.dtype == np.float64:  # the complex128 engine (x64 mode)
         chunk = max(1, memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]), "expval", False,
-                                                 len(obs), n_ops=plan.n_ops, x64=True))
+                                                 len(obs), n_ops=plan.n_ops, x64=True, general_obs=not parity))
         for r0 in range(0, table.shape[0], chunk):
             ang = torch.from_numpy(np.ascontiguousarray(table[r0:r0 + chunk])).cuda()
-            out.append(plan.run64(ang, "expval", masks).cpu().numpy())
+            if parity:
+                out.append(plan.run64(ang, "expval", masks).cpu().numpy())
+            else:  # PauliX / Hermitian ...: contracted with the complex128 states, like _simulate_x64
+                out.append(_x64_observables(plan.run64(ang, "state"), n_qubits, list(obs), masks).cpu().numpy())
         return np.concatenate(out, axis=0)
     chunk = memory.compute_chunk_size(n_qubits, min(max_rows, table.shape[0]),
                                       "expval" if (single_z or parity) else "state", False, len(obs),

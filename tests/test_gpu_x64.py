@@ -286,3 +286,35 @@ def test_x64_calls_chunk_instead_of_running_out_of_memory(monkeypatch):
     assert np.allclose(np.asarray(got_g), np.asarray(full_g), atol=1e-12)
     # and the float32 model would have let the state call through whole: 64 x 2^15 x 8 B = 16 MiB < 32 MiB
     assert memory.compute_chunk_size(n, 64, "state", False) == 64
+
+
+def test_mixed_observables_and_non_z_gradients_in_x64():
+    """a mixed Z / non-Z observable list reads every value off the ONE complex128 state it
+    holds (no re-run of the circuit per Z observable), and Script.gradient with a PauliX observable works
+    in x64 mode (it raised NotImplementedError): both against central differences / separate calls."""
+    from qml_essentials_amd import operations as op, utils
+    from qml_essentials_amd.script import Script
+
+    def circuit(a, b):
+        op.RY(a, wires=0)
+        op.RX(b, wires=1)
+        op.CX(wires=[0, 1])
+        op.RZ(a * b, wires=1)
+        op.H(wires=2)
+        op.CRX(b, wires=[2, 0])
+
+    obs = [op.PauliZ(0, record=False), op.PauliX(1, record=False), op.PauliZ(2, record=False), op.PauliY(0, record=False)]
+    a, b = 0.7, 1.3
+    with utils.x64_scope(True):
+        sc = Script(circuit, 3)
+        mixed = np.asarray(sc.execute(type="expval", obs=obs, args=(a, b)))
+        single = np.array([np.asarray(sc.execute(type="expval", obs=[o], args=(a, b)))[0] for o in obs])
+        assert mixed.dtype == np.float64 and np.abs(mixed - single).max() < 1e-14
+        (ga, gb) = sc.gradient(obs, args=(np.float64(a), np.float64(b)), argnums=(0, 1))
+        h = 1e-6
+        fa = (np.asarray(sc.execute(type="expval", obs=obs, args=(a + h, b)))
+              - np.asarray(sc.execute(type="expval", obs=obs, args=(a - h, b)))) / (2 * h)
+        fb = (np.asarray(sc.execute(type="expval", obs=obs, args=(a, b + h)))
+              - np.asarray(sc.execute(type="expval", obs=obs, args=(a, b - h)))) / (2 * h)
+    assert np.abs(np.asarray(ga).reshape(-1) - fa).max() < 1e-8
+    assert np.abs(np.asarray(gb).reshape(-1) - fb).max() < 1e-8
