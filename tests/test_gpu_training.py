@@ -191,3 +191,59 @@ def test_device_resident_adjoint_gradient_and_training():
     per_step = (time.time() - t0) / 200
     print(f"device-resident training step: {per_step * 1e3:.2f} ms")
     assert float(losses[-1]) < 0.1 * float(losses[0])
+
+
+def test_autograd_over_a_batch_of_parameter_sets():
+    """``differentiable(model)`` with ``params`` of shape (B_P, layers, n_params) --
+    the loops of the reference's tests/test_model.py:1097-1145 take batched parameters through jax.grad.
+    ONE adjoint sweep over the B_I x B_P batch; every set's gradient equals the gradient of the same loss
+    taken one set at a time, and central differences of the complex128 model; host tensors take the
+    one-set-at-a-time route and agree."""
+    import torch
+
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.torch_bridge import differentiable
+
+    rng = np.random.default_rng(9)
+    model = Model(n_qubits=5, n_layers=2, circuit_type="Circuit_19")
+    B_P, B_I = 3, 4
+    P = rng.uniform(0, 2 * np.pi, (B_P, *model.params.shape[1:])).astype(np.float32)
+    X = rng.uniform(0, 3, (B_I, 1)).astype(np.float32)
+    W = rng.normal(size=(B_I, B_P, 5)).astype(np.float32)
+    f = differentiable(model)
+    p = torch.tensor(P, device="cuda", requires_grad=True)
+    x = torch.tensor(X, device="cuda", requires_grad=True)
+    w = torch.tensor(W, device="cuda")
+    out = f(p, x)
+    assert tuple(out.shape) == (B_I, B_P, 5)
+    (out * w).sum().backward()
+    gp, gx = p.grad.cpu().numpy(), x.grad.cpu().numpy()
+    # one set at a time (the pre-existing single-set path)
+    for k in range(B_P):
+        pk = torch.tensor(P[k], device="cuda", requires_grad=True)
+        xk = torch.tensor(X, device="cuda", requires_grad=True)
+        (f(pk, xk) * w[:, k, :]).sum().backward()
+        assert np.abs(pk.grad.cpu().numpy() - gp[k]).max() < 2e-5, k
+    # central differences of the complex128 model on a few entries
+    m64 = Model(n_qubits=5, n_layers=2, circuit_type="Circuit_19", x64=True)
+
+    def loss64(Pd, Xd):
+        return float((np.asarray(m64(params=Pd, inputs=Xd)).reshape(B_I, B_P, 5) * W).sum())
+
+    h = 1e-5
+    for (k, l, j) in [(0, 0, 0), (1, 2, 3), (2, 1, P.shape[2] - 1)]:
+        Pp, Pm = P.astype(np.float64), P.astype(np.float64)
+        Pp[k, l, j] += h
+        Pm[k, l, j] -= h
+        fd = (loss64(Pp, X.astype(np.float64)) - loss64(Pm, X.astype(np.float64))) / (2 * h)
+        assert abs(fd - gp[k, l, j]) < 5e-4, ((k, l, j), fd, gp[k, l, j])
+    Xp, Xm = X.astype(np.float64), X.astype(np.float64)
+    Xp[1, 0] += h
+    Xm[1, 0] -= h
+    fdx = (loss64(P.astype(np.float64), Xp) - loss64(P.astype(np.float64), Xm)) / (2 * h)
+    assert abs(fdx - gx[1, 0]) < 1e-3
+    # host tensors: the same numbers through the one-set-at-a-time route
+    ph = torch.tensor(P, requires_grad=True)
+    xh = torch.tensor(X, requires_grad=True)
+    (f(ph, xh).cpu() * w.cpu()).sum().backward()
+    assert np.abs(ph.grad.numpy() - gp).max() < 2e-5 and np.abs(xh.grad.numpy() - gx).max() < 5e-5
