@@ -389,7 +389,19 @@ def k1_sweep(n=28, reps=24, warmup=8):
             ms, cnt, _ = plan.profile_end()
             per_wire.append(sum(ms) / max(1, sum(cnt)))
         gb = [bytes_per_amp * D / t / 1e6 for t in per_wire]
+        # what a controlled gate CAN get away with moving: a control on bit positions 0..3 sits inside every
+        # 128-byte line (16 amplitudes), so both control values share each line and all 16 D bytes must move
+        # whatever the kernel does; higher controls select whole lines and 8 D suffices (SURVEY 8-d's figure)
+        att = [bytes_per_amp] * n
+        if gate in ("CX", "CRX"):
+            att = [16 if (n - 1 - ((w + 1) % n)) <= 3 else 8 for w in range(n)]
+        gba = [a * D / t / 1e6 for a, t in zip(att, per_wire)]
         out[gate] = {"bytes_per_amplitude": bytes_per_amp,
+                     "attainable_bytes_per_amplitude_per_target_wire": att,
+                     "frac_of_8TBps_vs_attainable_min_mean_max": [round(min(gba) / HBM_PEAK_GBPS, 3),
+                                                                  round(float(np.mean(gba)) / HBM_PEAK_GBPS, 3),
+                                                                  round(max(gba) / HBM_PEAK_GBPS, 3)],
+                     "target_wires_at_0.70_or_more_of_attainable": int(sum(g / HBM_PEAK_GBPS >= 0.70 for g in gba)),
                      "ms_min_mean_max": [round(min(per_wire), 4), round(float(np.mean(per_wire)), 4),
                                          round(max(per_wire), 4)],
                      "frac_of_8TBps_min_mean_max": [round(min(gb) / HBM_PEAK_GBPS, 3),

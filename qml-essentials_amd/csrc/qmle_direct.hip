@@ -30,11 +30,14 @@ template <int MODE, bool DIAG, bool NT>
 __global__ void __launch_bounds__(256)
 k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
             const float *__restrict__ mats, uint32_t mat_floats, uint32_t mat_off,
-            uint64_t items) {
+            uint64_t items, uint32_t blk_mul) {
   const int b = blockIdx.y;
   const uint64_t chunks = (uint64_t)1 << (n - 1);
   float4 *st = states + (size_t)b * chunks;
-  const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  // blk_mul (odd, power-of-two grids only; 0 = off): workgroup i takes block (i * blk_mul) mod grid -- the
+  // workgroups in flight at any time are then spread over the whole state instead of one window of it
+  const uint32_t blk = blk_mul ? (blockIdx.x * blk_mul) & (gridDim.x - 1u) : blockIdx.x;
+  const uint64_t k = (uint64_t)blk * 256u + threadIdx.x;
   if (MODE < 5 && k >= items) return;  // modes 5 / 6 / 7: exact grids, whole waves
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
   if constexpr (MODE == 0) {
@@ -98,7 +101,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     // wave.  Every lane loads and stores contiguous float4s (coalesced like the diagonal gate)
     // and fetches the partner's through the cross-lane path; it computes its own half of the
     // pair only.  items = chunks / 2, two rows per lane.  (tools/k1_tune.hip: 0.76 -> 0.70 ms)
-    const uint64_t c0 = (uint64_t)blockIdx.x * 512u + threadIdx.x, c1 = c0 + 256u;
+    const uint64_t c0 = (uint64_t)blk * 512u + threadIdx.x, c1 = c0 + 256u;
     const bool up = (threadIdx.x >> (pt - 1)) & 1u;
     const float2 ms = up ? m.m11 : m.m00, mo = up ? m.m10 : m.m01;
     float4 v[2] = {ld4<NT>(st + c0), ld4<NT>(st + c1)};
@@ -120,7 +123,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     // diagonal gate -- one contiguous float4 per lane in, one out --, fetch the partner through
     // the cross-lane path and rewrite only the amplitudes whose control bit is set.  (A single-
     // gate LDS tile pass did this at 0.757 ms for n = 28; 8 D accounting: 0.35 -> 0.39.)
-    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;  // items = all chunks, exact grid
+    const uint64_t c = (uint64_t)blk * 256u + threadIdx.x;  // items = all chunks, exact grid
     const bool up = (threadIdx.x >> (pt - 1)) & 1u;
     const float2 ms = up ? m.m11 : m.m00, mo = up ? m.m10 : m.m01;
     const float4 v = ld4<NT>(st + c);
@@ -140,7 +143,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     // see fewer alternations between the two rows 2^pt amplitudes apart.  items = pairs / 4.
     // (tools/k1_tune.hip: 0.75-0.79 -> 0.70 ms for bits 21..27)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t row0 = ((uint64_t)blockIdx.x * 4u + wave) * 4u;
+    const uint64_t row0 = ((uint64_t)blk * 4u + wave) * 4u;
     float4 v0[4], v1[4];
     uint64_t c0[4];
 #pragma unroll
@@ -218,10 +221,10 @@ __global__ void __launch_bounds__(256) k_fill_zero(float4 *__restrict__ p, uint6
 template <int MODE>
 void launch_direct_mode(bool diag, bool nt, dim3 grid, hipStream_t stream, float4 *st, int n,
                         int pt, int pc, const float *mats, uint32_t mat_floats,
-                        uint32_t mat_off, uint64_t items) {
+                        uint32_t mat_off, uint64_t items, uint32_t blk_mul) {
 #define QMLE_LAUNCH_DIRECT(D, N)                                                              \
   hipLaunchKernelGGL((k_direct_1q<MODE, D, N>), grid, dim3(256), 0, stream, st, n, pt, pc, mats, \
-                     mat_floats, mat_off, items)
+                     mat_floats, mat_off, items, blk_mul)
   if (diag) { if (nt) QMLE_LAUNCH_DIRECT(true, true); else QMLE_LAUNCH_DIRECT(true, false); }
   else { if (nt) QMLE_LAUNCH_DIRECT(false, true); else QMLE_LAUNCH_DIRECT(false, false); }
 #undef QMLE_LAUNCH_DIRECT
@@ -263,15 +266,29 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
   const bool nt = ((size_t)batch << n) * sizeof(float2) >= ((size_t)1 << 30);
   dim3 grid((unsigned)((items + 255) / 256), (unsigned)batch);
   float4 *st = reinterpret_cast<float4 *>(states);
+  // A control on bit position 7 or 8 is byte-address bit 10 / 11: the gate touches 2 KiB (1 KiB) on, 2 KiB
+  // (1 KiB) off, and with workgroups visiting that half in ascending order the HBM channels behind the L2
+  // are loaded unevenly (round 3: even TCC_EA0 requests per channel, uneven DRAM credit stalls; 0.50 / 0.44
+  // ms at n = 28 where the neighbouring wires take 0.35 - 0.38).  Spreading the workgroups IN FLIGHT over
+  // the whole state -- workgroup i takes block i * 4097 mod grid, ~32 MiB apart -- brings both to 0.38 ms
+  // (tools/k1_block_order.py, profiles/r04_k1_block_order.txt); every other control position streams best
+  // in ascending order (+2 ... +15 % with any multiplier), so only these two get it.
+  // QMLE_K1_BLOCK_MUL=<odd | 0> overrides (read per launch).
+  uint32_t blk_mul = 0;
+  if (op.nc && mode == 2 && (grid.x & (grid.x - 1u)) == 0 && items == (uint64_t)grid.x * 256u) {
+    if (!diag && (pc == 7 || pc == 8) && n >= 24 && grid.x > 4097u) blk_mul = 4097u;
+    const char *e = std::getenv("QMLE_K1_BLOCK_MUL");
+    if (e) blk_mul = atoi(e) > 0 ? ((uint32_t)atoi(e) | 1u) : 0u;
+  }
   switch (mode) {
-    case 0: launch_direct_mode<0>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 1: launch_direct_mode<1>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 2: launch_direct_mode<2>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 3: launch_direct_mode<3>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 5: launch_direct_mode<5>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    case 7: launch_direct_mode<7>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
-    default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items); break;
+    case 0: launch_direct_mode<0>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 1: launch_direct_mode<1>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 2: launch_direct_mode<2>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 3: launch_direct_mode<3>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 5: launch_direct_mode<5>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 7: launch_direct_mode<7>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
   }
   HIPCHK(hipGetLastError());
   return QMLE_OK;

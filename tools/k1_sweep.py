@@ -9,3 +9,5 @@ for g, v in bench.k1_sweep().items():
     print(g, "bytes/amp", v["bytes_per_amplitude"], "ms min/mean/max", v["ms_min_mean_max"],
           "frac of 8 TB/s min/mean/max", v["frac_of_8TBps_min_mean_max"], "slowest wire", v["slowest_target_wire"])
     print("   ms per target wire 0..27:", v["ms_per_target_wire"])
+    print("   vs attainable bytes: frac min/mean/max", v["frac_of_8TBps_vs_attainable_min_mean_max"],
+          "wires at >= 0.70:", v["target_wires_at_0.70_or_more_of_attainable"], "of", len(v["ms_per_target_wire"]))
