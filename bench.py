@@ -278,7 +278,7 @@ def load_traffic(key, path=None, sha=None):
     have = sha or source_sha16()
     if want != have:
         msg = (f"STALE: PMC record {key!r} was collected for kernel sources {want}, this tree is {have}; "
-               f"re-run tools/collect_profiles_r03.sh on a GPU box")
+               f"re-run tools/collect_profiles_r04.sh on a GPU box")
         print("bench.py: " + msg, file=sys.stderr)
         return None, None, None, msg
     return rec["hbm_bytes_per_launch"], rec.get("source"), rec.get("states_per_launch"), None
@@ -418,23 +418,28 @@ VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak, /opt/skills/guides/MI355X_M
 
 
 def _wall(fn, reps):
-    """Median wall-clock of `fn` over `reps` calls, each bracketed by synchronize + barrier;
-    max over ranks per call (the job is done when the slowest rank is).  Also the GPU's share:
-    HIP events on the launch stream around the call (first launch enqueued -> last kernel done),
-    median over the calls on this rank."""
+    """Median wall-clock of `fn` over `reps` calls -- `fn` returns HOST values, so a call is complete
+    when it returns; each call starts from a synchronised device and a barrier, and counts as the
+    max over ranks (the job is done when the slowest rank is).  Then, in calls of their own (an
+    event record costs the host ~5 us, which the wall-clock of a 0.2 ms call should not carry), the
+    GPU's share: HIP events on the launch stream around the call (first launch enqueued -> last
+    kernel done), median over the calls on this rank."""
     from qml_essentials_amd import distributed
 
     ts, gs = [], []
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(reps):
         torch.cuda.synchronize()
         distributed.barrier()
         t0 = time.perf_counter()
-        e0.record()
         out = fn()
+        ts.append(max(max_over_ranks(time.perf_counter() - t0)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(max(max_over_ranks(time.perf_counter() - t0)))
         gs.append(e0.elapsed_time(e1))
     return sorted(ts)[len(ts) // 2], out, sorted(gs)[len(gs) // 2]
 
@@ -466,6 +471,7 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
     expval averaged over the wires; the GRID is split over the ranks (512 points per GPU at N = 8),
     one all-gather of (4096, 10) floats; the FFT of the 4096 values runs on the host."""
     from qml_essentials_amd import distributed
+    from qml_essentials_amd.coefficients import Coefficients
     from qml_essentials_amd.model import Model
 
     m = Model(n, layers, "Hardware_Efficient")
@@ -473,9 +479,9 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
 
     def call():
         # what Coefficients._fourier_transform does with its own (device-resident) grid: one
-        # device -> host copy of the 4096 values, float64 FFT on the host (25 us)
+        # device -> host copy of the 4096 values, float64 real-input FFT on the host (16 us)
         y = m(inputs=x, force_mean=True)
-        return np.fft.fft(y.cpu().numpy().astype(np.float64)) / points
+        return Coefficients._fft_real(y.cpu().numpy().astype(np.float64))
 
     for _ in range(3):
         call()

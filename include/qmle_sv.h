@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 147 /* 0.1.4.7: qmle_plan_executed (qmle_plan_expval_child = the folded child only); 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 148 /* 0.1.4.7: qmle_plan_executed (qmle_plan_expval_child = the folded child only); 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -225,6 +225,26 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
                       const float *d_coef, const float *d_const, const double *d_period,
                       int n_slots, int64_t batch, int64_t batch_offset, float *d_out,
                       qmle_stream stream);
+
+/* qmle_build_angles + qmle_run_batch behind ONE call (the Model's device route: its angle map is all the
+ * host holds, model.py:804-816 / ansaetze.py:323-371).  `map` carries qmle_build_angles' arguments;
+ * d_angles [batch][plan n_slots] float32 is scratch the call fills and then reads (may be NULL for a plan
+ * without slots).  Same results as the two calls; the host's time between the two launches -- 8-14 us of an
+ * idle GPU in the 0.2 ms analysis loops of BASELINE configs 3 / 4 -- is gone. */
+typedef struct qmle_angle_map {
+  const float *const *d_leaves;   /* HOST array of n_leaves device pointers */
+  const int64_t *leaf_strides;    /* HOST */
+  const int32_t *leaf_div;        /* HOST */
+  const int32_t *leaf_mod;        /* HOST */
+  int32_t n_leaves;
+  const int32_t *d_ptr, *d_arg, *d_idx;
+  const float *d_coef, *d_const;
+  const double *d_period;         /* may be NULL */
+  int64_t batch_offset;
+} qmle_angle_map;
+int qmle_run_batch_map(qmle_plan *plan, const qmle_angle_map *map, float *d_angles, int batch,
+                       int meas_type, const int32_t *obs_wires, int n_obs, void *d_out,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream);
 
 /* Apply the plan's passes in place to resident states [batch][2^n] complex64 (no
  * initialisation, no measurement) -- the per-gate loop simulation.py:102-103 alone.

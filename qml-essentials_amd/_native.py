@@ -83,6 +83,44 @@ class QmleOp(C.Structure):
     ]
 
 
+class QmleAngleMap(C.Structure):
+    """qmle_angle_map (include/qmle_sv.h): qmle_build_angles' arguments for qmle_run_batch_map."""
+    _fields_ = [
+        ("d_leaves", C.POINTER(C.c_void_p)),
+        ("leaf_strides", C.POINTER(C.c_int64)),
+        ("leaf_div", C.POINTER(C.c_int32)),
+        ("leaf_mod", C.POINTER(C.c_int32)),
+        ("n_leaves", C.c_int32),
+        ("d_ptr", C.c_void_p), ("d_arg", C.c_void_p), ("d_idx", C.c_void_p),
+        ("d_coef", C.c_void_p), ("d_const", C.c_void_p), ("d_period", C.c_void_p),
+        ("batch_offset", C.c_int64),
+    ]
+
+
+class AngleMapArgs:
+    """A reusable qmle_angle_map: the map's device arrays are fixed, the leaves change per call."""
+
+    def __init__(self, n_leaves, d_ptr, d_arg, d_idx, d_coef, d_const, d_period):
+        k = max(1, n_leaves)
+        self.lp, self.ls = (C.c_void_p * k)(), (C.c_int64 * k)()
+        self.ld, self.lm = (C.c_int32 * k)(), (C.c_int32 * k)()
+        self._keep = (d_ptr, d_arg, d_idx, d_coef, d_const, d_period)
+        self.c = QmleAngleMap(C.cast(self.lp, C.POINTER(C.c_void_p)), C.cast(self.ls, C.POINTER(C.c_int64)),
+                              C.cast(self.ld, C.POINTER(C.c_int32)), C.cast(self.lm, C.POINTER(C.c_int32)),
+                              n_leaves, d_ptr.data_ptr(), d_arg.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(),
+                              d_const.data_ptr(), d_period.data_ptr() if d_period is not None else None, 0)
+        self.ref = C.byref(self.c)
+
+    def set(self, leaves, strides, divs, mods, batch_offset=0):
+        for k, t in enumerate(leaves):
+            self.lp[k] = t.data_ptr()
+            self.ls[k] = int(strides[k])
+            self.ld[k] = int(divs[k])
+            self.lm[k] = int(mods[k])
+        self.c.batch_offset = int(batch_offset)
+        return self
+
+
 _lib = None
 
 # Opt-in plan autotuner (QMLE_AUTOTUNE=1 or set_autotune(True)): a plan's first "state" / "expval" run on
@@ -117,6 +155,7 @@ SYMBOLS = [
     ("qmle_build_angles", _I, [C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32), _I, _VP, _VP, _VP, _VP, _VP, _VP, _I,
                                C.c_int64, C.c_int64, _VP, _VP]),
+    ("qmle_run_batch_map", _I, [_VP, _VP, _VP, _I, _I, C.POINTER(C.c_int32), _I, _VP, _VP, _SZ, _VP]),
     ("qmle_apply_inplace", _I, [_VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     ("qmle_profile_begin", _I, [_VP, _I]),
     ("qmle_profile_end", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
@@ -386,6 +425,30 @@ class Plan:
                     raise
         raise torch.OutOfMemoryError("qmle workspace")
 
+    def _out(self, B: int, meas: str, n_obs: int, dev):
+        torch = require_gpu()
+        D = 1 << self.n_qubits
+        if meas == "state":
+            return torch.empty((B, D), dtype=torch.complex64, device=dev)
+        if meas == "probs":
+            return torch.empty((B, D), dtype=torch.float32, device=dev)
+        if meas == "expval":
+            return torch.empty((B, n_obs), dtype=torch.float32, device=dev)
+        if meas == "mw":  # (Q, purity of wire 0 .. n-1) per state: QMLE_MEAS_MEYER_WALLACH
+            return torch.empty((B, self.n_qubits + 1), dtype=torch.float32, device=dev)
+        return torch.empty((B, D, D), dtype=torch.complex64, device=dev)
+
+    def _tune_once(self, meas: str, n_obs: int, B: int) -> bool:
+        """Opt-in autotuner: the plan's first run of this measurement times the candidates."""
+        if not (_AUTOTUNE and meas in ("state", "expval")):
+            return False
+        tuned = self.__dict__.setdefault("_tuned", set())
+        if meas in tuned:
+            return False
+        tuned.add(meas)
+        self.autotune(meas, n_obs, batch=B)
+        return True  # (a workspace sized for the old schedule is void)
+
     def run(self, angles, meas: str, obs_wires: Sequence[int] = (), out=None, workspace=None,
             states_in_flight: int = 0):
         """simulate_and_measure for a batch.  ``angles``: float32 cuda tensor [B, n_slots]."""
@@ -400,25 +463,11 @@ class Plan:
         if angles.dim() != 2 or (self.n_slots and angles.shape[1] != self.n_slots):
             raise ValueError(f"angles must be [B, {self.n_slots}], got {tuple(angles.shape)}")
         B = int(angles.shape[0])
-        D = 1 << self.n_qubits
         n_obs = len(obs_wires)
         if out is None:
-            if meas == "state":
-                out = torch.empty((B, D), dtype=torch.complex64, device=dev)
-            elif meas == "probs":
-                out = torch.empty((B, D), dtype=torch.float32, device=dev)
-            elif meas == "expval":
-                out = torch.empty((B, n_obs), dtype=torch.float32, device=dev)
-            elif meas == "mw":  # (Q, purity of wire 0 .. n-1) per state: QMLE_MEAS_MEYER_WALLACH
-                out = torch.empty((B, self.n_qubits + 1), dtype=torch.float32, device=dev)
-            else:
-                out = torch.empty((B, D, D), dtype=torch.complex64, device=dev)
-        if _AUTOTUNE and meas in ("state", "expval"):
-            tuned = self.__dict__.setdefault("_tuned", set())
-            if meas not in tuned:
-                tuned.add(meas)
-                self.autotune(meas, n_obs, batch=B)
-                workspace = None  # (sized for the old schedule)
+            out = self._out(B, meas, n_obs, dev)
+        if self._tune_once(meas, n_obs, B):
+            workspace = None
         workspace = self._workspace(B, meas, n_obs, states_in_flight, workspace, dev)
         rc = lib().qmle_run_batch(
             self._h, C.c_void_p(angles.data_ptr()), B, MEAS[meas], _i32(obs_wires), n_obs,
@@ -426,6 +475,29 @@ class Plan:
             C.c_size_t(workspace.numel()), _stream_ptr(),
         )
         check(rc, "qmle_run_batch")
+        return out
+
+    def run_map(self, amap: "AngleMapArgs", B: int, meas: str, obs_wires: Sequence[int] = (), out=None,
+                workspace=None):
+        """:meth:`run` with the angle table built inside the same native call (qmle_run_batch_map):
+        ``amap`` holds the affine map and this call's leaves; the table itself is scratch."""
+        torch = require_gpu()
+        if meas not in MEAS:
+            raise ValueError(f"Unknown measurement type: {meas!r}")  # simulation.py:271
+        dev = current_device()
+        n_obs = len(obs_wires)
+        angles = torch.empty((B, max(1, self.n_slots)), dtype=torch.float32, device=dev)
+        if out is None:
+            out = self._out(B, meas, n_obs, dev)
+        if self._tune_once(meas, n_obs, B):
+            workspace = None
+        workspace = self._workspace(B, meas, n_obs, 0, workspace, dev)
+        rc = lib().qmle_run_batch_map(
+            self._h, amap.ref, C.c_void_p(angles.data_ptr()), B, MEAS[meas], _i32(obs_wires), n_obs,
+            C.c_void_p(out.data_ptr()), C.c_void_p(workspace.data_ptr()),
+            C.c_size_t(workspace.numel()), _stream_ptr(),
+        )
+        check(rc, "qmle_run_batch_map")
         return out
 
     def run64(self, angles, meas: str, wire_groups: Sequence[Sequence[int]] = ()):

@@ -42,28 +42,41 @@ struct AngleLeaves {
   int div[8], mod[8];
 };
 
+// One work item per (state, slot), a block = (256 / L) states x L slot lanes (L = 4 .. 256 by the slot
+// count): the leaf rows of a state -- (b / div) % mod, the only divisions -- are taken once per work item and
+// leaf instead of once per term, in 32 bits when the batch allows (a 64-bit division is ~100 instructions and
+// the kernel was 8.6 us for the 4096 x 270 table of the Fourier grid, as long as its dependent loads).
+template <class IDX>
 __global__ void __launch_bounds__(256)
-k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restrict__ arg,
+k_build_angles(AngleLeaves lv, int n_leaves, const int *__restrict__ ptr, const int *__restrict__ arg,
                const int *__restrict__ idx, const float *__restrict__ coef,
-               const float *__restrict__ cst, const double *__restrict__ period, int n_slots,
+               const float *__restrict__ cst, const double *__restrict__ period, int n_slots, int lgL,
                long long batch, long long b_offset, float *__restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= batch * n_slots) return;
-  const long long b = i / n_slots;
-  const int s = (int)(i - b * n_slots);
-  const long long gb = b + b_offset;
-  // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
-  // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
-  // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
-  double acc = (double)cst[s];
-  for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
-    const int k = arg[t];
-    const long long row = (gb / lv.div[k]) % lv.mod[k];
-    acc = fma((double)coef[t], (double)lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
+  const int L = 1 << lgL, sl = threadIdx.x & (L - 1);
+  const long long b = (long long)blockIdx.x * (256 >> lgL) + (threadIdx.x >> lgL);
+  if (b >= batch) return;
+  const IDX gb = (IDX)(b + b_offset);
+  long long row[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    row[k] = k < n_leaves ? (long long)((gb / (IDX)lv.div[k]) % (IDX)lv.mod[k]) * lv.stride[k] : 0;
+  float *o = out + b * n_slots;
+  for (int s = sl; s < n_slots; s += L) {
+    // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
+    // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
+    // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
+    double acc = (double)cst[s];
+    for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
+      const int k = arg[t];
+      long long r = row[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) r = k == j ? row[j] : r;  // (no run-time index into the register array)
+      acc = fma((double)coef[t], (double)lv.ptr[k][r + idx[t]], acc);
+    }
+    const double per = period ? period[s] : 0.0;
+    if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
+    o[s] = (float)acc;
   }
-  const double per = period ? period[s] : 0.0;
-  if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
-  out[i] = (float)acc;
 }
 
 }  // namespace
@@ -377,15 +390,20 @@ static size_t expval_partial_rows(const qmle_plan *p) {
 // next-tile prefetch) costs the pass as much as the read it saves: n = 28, 0.68 ms instead of 0.47 for the
 // pass + two reads = 1.01 ms after the circuit against 0.99 ms for the three reads of the stand-alone
 // kernels -- so tiled plans keep the stand-alone reads unless QMLE_MW_FUSE_TILED=1 (read per call: A/B, tests).
-static bool plan_mw_fusable(const qmle_plan *p) {
-  if (std::getenv("QMLE_NO_MW_FUSION") != nullptr || p->stages.empty()) return false;
+static bool plan_mw_fusable(const qmle_plan *p, bool whatever_the_switches = false) {
+  if (p->stages.empty()) return false;
   const Stage &last = p->stages.back();
-  if (last.T < p->n && std::getenv("QMLE_MW_FUSE_TILED") == nullptr) return false;
+  if (!whatever_the_switches) {
+    if (std::getenv("QMLE_NO_MW_FUSION") != nullptr) return false;
+    if (last.T < p->n && std::getenv("QMLE_MW_FUSE_TILED") == nullptr) return false;
+  }
   return mw_fusable(p->n, last);
 }
 // rows + purities of `batch` states (conservative per state: the rows per state shrink with the batch)
 static size_t mw_ws_bytes(const qmle_plan *p, int batch) {
-  const size_t one = plan_mw_fusable(p) ? mw_fused_ws_bytes(p->n, 1, p->stages.back()) : mw_resident_ws_bytes(p->n, 1);
+  // (enough for either route: the switches are read per call, a workspace sized before one was flipped stays valid)
+  size_t one = mw_resident_ws_bytes(p->n, 1);
+  if (plan_mw_fusable(p, true)) one = std::max(one, mw_fused_ws_bytes(p->n, 1, p->stages.back()));
   return align_up(one, 256) * (size_t)batch;
 }
 
@@ -956,12 +974,35 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
     lv.div[k] = leaf_div[k];
     lv.mod[k] = leaf_mod[k];
   }
-  const uint64_t total = (uint64_t)batch * (uint64_t)n_slots;
-  hipLaunchKernelGGL(k_build_angles, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     lv, d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, (long long)batch,
-                     (long long)batch_offset, d_out);
+  int lgL = 2;
+  while (lgL < 8 && (1 << lgL) < n_slots) lgL += 2;
+  const uint64_t blocks = ((uint64_t)batch + (256u >> lgL) - 1) / (256u >> lgL);
+  if (blocks > 0x7fffffffull) return QMLE_ERR_INVALID_ARG;
+  if ((uint64_t)batch + (uint64_t)batch_offset < (1ull << 32) && batch_offset >= 0)
+    hipLaunchKernelGGL(k_build_angles<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, lv, n_leaves,
+                       d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, lgL, (long long)batch,
+                       (long long)batch_offset, d_out);
+  else
+    hipLaunchKernelGGL(k_build_angles<long long>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, lv, n_leaves,
+                       d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, lgL, (long long)batch,
+                       (long long)batch_offset, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
+}
+
+int qmle_run_batch_map(qmle_plan *plan, const qmle_angle_map *map, float *d_angles, int batch,
+                       int meas_type, const int32_t *obs_wires, int n_obs, void *d_out,
+                       void *d_workspace, size_t workspace_bytes, qmle_stream stream) {
+  if (!plan || !map || batch < 1) return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots > 0) {
+    if (!d_angles) return QMLE_ERR_INVALID_ARG;
+    const int rc = qmle_build_angles(map->d_leaves, map->leaf_strides, map->leaf_div, map->leaf_mod, map->n_leaves,
+                                     map->d_ptr, map->d_arg, map->d_idx, map->d_coef, map->d_const, map->d_period,
+                                     plan->n_slots, batch, map->batch_offset, d_angles, stream);
+    if (rc != QMLE_OK) return rc;
+  }
+  return qmle_run_batch(plan, d_angles, batch, meas_type, obs_wires, n_obs, d_out, d_workspace, workspace_bytes,
+                        stream);
 }
 
 int qmle_profile_begin(qmle_plan *plan, int capacity) {

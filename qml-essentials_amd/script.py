@@ -97,6 +97,19 @@ class CompiledCall:
         overrides the call's measurement with another one of the same circuit ("mw": Meyer-Wallach
         out of the producing pass, for a call compiled for "state")."""
         strides = [t[0].numel() if t.shape[0] else 0 for t in leaves]
+        kind = meas if meas is not None and meas != self.type else self.type
+        arg = ()
+        if kind == "expval":
+            how, arg = self._measure()
+            if how != "z":
+                kind = None
+        if kind is not None and self.n_slots:
+            # one native call: angle table (scratch) + the batch -- no host time between the two launches
+            am = getattr(self, "_amap", None)
+            if am is None:
+                am = self._amap = N.AngleMapArgs(len(self.leaf_ids), self.d_ptr, self.d_arg, self.d_idx, self.d_coef,
+                                                 self.d_const, self.d_period)
+            return self.plan.run_map(am.set(leaves, strides, divs, mods, batch_offset), batch, kind, arg)
         angles = N.build_angles(leaves, strides, divs, mods, self.d_ptr, self.d_arg, self.d_idx,
                                 self.d_coef, self.d_const, self.n_slots, batch, batch_offset,
                                 d_period=self.d_period)
@@ -106,10 +119,10 @@ class CompiledCall:
         if meas is not None and meas != self.type:
             return self.plan.run(angles, meas)
         if self.type == "expval":
-            kind, arg = self._measure()
-            if kind == "z":
+            how, arg = self._measure()
+            if how == "z":
                 return self.plan.run(angles, "expval", arg)
-            if kind == "parity":
+            if how == "parity":
                 return self.plan.run_parity(angles, arg)
             return simulation._general_expval(self.plan.run(angles, "state"), self.n_qubits, self.obs)
         return self.plan.run(angles, self.type)

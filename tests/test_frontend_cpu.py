@@ -253,3 +253,17 @@ def test_entanglement_density_matrix_helpers_host_math():
     rhos = np.stack([np.outer(bell, bell.conj()), np.outer(prod, prod.conj())])
     eof = Entanglement._compute_entanglement_of_formation(rhos, 2, always_decompose=False)
     assert np.allclose(eof, [1.0, 0.0], atol=1e-12)
+
+
+def test_real_input_fft_equals_the_complex_transform_and_is_exactly_hermitian():
+    """Coefficients._fft_real (rfft + conjugate mirror) against fft / N of coefficients.py:143-150:
+    odd and even lengths, one and several output columns; c_k == conj(c_-k) bit for bit."""
+    from qml_essentials_amd.coefficients import Coefficients
+
+    rng = np.random.default_rng(3)
+    for n in (3, 4, 5, 8, 9, 120, 121, 4096):
+        for shape in ((n,), (n, 3)):
+            v = rng.standard_normal(shape)
+            got = Coefficients._fft_real(v)
+            np.testing.assert_allclose(got, np.fft.fft(v, axis=0) / n, rtol=0, atol=1e-15)
+            assert np.array_equal(got[1:], np.conj(got[1:][::-1]))

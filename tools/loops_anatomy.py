@@ -29,7 +29,7 @@ def legs():
 
     def c4():
         y = m4(inputs=x4, force_mean=True)
-        return np.fft.fft(y.cpu().numpy().astype(np.float64)) / 4096
+        return Coefficients._fft_real(y.cpu().numpy().astype(np.float64))
 
     return {
         "c3": lambda: Expressibility.kl_divergence_to_haar(m3, n_samples=1024, n_bins=75, random_key=1000),
@@ -51,14 +51,17 @@ def main():
         reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         walls, gpus = [], []
-        for _ in range(reps):
+        for _ in range(reps):  # wall: the call alone (it returns host values); GPU share: calls of their own
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            fn()
+            walls.append(time.perf_counter() - t0)
+        for _ in range(reps):
+            torch.cuda.synchronize()
             e0.record()
             fn()
             e1.record()
             torch.cuda.synchronize()
-            walls.append(time.perf_counter() - t0)
             gpus.append(e0.elapsed_time(e1))
         walls.sort(), gpus.sort()
         print(f"{name}: wall median {walls[reps // 2] * 1e3:.3f} ms (min {walls[0] * 1e3:.3f}), "
