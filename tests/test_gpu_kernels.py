@@ -958,3 +958,49 @@ def test_device_parameter_sampler_is_numpys_stream_bit_for_bit():
     finally:
         del os.environ["QMLE_HOST_SAMPLER"]
     assert a.dtype == np.float32 and a.shape == (2048, 3, 12) and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset", [0, 5, (1 << 33) + 3])
+def test_angle_table_and_batch_behind_one_call_equal_the_two_calls(offset):
+    """qmle_run_batch_map == qmle_build_angles + qmle_run_batch bit for bit (model.py:804-816: the affine
+    angle map; model.py:1449-1481: rows of the cartesian inputs x params batch), with a batch offset in
+    the 32-bit and in the 64-bit range of the row arithmetic; the table against the host formula."""
+    import torch
+
+    from qml_essentials_amd import _native as N
+    from qml_essentials_amd.model import Model
+
+    m = Model(6, 2, "Hardware_Efficient")
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.uniform(0, 6.28, (7, 1)).astype(np.float32)).cuda()
+    p = torch.from_numpy(rng.uniform(0, 6.28, (3, *m.params.shape[-2:])).astype(np.float32)).cuda()
+    cc, leaves, divs, mods, B = m._forward_device(p, x, None, "expval", False, _want_call=True)
+    assert B == 21 and cc.n_slots > 0
+    strides = [t[0].numel() for t in leaves]
+    how, wires = cc._measure()
+    assert how == "z"
+    table = N.build_angles(leaves, strides, divs, mods, cc.d_ptr, cc.d_arg, cc.d_idx, cc.d_coef, cc.d_const,
+                           cc.n_slots, B, offset, d_period=cc.d_period)
+    two = cc.plan.run(table, "expval", wires)
+    one = cc.run(leaves, divs, mods, B, offset)
+    assert torch.equal(one, two)
+    # the table itself: const + sum coef * leaf[row(b)][idx], rows from the flattened sample index
+    ptr, arg, idx, coef = cc._map
+    host = [t.cpu().numpy().reshape(t.shape[0], -1).astype(np.float64) for t in leaves]
+    cst = cc.d_const.cpu().numpy().astype(np.float64)
+    per = cc.d_period.cpu().numpy()
+    want = np.zeros((B, cc.n_slots))
+    for b in range(B):
+        gb = b + offset
+        for s in range(cc.n_slots):
+            acc = cst[s]
+            for t in range(ptr[s], ptr[s + 1]):
+                k = arg[t]
+                acc += float(coef[t]) * host[k][(gb // divs[k]) % mods[k], idx[t]]
+            if per[s] > 0 and abs(acc) > per[s]:
+                acc -= per[s] * np.rint(acc / per[s])
+            want[b, s] = acc
+    np.testing.assert_allclose(table.cpu().numpy(), want, rtol=0, atol=2e-6)
+    if offset == 0:
+        np.testing.assert_allclose(m(params=p, inputs=x).cpu().numpy().reshape(one.shape), one.cpu().numpy(), rtol=0, atol=0)
