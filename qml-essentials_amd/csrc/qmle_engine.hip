@@ -42,41 +42,33 @@ struct AngleLeaves {
   int div[8], mod[8];
 };
 
-// One work item per (state, slot), a block = (256 / L) states x L slot lanes (L = 4 .. 256 by the slot
-// count): the leaf rows of a state -- (b / div) % mod, the only divisions -- are taken once per work item and
-// leaf instead of once per term, in 32 bits when the batch allows (a 64-bit division is ~100 instructions and
-// the kernel was 8.6 us for the 4096 x 270 table of the Fourier grid, as long as its dependent loads).
+// One work item per (state, slot), flattened (every lane busy whatever the slot count: a block-per-state
+// layout with the divisions hoisted out of the term loop measured 6.5 instead of 4.1 us for the 2048 x 108
+// table of the Expressibility loop -- the kernel is a chain of three dependent loads, not arithmetic).
+// IDX: 32-bit index arithmetic when batch x slots and batch + offset allow, 64-bit otherwise.
 template <class IDX>
 __global__ void __launch_bounds__(256)
-k_build_angles(AngleLeaves lv, int n_leaves, const int *__restrict__ ptr, const int *__restrict__ arg,
+k_build_angles(AngleLeaves lv, const int *__restrict__ ptr, const int *__restrict__ arg,
                const int *__restrict__ idx, const float *__restrict__ coef,
-               const float *__restrict__ cst, const double *__restrict__ period, int n_slots, int lgL,
+               const float *__restrict__ cst, const double *__restrict__ period, int n_slots,
                long long batch, long long b_offset, float *__restrict__ out) {
-  const int L = 1 << lgL, sl = threadIdx.x & (L - 1);
-  const long long b = (long long)blockIdx.x * (256 >> lgL) + (threadIdx.x >> lgL);
-  if (b >= batch) return;
-  const IDX gb = (IDX)(b + b_offset);
-  long long row[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    row[k] = k < n_leaves ? (long long)((gb / (IDX)lv.div[k]) % (IDX)lv.mod[k]) * lv.stride[k] : 0;
-  float *o = out + b * n_slots;
-  for (int s = sl; s < n_slots; s += L) {
-    // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
-    // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
-    // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
-    double acc = (double)cst[s];
-    for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
-      const int k = arg[t];
-      long long r = row[0];
-#pragma unroll
-      for (int j = 1; j < 8; ++j) r = k == j ? row[j] : r;  // (no run-time index into the register array)
-      acc = fma((double)coef[t], (double)lv.ptr[k][r + idx[t]], acc);
-    }
-    const double per = period ? period[s] : 0.0;
-    if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
-    o[s] = (float)acc;
+  const IDX i = (IDX)blockIdx.x * 256u + threadIdx.x;
+  if ((long long)i >= batch * n_slots) return;
+  const IDX b = i / (IDX)n_slots;
+  const int s = (int)(i - b * (IDX)n_slots);
+  const IDX gb = b + (IDX)b_offset;
+  // fp64 accumulation, then reduction into (-period/2, period/2] (4 pi for a rotation gate, which
+  // depends on angle / 2 only): binary / ternary encodings scale inputs by up to 3^(n-1), and a
+  // float32 angle of ~1500 rad would carry 1e-4 rad of rounding into the gate matrices
+  double acc = (double)cst[s];
+  for (int t = ptr[s]; t < ptr[s + 1]; ++t) {
+    const int k = arg[t];
+    const long long row = (long long)((gb / (IDX)lv.div[k]) % (IDX)lv.mod[k]);
+    acc = fma((double)coef[t], (double)lv.ptr[k][row * lv.stride[k] + idx[t]], acc);
   }
+  const double per = period ? period[s] : 0.0;
+  if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
+  out[i] = (float)acc;
 }
 
 }  // namespace
@@ -974,17 +966,14 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
     lv.div[k] = leaf_div[k];
     lv.mod[k] = leaf_mod[k];
   }
-  int lgL = 2;
-  while (lgL < 8 && (1 << lgL) < n_slots) lgL += 2;
-  const uint64_t blocks = ((uint64_t)batch + (256u >> lgL) - 1) / (256u >> lgL);
-  if (blocks > 0x7fffffffull) return QMLE_ERR_INVALID_ARG;
-  if ((uint64_t)batch + (uint64_t)batch_offset < (1ull << 32) && batch_offset >= 0)
-    hipLaunchKernelGGL(k_build_angles<uint32_t>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, lv, n_leaves,
-                       d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, lgL, (long long)batch,
+  const uint64_t total = (uint64_t)batch * (uint64_t)n_slots;
+  if (total + 256 < (1ull << 32) && batch_offset >= 0 && (uint64_t)batch + (uint64_t)batch_offset < (1ull << 32))
+    hipLaunchKernelGGL(k_build_angles<uint32_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, lv,
+                       d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, (long long)batch,
                        (long long)batch_offset, d_out);
   else
-    hipLaunchKernelGGL(k_build_angles<long long>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, lv, n_leaves,
-                       d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, lgL, (long long)batch,
+    hipLaunchKernelGGL(k_build_angles<unsigned long long>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       lv, d_ptr, d_arg, d_idx, d_coef, d_const, d_period, n_slots, (long long)batch,
                        (long long)batch_offset, d_out);
   HIPCHK(hipGetLastError());
   return QMLE_OK;

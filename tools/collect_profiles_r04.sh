@@ -9,8 +9,6 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-echo "[1] bench line"; python3 $R/bench.py > $OUT/bench.log 2> $OUT/bench.err
-tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench_n1.json
 echo "[2] kernel stats of the headline command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- \
   python3 $R/bench.py --steps 2 --warmup 1 --skip-aux > $OUT/stats.log 2>&1
@@ -58,5 +56,9 @@ echo "[8] whole-state regime, deep circuits, configs"
 python3 tools/whole_state_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_ws_bench_after.txt || true
 python3 tools/accum_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_accum_probe.txt || true
 python3 tools/configs_bench.py 2>/dev/null | grep "^|" > $OUT/${TAG}_configs.md || true
+echo "[9] bench line (after the traffic records: its roofline.traffic is the PMC figure of THIS tree)"
+cd /tmp
+python3 $R/bench.py > $OUT/bench.log 2> $OUT/bench.err
+tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench_n1.json
 head -c 600 $OUT/${TAG}_bench_n1.json; echo
 head -n 8 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-160
