@@ -933,6 +933,28 @@ k_mw_purity_final(const double *__restrict__ partial, int n, int batch, int slic
   const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
   pur_out[i] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
 }
+// Whole-state plans: ONE row per state and every position local to the producing tile -- purities and Q of a
+// state from its row in one work item (the same fp64 arithmetic as k_mw_purity_fused + k_mw_pack, whose
+// 24 576 one-row workgroups took 16 + 5 us of the 12-qubit sampling loop's 185)
+__global__ void __launch_bounds__(64)
+k_mw_whole_state_finish(const MwFusedArgs a, int batch, float *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const float *row = a.first + (size_t)b * kMwFusedRowA;
+  const int T = a.T, n = a.n;
+  const double tot = (double)row[3 * T];
+  float *o = out + (size_t)b * (n + 1);
+  double sum = 0.0;
+  for (int p = 0; p < n; ++p) {
+    const int j = a.loc[p];
+    const double cr = (double)row[2 * j], ci = (double)row[2 * j + 1], z = (double)row[2 * T + j];
+    const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
+    const float v = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
+    sum += v;
+    o[1 + (n - 1 - p)] = v;  // index by wire
+  }
+  o[0] = (float)(2.0 * (1.0 - sum / n));
+}
 // (Q [batch], purities by wire [batch][n]) -> out[b] = (Q, purities by wire)
 __global__ void k_mw_pack_wires(const float *__restrict__ q, const float *__restrict__ pur, int n, int batch,
                                 float *__restrict__ out) {
@@ -1440,6 +1462,11 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
       else hipLaunchKernelGGL(k_mw_read_later<false>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
     }
     for (int p = 0; p < n; ++p) { pa.src_read[p] = (int8_t)cv.src_read[p]; pa.src_col[p] = (int8_t)cv.src_col[p]; }
+  }
+  if (last.T == n && pa.rows_first == 1) {
+    hipLaunchKernelGGL(k_mw_whole_state_finish, dim3((batch + 63) / 64), dim3(64), 0, stream, pa, batch, d_out);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
   }
   float *d_pur = ws;
   ws += (size_t)batch * QMLE_MAX_QUBITS;

@@ -38,7 +38,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
   // workgroups in flight at any time are then spread over the whole state instead of one window of it
   const uint32_t blk = blk_mul ? (blockIdx.x * blk_mul) & (gridDim.x - 1u) : blockIdx.x;
   const uint64_t k = (uint64_t)blk * 256u + threadIdx.x;
-  if (MODE < 5 && k >= items) return;  // modes 5 / 6 / 7: exact grids, whole waves
+  if (MODE < 5 && k >= items) return;  // modes 5 .. 8: exact grids, whole waves
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
   if constexpr (MODE == 0) {
     if constexpr (DIAG) {  // items = all chunks
@@ -163,6 +163,35 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     for (int u = 0; u < 4; ++u) st4<NT>(st + c0[u], v0[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) st4<NT>(st + (c0[u] | (1ull << (pt - 1))), v1[u]);
+  } else if constexpr (MODE == 8) {
+    // controlled dense gate, control and target both on chunk bits >= 8: mode 6's bursts inside the
+    // control = 1 half -- a wave takes 4 adjacent rows (4 KiB contiguous) of each of the two streams, all
+    // loads of one stream first.  items = controlled pairs / 4.
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t row0 = ((uint64_t)blk * 4u + wave) * 4u;
+    const int lo = pt < pc ? pt - 1 : pc - 1, hi = pt < pc ? pc - 1 : pt - 1;
+    float4 v0[4], v1[4];
+    uint64_t c0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      c0[u] = ins0_64(ins0_64((row0 + u) * 64u + lane, lo), hi) | (1ull << (pc - 1));
+      v0[u] = ld4<NT>(st + c0[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v1[u] = ld4<NT>(st + (c0[u] | (1ull << (pt - 1))));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float2 a0 = make_float2(v0[u].x, v0[u].y), a1 = make_float2(v1[u].x, v1[u].y);
+      float2 b0 = make_float2(v0[u].z, v0[u].w), b1 = make_float2(v1[u].z, v1[u].w);
+      apply2(m, a0, a1);
+      apply2(m, b0, b1);
+      v0[u] = make_float4(a0.x, a0.y, b0.x, b0.y);
+      v1[u] = make_float4(a1.x, a1.y, b1.x, b1.y);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4<NT>(st + c0[u], v0[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4<NT>(st + (c0[u] | (1ull << (pt - 1))), v1[u]);
   } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
     if constexpr (DIAG) {  // items = all chunks
       float4 v = ld4<NT>(st + k);
@@ -260,6 +289,20 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     // control and target both inside a wave's 1 KiB: one contiguous float4 per lane (mode 7)
     // (controls on bits >= 4 select whole 128-byte lines: mode 2 moves half the state, 0.37 vs 0.65 ms)
     if (!diag && !k1_plain && n >= 14 && pt >= 1 && pt <= 6 && pc >= 0 && pc <= 3) { mode = 7; items = chunks; }
+    // bursts of 4 rows per stream (mode 8) where control and target leave a wave's 4 KiB whole.  Which
+    // positions gain is measured, not derived (n = 28, tools/k1_block_order.py with QMLE_K1_CTRL_BURST=0 / 9
+    // for four control placements, profiles/r04_k1_ctrl_burst.txt): target position >= 21 always (0.35-0.42
+    // -> 0.34-0.37 ms), target position 9 .. 11 (0.38-0.41 -> 0.35-0.37), and the neighbouring control below
+    // the target from position 17 up (0.36-0.39 -> 0.34-0.35); target positions 12 .. 16 stream best one
+    // pair per work item (+5 .. +9 % in bursts).  QMLE_K1_CTRL_BURST=<min target position | 0> overrides.
+    if (mode == 2 && !diag && !k1_plain && n >= 16 && pt >= 9 && pc >= 9) {
+      bool burst = n >= 24 && (pt >= 21 || pt <= 11 || (pc == pt - 1 && pt >= 17));
+      if (const char *e = std::getenv("QMLE_K1_CTRL_BURST")) burst = atoi(e) > 0 && pt >= atoi(e);
+      if (burst) {
+        mode = 8;
+        items = chunks >> 4;
+      }
+    }
   }
   if (items == 0) items = 1;
   // streaming (non-temporal) accesses once the working set dwarfs the Infinity Cache
@@ -288,6 +331,7 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     case 5: launch_direct_mode<5>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     case 7: launch_direct_mode<7>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 8: launch_direct_mode<8>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
   }
   HIPCHK(hipGetLastError());

@@ -121,6 +121,38 @@ def test_low_control_streaming_mode_every_control_target_pair(n):
                 assert err < 1e-6, (gate, pc, pt, err)
 
 
+@pytest.mark.parametrize("burst", ["0", "9"])
+def test_controlled_one_gate_passes_every_control_target_pair(burst, monkeypatch):
+    """k_direct_1q modes 2 / 3 / 4 / 7 / 8 (round 4): every (control, target) position pair of a 16-qubit
+    register for CRX and CX, one gate per launch, against the oracle -- with the 4-rows-per-stream burst
+    form (mode 8: control and target on positions >= 9) switched off and switched on from position 9 (at
+    n = 28 the library picks it by measured rules on positions this register does not have; the switch
+    is read per launch)."""
+    from qml_essentials_amd import _native as N
+
+    monkeypatch.setenv("QMLE_K1_CTRL_BURST", burst)
+    n = 16
+    rng = np.random.default_rng(161)
+    prefix = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    prefix += [("CX", [q, (q + 1) % n], ()) for q in range(n - 1)]
+    prefix += [("RX", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    flags = N.plan_flags(no_fusion=True, force_global=True)
+    worst = 0.0
+    for pc in range(n):
+        for pt in range(n):
+            if pt == pc or not (pc <= 3 or pc >= 9 or (pc + pt) % 3 == 0):
+                continue  # (every low / high control; a third of the middle ones)
+            c, t = n - 1 - pc, n - 1 - pt
+            gate = ("CRX", [c, t], (0.9,)) if (pc + pt) % 2 else ("CX", [c, t], ())
+            tape = prefix + [gate]
+            got, plan = _run(tape, n, "state", flags=flags)
+            want = OE.simulate_pure(tape, n, np.complex128)
+            err = np.abs(got[0] - want).max()
+            assert err < 1e-6, (gate, pc, pt, err)
+            worst = max(worst, err)
+    assert worst > 0.0
+
+
 @pytest.mark.parametrize("n", [4, 9, 13, 14])
 def test_every_wire_every_single_gate_kind(n):
     """One gate per circuit on a random state prefix: exercises every target /
