@@ -39,6 +39,11 @@ echo "[5] K1 sweep kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1stats -o k1 -- python3 $R/tools/k1_sweep.py > $OUT/k1.log 2>&1
 cp $(find $OUT/k1stats -name "*kernel_stats.csv" | head -n 1) $OUT/${TAG}_k1_kernel_stats.csv
 grep -v -E "amdgpu.ids|rocprofv3|^[WEI][0-9]" $OUT/k1.log > $OUT/${TAG}_k1_single_gate_n28.txt || true
+echo "[5b] K1 controlled gates: block order (control positions 7 / 8) and the 4-row burst form, per target wire"
+cd $R
+python3 tools/k1_block_order.py 16 17 18 19 20 21 2>/dev/null > $OUT/${TAG}_k1_block_order.txt || true
+(for d in 1 -1 5 -7; do for b in 0 9; do echo "control = target wire + ($d), QMLE_K1_CTRL_BURST=$b"; K1_CTRL_DELTA=$d QMLE_K1_CTRL_BURST=$b K1_MULS=0 python3 tools/k1_block_order.py 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 2>/dev/null; done; done) > $OUT/${TAG}_k1_ctrl_burst_raw.txt || true
+cd /tmp
 echo "[6] traffic.json (signed with the source hash)"
 cd $R
 python3 tools/update_traffic.py $OUT/${TAG}_pmc_k2_dense_n24.json 24 32 dense \
