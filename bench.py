@@ -453,7 +453,7 @@ def expressibility_leg(n=12, samples=1024, reps=21):
 
     m = Model(n, 3, "Hardware_Efficient", data_reupload=False)
     Expressibility.kl_divergence_to_haar(m, n_samples=max(64, distributed.world()[1]), n_bins=75, random_key=1)
-    for _ in range(3):
+    for _ in range(100):  # ~20 ms: past the clock transient that follows the HBM-bound headline steps
         Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75, random_key=1000)
     sec, kl, gpu_ms = _wall(lambda: Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75,
                                                                          random_key=1000), reps)
@@ -483,7 +483,7 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
         y = m(inputs=x, force_mean=True)
         return Coefficients._fft_real(y.cpu().numpy().astype(np.float64))
 
-    for _ in range(3):
+    for _ in range(100):  # ~20 ms of warm-up, as for the other legs
         call()
     sec, coeffs, gpu_ms = _wall(call, reps)
     size = distributed.world()[1]
