@@ -366,3 +366,24 @@ def test_every_schedule_candidate_places_every_gate_exactly_once(monkeypatch):
                     assert all(n - 1 - w in tile for w in ops[s][1]), (k, pad, s)
             seen.add(tuple(tuple(st["bits"]) for st in d["stages"] if st["kind"] == "tile"))
     assert len(seen) >= 8  # (the candidates really are different schedules)
+
+
+def test_round4_entry_points_refuse_bad_arguments_before_touching_a_device():
+    """qmle_run_batch_map / qmle_plan_autotune / qmle_plan_executed (include/qmle_sv.h, round 4): argument
+    errors are status codes, decided on the host -- no HIP call is needed to get them."""
+    import ctypes as C
+
+    lib = N.lib()
+    ops, slots = he_layer_ops(4)
+    plan = N.Plan(ops, 4, slots)
+    null = C.c_void_p(None)
+    assert lib.qmle_run_batch_map(null, null, null, 1, 2, None, 0, null, null, 0, null) == -1       # no plan
+    assert lib.qmle_run_batch_map(plan._h, null, null, 1, 2, None, 0, null, null, 0, null) == -1    # no map
+    amap = N.QmleAngleMap()
+    assert lib.qmle_run_batch_map(plan._h, C.byref(amap), null, 0, 2, None, 0, null, null, 0, null) == -1  # batch 0
+    assert lib.qmle_run_batch_map(plan._h, C.byref(amap), null, 1, 2, None, 0, null, null, 0, null) == -1  # slots, no table
+    chosen = (C.c_int32 * 2)()
+    a, b = C.c_double(), C.c_double()
+    assert lib.qmle_plan_autotune(null, 0, 0, 1, 2, 2, null, chosen, C.byref(a), C.byref(b)) == -1
+    assert lib.qmle_plan_executed(null, 0) is None
+    assert plan.executed("state").stats()["n_ops"] == plan.stats()["n_ops"]
