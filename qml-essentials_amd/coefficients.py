@@ -37,10 +37,9 @@ class Coefficients:
         kwargs.setdefault("force_mean", True)
         kwargs.setdefault("execution_type", "expval")
         coeffs, freqs = cls._fourier_transform(model, mfs=mfs, mts=mts, **kwargs)
-        if not np.isclose(np.sum(coeffs).imag, 0.0, atol=1.0e-6):
-            raise ValueError(
-                f"Spectrum is not real. Imaginary part of coefficients is: {np.sum(coeffs).imag}"
-            )
+        imag = float(np.sum(coeffs).imag)
+        if not abs(imag) <= 1.0e-6:  # (= np.isclose(imag, 0.0, atol=1e-6), without its 8 us; NaN fails too)
+            raise ValueError(f"Spectrum is not real. Imaginary part of coefficients is: {imag}")
         if trim:
             for ax in range(model.n_input_feat):
                 if coeffs.shape[ax] % 2 == 0:
@@ -65,9 +64,6 @@ class Coefficients:
         """Sample the model on ``x_k = 2 pi k / N_f`` per feature and FFT
         (``coefficients.py:109-150``; feature 0 is the slowest grid axis)."""
         F = model.n_input_feat
-        n_freqs = np.array([mfs * model.degree[i] for i in range(F)])
-        axes = [np.arange(0, 2 * mts * np.pi, 2 * np.pi / n_freqs[i]) for i in range(F)]
-        grid = np.array(np.meshgrid(*axes)).T.reshape(-1, F)
         # the engine returns float32; the (tiny) host FFT runs in double so that it adds no
         # rounding noise of its own to the spectrum.  complex128 mode (utils.enable_x64 /
         # Model(x64=True)): the grid stays float64 too -- a float32-rounded grid point is off by
@@ -75,8 +71,22 @@ class Coefficients:
         from .utils import x64_enabled
 
         x64 = x64_enabled() if getattr(model, "x64", None) is None else bool(model.x64)
-        freqs = [np.fft.fftfreq(int(mts * n_freqs[i]), 1 / n_freqs[i]) for i in range(F)]
-        lens = [a.shape[0] for a in axes]
+        # grid, frequencies and the device copy of the grid depend on (degrees, mfs, mts) only: a
+        # spectrum is asked for again and again on the same grid, and the ~40 us of numpy calls that
+        # build it are a fifth of a 4096-point call
+        key = (tuple(mfs * model.degree[i] for i in range(F)), mts, x64)
+        hit = cls._PLANS.get(key)
+        if hit is None:
+            n_freqs = np.array(key[0])
+            axes = [np.arange(0, 2 * mts * np.pi, 2 * np.pi / n_freqs[i]) for i in range(F)]
+            grid = np.array(np.meshgrid(*axes)).T.reshape(-1, F)
+            freqs = [np.fft.fftfreq(int(mts * n_freqs[i]), 1 / n_freqs[i]) for i in range(F)]
+            lens = [a.shape[0] for a in axes]
+            if len(cls._PLANS) > 32:
+                cls._PLANS.clear()
+            hit = cls._PLANS[key] = (grid, freqs, lens)
+        grid, freqs, lens = hit
+        freqs = [f.copy() for f in freqs]  # (callers may edit what they get back)
         grid_dev = None if x64 else cls._device_grid(grid)
         if grid_dev is not None:
             # the grid lives on the GPU (cached per grid): nothing is uploaded per call, and the
@@ -108,6 +118,7 @@ class Coefficients:
         return out
 
     _GRIDS: dict = {}
+    _PLANS: dict = {}  # (n_freqs, mts, x64) -> (host grid, frequency axes, grid lengths)
 
     @classmethod
     def _device_grid(cls, grid: np.ndarray):
@@ -121,10 +132,10 @@ class Coefficients:
 
         key = (grid.shape, float(grid[-1].sum()), float(grid[len(grid) // 2].sum()), torch.cuda.current_device())
         hit = cls._GRIDS.get(key)
-        if hit is None or not np.array_equal(hit[0], grid):
+        if hit is None or (hit[0] is not grid and not np.array_equal(hit[0], grid)):
             if len(cls._GRIDS) > 16:
                 cls._GRIDS.clear()
-            hit = cls._GRIDS[key] = (grid.copy(), torch.from_numpy(grid.astype(np.float32)).cuda())
+            hit = cls._GRIDS[key] = (grid, torch.from_numpy(grid.astype(np.float32)).cuda())
         return hit[1]
 
     @classmethod
