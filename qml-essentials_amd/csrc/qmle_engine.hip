@@ -22,12 +22,12 @@
 
 namespace {
 
-__global__ void k_build_matrices(const BuildOp *__restrict__ build,
-                                 const BuildGroup *__restrict__ groups, int n_groups,
-                                 const float *__restrict__ angles, int n_slots,
-                                 const float *__restrict__ consts, float *__restrict__ mats,
-                                 uint32_t mat_floats, int batch) {
-  build_matrices_body<float, float, float>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
+template <bool GMAJOR>
+__global__ void __launch_bounds__(64)
+k_build_matrices(const BuildOp *__restrict__ build, const BuildGroup *__restrict__ groups, int n_groups,
+                 const float *__restrict__ angles, int n_slots, const float *__restrict__ consts,
+                 float *__restrict__ mats, uint32_t mat_floats, int batch) {
+  build_matrices_body<float, float, float, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -142,9 +142,14 @@ bool plan_sparse(const qmle_plan *p) {
 int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream) {
   if (p->groups.empty()) return QMLE_OK;
   const int ng = (int)p->groups.size();
-  const uint64_t items = (uint64_t)batch * (uint64_t)ng;  // one work item per (sample, group)
-  hipLaunchKernelGGL(k_build_matrices, dim3(grid_for(items, 64)), dim3(64), 0, stream, p->dev.d_build,
-                     p->dev.d_groups, ng, d_angles, p->n_slots, p->dev.d_consts, d_mats, p->mat_floats, batch);
+  // one work item per (sample, group); from 64 samples on, whole waves per group (build_matrices_body)
+  const uint64_t items = batch >= 64 ? (uint64_t)ng * (((uint64_t)batch + 63) / 64) * 64 : (uint64_t)batch * (uint64_t)ng;
+  if (batch >= 64)
+    hipLaunchKernelGGL(k_build_matrices<true>, dim3(grid_for(items, 64)), dim3(64), 0, stream, p->dev.d_build,
+                       p->dev.d_groups, ng, d_angles, p->n_slots, p->dev.d_consts, d_mats, p->mat_floats, batch);
+  else
+    hipLaunchKernelGGL(k_build_matrices<false>, dim3(grid_for(items, 64)), dim3(64), 0, stream, p->dev.d_build,
+                       p->dev.d_groups, ng, d_angles, p->n_slots, p->dev.d_consts, d_mats, p->mat_floats, batch);
   HIPCHK(hipGetLastError());
   return QMLE_OK;
 }

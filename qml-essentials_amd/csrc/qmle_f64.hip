@@ -17,12 +17,12 @@
 
 namespace {
 
-__global__ void k_build_matrices_f64(const BuildOp *__restrict__ build,
-                                     const BuildGroup *__restrict__ groups, int n_groups,
-                                     const double *__restrict__ angles, int n_slots,
-                                     const double *__restrict__ consts, double *__restrict__ mats,
-                                     uint32_t mat_floats, int batch) {
-  build_matrices_body<double, double, double>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
+template <bool GMAJOR>
+__global__ void __launch_bounds__(64)
+k_build_matrices_f64(const BuildOp *__restrict__ build, const BuildGroup *__restrict__ groups, int n_groups,
+                     const double *__restrict__ angles, int n_slots, const double *__restrict__ consts,
+                     double *__restrict__ mats, uint32_t mat_floats, int batch) {
+  build_matrices_body<double, double, double, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -296,7 +296,11 @@ int qmle_apply_inplace_f64(qmle_plan *plan, const double *d_angles, int batch, v
   double *d_mats = (double *)ws;
   if (!plan->groups.empty()) {
     const int ng = (int)plan->groups.size();
-    hipLaunchKernelGGL(k_build_matrices_f64, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
+    if (batch >= 64)
+      hipLaunchKernelGGL(k_build_matrices_f64<true>, dim3(grid_for((uint64_t)ng * (((uint64_t)batch + 63) / 64) * 64, 64)), dim3(64), 0, stream, plan->dev.d_build,
+                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
+    else
+      hipLaunchKernelGGL(k_build_matrices_f64<false>, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
                        plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
   }
   const int n = plan->n;
@@ -342,7 +346,11 @@ int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int m
   ws += align_up((size_t)batch * (plan->mat_floats ? plan->mat_floats : 1) * sizeof(double), 256);
   if (!plan->groups.empty()) {
     const int ng = (int)plan->groups.size();
-    hipLaunchKernelGGL(k_build_matrices_f64, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
+    if (batch >= 64)
+      hipLaunchKernelGGL(k_build_matrices_f64<true>, dim3(grid_for((uint64_t)ng * (((uint64_t)batch + 63) / 64) * 64, 64)), dim3(64), 0, stream, plan->dev.d_build,
+                       plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
+    else
+      hipLaunchKernelGGL(k_build_matrices_f64<false>, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream, plan->dev.d_build,
                        plan->dev.d_groups, ng, d_angles, plan->n_slots, d_c64, d_mats, plan->mat_floats, batch);
   }
   const size_t D = (size_t)1 << n;

@@ -137,18 +137,33 @@ __device__ void source_matrix(const BuildOp &b, const AT *__restrict__ ang,
 
 // AT / CT / OT: angle table, constant blob and matrix row types -- float / float / float for the
 // complex64 engine, double throughout for the complex128 one (qmle_run_batch_f64)
-template <class AT, class CT, class OT>
+// GMAJOR: whole waves per group (launch side: batch >= 64, blocks of one wave) -- the group index is then
+// provably wave-uniform and the descriptors come through the scalar cache
+template <class AT, class CT, class OT, bool GMAJOR = false>
 __device__ __forceinline__ void build_matrices_body(const BuildOp *__restrict__ build,
                                                     const BuildGroup *__restrict__ groups, int n_groups,
                                                     const AT *__restrict__ angles, int n_slots,
                                                     const CT *__restrict__ consts, OT *__restrict__ mats,
                                                     uint32_t mat_floats, int batch) {
-  // one work item per (sample, group), samples and groups flattened: a grid of (groups / 64, samples)
-  // left 62 of the 192 lanes per sample idle at 130 groups (C4) -- a third of the kernel
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long b_ll = idx / n_groups;
-  if (b_ll >= batch) return;
-  const int b = (int)b_ll, g = (int)(idx - b_ll * n_groups);
+  // one work item per (sample, group).  batch >= 64 (blocks of ONE wave): a wave takes 64 consecutive
+  // samples of the SAME group -- every lane then walks the same source gates through the same branches
+  // of the opcode switch.  With the samples-then-groups flattening used below that, neighbouring lanes
+  // held different groups (RX next to RY next to CX ...) and a wave executed every branch any of its lanes
+  // needed, one after the other: 20 us for the 4096 x 130 groups of the Fourier grid, untouched by cheaper
+  // trigonometry, fewer registers, prefetched descriptors or LDS staging.
+  int b, g;
+  if constexpr (GMAJOR) {
+    const uint32_t per = ((uint32_t)batch + 63u) >> 6;  // waves per group
+    g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / per));
+    b = (int)((blockIdx.x - (uint32_t)g * per) * 64u + threadIdx.x);
+    if (g >= n_groups || b >= batch) return;
+  } else {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b_ll = idx / n_groups;
+    if (b_ll >= batch) return;
+    b = (int)b_ll;
+    g = (int)(idx - b_ll * n_groups);
+  }
   const BuildGroup grp = groups[g];
   const AT *ang = angles + (size_t)b * n_slots;
   const int dim = (int)grp.dim;
