@@ -228,9 +228,12 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
 
 /* qmle_build_angles + qmle_run_batch behind ONE call (the Model's device route: its angle map is all the
  * host holds, model.py:804-816 / ansaetze.py:323-371).  `map` carries qmle_build_angles' arguments;
- * d_angles [batch][plan n_slots] float32 is scratch the call fills and then reads (may be NULL for a plan
- * without slots).  Same results as the two calls; the host's time between the two launches -- 8-14 us of an
- * idle GPU in the 0.2 ms analysis loops of BASELINE configs 3 / 4 -- is gone. */
+ * d_angles [batch][plan n_slots] float32 is SCRATCH: the call may fill and read it (fewer than 64 samples, or
+ * a plan with the Golomb diagonal, which reads its angle in the pass itself) or leave it untouched -- from 64
+ * samples on the per-sample gate matrices are built straight from the map (same arithmetic, same results
+ * bit for bit, one kernel and the table's round trip less).  May be NULL for a plan without slots.  The
+ * host's time between the two launches -- 8-14 us of an idle GPU in the 0.2 ms analysis loops of BASELINE
+ * configs 3 / 4 -- is gone either way. */
 typedef struct qmle_angle_map {
   const float *const *d_leaves;   /* HOST array of n_leaves device pointers */
   const int64_t *leaf_strides;    /* HOST */

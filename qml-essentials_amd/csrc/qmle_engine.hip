@@ -27,7 +27,16 @@ __global__ void __launch_bounds__(64)
 k_build_matrices(const BuildOp *__restrict__ build, const BuildGroup *__restrict__ groups, int n_groups,
                  const float *__restrict__ angles, int n_slots, const float *__restrict__ consts,
                  float *__restrict__ mats, uint32_t mat_floats, int batch) {
-  build_matrices_body<float, float, float, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
+  build_matrices_body<const float *, float, float, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
+}
+
+// the same straight from the affine angle map (qmle_run_batch_map; whole waves per group only)
+__global__ void __launch_bounds__(64)
+k_build_matrices_map(const BuildOp *__restrict__ build, const BuildGroup *__restrict__ groups, int n_groups,
+                     const AngleMapSrc map, int n_slots, const float *__restrict__ consts,
+                     float *__restrict__ mats, uint32_t mat_floats, int batch) {
+  build_matrices_body<const AngleMapSrc &, float, float, true>(build, groups, n_groups, map, n_slots, consts, mats,
+                                                              mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -36,12 +45,6 @@ k_build_matrices(const BuildOp *__restrict__ build, const BuildGroup *__restrict
 // of leaf k for flattened sample b is (b / div_k) % mod_k -- the cartesian batch of
 // model.py:1449-1481 without materialising the repeats.
 // ---------------------------------------------------------------------------
-struct AngleLeaves {
-  const float *ptr[8];
-  long long stride[8];  // floats per row
-  int div[8], mod[8];
-};
-
 // One work item per (state, slot), flattened (every lane busy whatever the slot count: a block-per-state
 // layout with the divisions hoisted out of the term loop measured 6.5 instead of 4.1 us for the 2048 x 108
 // table of the Expressibility loop -- the kernel is a chain of three dependent loads, not arithmetic).
@@ -138,10 +141,22 @@ bool plan_sparse(const qmle_plan *p) {
   return !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH)) && !pf_env;
 }
 
+// qmle_run_batch_map hands its angle map to the matrix builder of the batch it is about to run (this
+// thread's next launch_build_matrices of >= 64 samples): the angles are then formed inside the builder and
+// the table is never written
+static thread_local const AngleMapSrc *tls_angle_map = nullptr;
+
 // per-sample gate matrices for the whole batch: d_mats[b][mat_floats] from d_angles[b][n_slots]
 int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream) {
   if (p->groups.empty()) return QMLE_OK;
   const int ng = (int)p->groups.size();
+  if (tls_angle_map && batch >= 64) {
+    const uint64_t waves = (uint64_t)ng * (((uint64_t)batch + 63) / 64);
+    hipLaunchKernelGGL(k_build_matrices_map, dim3(grid_for(waves * 64, 64)), dim3(64), 0, stream, p->dev.d_build,
+                       p->dev.d_groups, ng, *tls_angle_map, p->n_slots, p->dev.d_consts, d_mats, p->mat_floats, batch);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
   // one work item per (sample, group); from 64 samples on, whole waves per group (build_matrices_body)
   const uint64_t items = batch >= 64 ? (uint64_t)ng * (((uint64_t)batch + 63) / 64) * 64 : (uint64_t)batch * (uint64_t)ng;
   if (batch >= 64)
@@ -988,15 +1003,43 @@ int qmle_run_batch_map(qmle_plan *plan, const qmle_angle_map *map, float *d_angl
                        int meas_type, const int32_t *obs_wires, int n_obs, void *d_out,
                        void *d_workspace, size_t workspace_bytes, qmle_stream stream) {
   if (!plan || !map || batch < 1) return QMLE_ERR_INVALID_ARG;
-  if (plan->n_slots > 0) {
-    if (!d_angles) return QMLE_ERR_INVALID_ARG;
+  if (plan->n_slots == 0)
+    return qmle_run_batch(plan, d_angles, batch, meas_type, obs_wires, n_obs, d_out, d_workspace, workspace_bytes,
+                          stream);
+  if (!d_angles) return QMLE_ERR_INVALID_ARG;
+  // The table is needed as a table only by the Golomb diagonal (QMLE_OP_DIAG_ALL reads its angle in the pass
+  // itself); every other gate meets its angles in the matrix builder, which can form them from the map --
+  // one kernel (5-9 us of the 0.17 ms analysis loops) and the table's round trip less.  From 64 samples on
+  // (whole waves per group); QMLE_NO_MAP_FUSION=1 keeps the two kernels (A/B, tests).
+  bool table = batch < 64 || std::getenv("QMLE_NO_MAP_FUSION") != nullptr || map->n_leaves < 0 || map->n_leaves > 8 ||
+               !map->d_ptr || !map->d_const;
+  for (const qmle_op &o : plan->ops) table = table || o.opcode == QMLE_OP_DIAG_ALL;
+  if (table) {
     const int rc = qmle_build_angles(map->d_leaves, map->leaf_strides, map->leaf_div, map->leaf_mod, map->n_leaves,
                                      map->d_ptr, map->d_arg, map->d_idx, map->d_coef, map->d_const, map->d_period,
                                      plan->n_slots, batch, map->batch_offset, d_angles, stream);
     if (rc != QMLE_OK) return rc;
+    return qmle_run_batch(plan, d_angles, batch, meas_type, obs_wires, n_obs, d_out, d_workspace, workspace_bytes,
+                          stream);
   }
-  return qmle_run_batch(plan, d_angles, batch, meas_type, obs_wires, n_obs, d_out, d_workspace, workspace_bytes,
-                        stream);
+  AngleMapSrc src;
+  std::memset(&src, 0, sizeof(src));
+  for (int k = 0; k < map->n_leaves; ++k) {
+    if (!map->d_leaves[k] || map->leaf_div[k] < 1 || map->leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
+    src.lv.ptr[k] = map->d_leaves[k];
+    src.lv.stride[k] = map->leaf_strides[k];
+    src.lv.div[k] = map->leaf_div[k];
+    src.lv.mod[k] = map->leaf_mod[k];
+  }
+  src.ptr = map->d_ptr; src.arg = map->d_arg; src.idx = map->d_idx;
+  src.coef = map->d_coef; src.cst = map->d_const; src.period = map->d_period;
+  src.b_offset = map->batch_offset;
+  src.small = map->batch_offset >= 0 && (uint64_t)batch + (uint64_t)map->batch_offset < (1ull << 32);
+  tls_angle_map = &src;
+  const int rc = qmle_run_batch(plan, d_angles, batch, meas_type, obs_wires, n_obs, d_out, d_workspace,
+                                workspace_bytes, stream);
+  tls_angle_map = nullptr;
+  return rc;
 }
 
 int qmle_profile_begin(qmle_plan *plan, int capacity) {

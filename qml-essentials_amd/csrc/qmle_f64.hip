@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(64)
 k_build_matrices_f64(const BuildOp *__restrict__ build, const BuildGroup *__restrict__ groups, int n_groups,
                      const double *__restrict__ angles, int n_slots, const double *__restrict__ consts,
                      double *__restrict__ mats, uint32_t mat_floats, int batch) {
-  build_matrices_body<double, double, double, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
+  build_matrices_body<const double *, double, double, GMAJOR>(build, groups, n_groups, angles, n_slots, consts, mats, mat_floats, batch);
 }
 
 // ---------------------------------------------------------------------------------------------

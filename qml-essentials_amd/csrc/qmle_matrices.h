@@ -21,8 +21,10 @@ struct M2 {
   cd a, b, c, d;  // [[a, b], [c, d]]
 };
 // the 2x2 source gates of source_matrix(), entries in registers
-template <class AT, class CT>
-__device__ __forceinline__ M2 source_2x2(const BuildOp &b, const AT *__restrict__ ang, const CT *__restrict__ consts) {
+// ANG: anything indexable by slot -- a row of the angle table (`const float *` / `const double *`) or an
+// AngleMapRow that forms the angle from the leaves on the fly (same arithmetic as k_build_angles)
+template <class ANG, class CT>
+__device__ __forceinline__ M2 source_2x2(const BuildOp &b, ANG ang, const CT *__restrict__ consts) {
   const cd z = {0.0, 0.0}, one = {1.0, 0.0};
   double th = 0.0, c = 1.0, s = 0.0;
   if (b.slot[0] >= 0) {
@@ -61,8 +63,8 @@ __device__ __forceinline__ M2 source_2x2(const BuildOp &b, const AT *__restrict_
   }
 }
 
-template <class AT, class CT>
-__device__ void source_matrix(const BuildOp &b, const AT *__restrict__ ang,
+template <class ANG, class CT>
+__device__ void source_matrix(const BuildOp &b, ANG ang,
                               const CT *__restrict__ consts, cd *M, int dim) {
   const int nn = dim * dim;
   for (int i = 0; i < nn; ++i) M[i] = {0.0, 0.0};
@@ -135,14 +137,54 @@ __device__ void source_matrix(const BuildOp &b, const AT *__restrict__ ang,
   }
 }
 
+// Angle table computed on the fly: table[b][s] = c[s] + sum_t coef[t] * leaf_{arg[t]}[row_k(b)][idx[t]],
+// row_k(b) = ((b + b_offset) / div_k) % mod_k, fp64 sum, reduced into (-period/2, period/2], rounded to
+// float32 -- bit for bit what k_build_angles stores (qmle_engine.hip); qmle_run_batch_map uses it to skip
+// that kernel and the table's round trip when nothing but the matrix builder reads angles.
+struct AngleLeaves {
+  const float *ptr[8];
+  long long stride[8];  // floats per row
+  int div[8], mod[8];
+};
+struct AngleMapSrc {
+  AngleLeaves lv;
+  const int *ptr, *arg, *idx;
+  const float *coef, *cst;
+  const double *period;
+  long long b_offset;
+  int small;  // batch + offset < 2^32: row arithmetic in 32 bits
+};
+struct AngleMapRow {
+  const AngleMapSrc *m;
+  unsigned long long gb;
+  __device__ __forceinline__ float operator[](int s) const {
+    double acc = (double)m->cst[s];
+    for (int t = m->ptr[s]; t < m->ptr[s + 1]; ++t) {
+      const int k = m->arg[t];
+      const long long row = m->small ? (long long)(((uint32_t)gb / (uint32_t)m->lv.div[k]) % (uint32_t)m->lv.mod[k])
+                                     : (long long)((gb / (unsigned long long)m->lv.div[k]) % (unsigned long long)m->lv.mod[k]);
+      acc = fma((double)m->coef[t], (double)m->lv.ptr[k][row * m->lv.stride[k] + m->idx[t]], acc);
+    }
+    const double per = m->period ? m->period[s] : 0.0;
+    if (per > 0.0 && (acc > per || acc < -per)) acc -= per * rint(acc / per);
+    return (float)acc;
+  }
+};
+template <class T>
+__device__ __forceinline__ const T *angle_row(const T *table, int b, int n_slots) { return table + (size_t)b * n_slots; }
+__device__ __forceinline__ AngleMapRow angle_row(const AngleMapSrc &m, int b, int) {
+  return AngleMapRow{&m, (unsigned long long)((long long)b + m.b_offset)};
+}
+
 // AT / CT / OT: angle table, constant blob and matrix row types -- float / float / float for the
 // complex64 engine, double throughout for the complex128 one (qmle_run_batch_f64)
 // GMAJOR: whole waves per group (launch side: batch >= 64, blocks of one wave) -- the group index is then
 // provably wave-uniform and the descriptors come through the scalar cache
-template <class AT, class CT, class OT, bool GMAJOR = false>
+// ASRC: `const AT *` (the angle table) or `const AngleMapSrc &`
+template <class ASRC, class CT, class OT, bool GMAJOR = false>
 __device__ __forceinline__ void build_matrices_body(const BuildOp *__restrict__ build,
                                                     const BuildGroup *__restrict__ groups, int n_groups,
-                                                    const AT *__restrict__ angles, int n_slots,
+                                                    ASRC angles, int n_slots,
                                                     const CT *__restrict__ consts, OT *__restrict__ mats,
                                                     uint32_t mat_floats, int batch) {
   // one work item per (sample, group).  batch >= 64 (blocks of ONE wave): a wave takes 64 consecutive
@@ -165,7 +207,7 @@ __device__ __forceinline__ void build_matrices_body(const BuildOp *__restrict__ 
     g = (int)(idx - b_ll * n_groups);
   }
   const BuildGroup grp = groups[g];
-  const AT *ang = angles + (size_t)b * n_slots;
+  const auto ang = angle_row(angles, b, n_slots);
   const int dim = (int)grp.dim;
   if (dim == 2) {
     // 2x2 groups (all but the two-qubit Pauli rotations / SWAP / explicit 4x4): four named

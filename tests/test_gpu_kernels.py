@@ -1005,10 +1005,11 @@ def test_angle_table_and_batch_behind_one_call_equal_the_two_calls(offset):
 
     m = Model(6, 2, "Hardware_Efficient")
     rng = np.random.default_rng(11)
-    x = torch.from_numpy(rng.uniform(0, 6.28, (7, 1)).astype(np.float32)).cuda()
+    # 90 samples: from 64 on qmle_run_batch_map forms the angles inside the matrix builder (no table)
+    x = torch.from_numpy(rng.uniform(0, 6.28, (30, 1)).astype(np.float32)).cuda()
     p = torch.from_numpy(rng.uniform(0, 6.28, (3, *m.params.shape[-2:])).astype(np.float32)).cuda()
     cc, leaves, divs, mods, B = m._forward_device(p, x, None, "expval", False, _want_call=True)
-    assert B == 21 and cc.n_slots > 0
+    assert B == 90 and cc.n_slots > 0
     strides = [t[0].numel() for t in leaves]
     how, wires = cc._measure()
     assert how == "z"
@@ -1017,6 +1018,8 @@ def test_angle_table_and_batch_behind_one_call_equal_the_two_calls(offset):
     two = cc.plan.run(table, "expval", wires)
     one = cc.run(leaves, divs, mods, B, offset)
     assert torch.equal(one, two)
+    few = cc.run(leaves, divs, mods, 21, offset)  # < 64 samples: table + batch inside the one call
+    assert torch.equal(few, two[:21])
     # the table itself: const + sum coef * leaf[row(b)][idx], rows from the flattened sample index
     ptr, arg, idx, coef = cc._map
     host = [t.cpu().numpy().reshape(t.shape[0], -1).astype(np.float64) for t in leaves]
