@@ -29,7 +29,7 @@ def main():
     print("stats over the whole run (avg us, count):")
     for name, avg, cnt in db.execute(
             "select name, avg(end - start) / 1e3, count(*) from kernels group by name order by sum(end - start) desc"):
-        print(f"  {avg:9.2f} {cnt:6d}  {clean(name)[:90]}")
+        print(f"  {avg:9.2f} {cnt:6d}  {clean(name)[:90]}", flush=False)
 
 
 if __name__ == "__main__":
