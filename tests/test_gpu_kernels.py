@@ -1039,3 +1039,36 @@ def test_angle_table_and_batch_behind_one_call_equal_the_two_calls(offset):
     np.testing.assert_allclose(table.cpu().numpy(), want, rtol=0, atol=2e-6)
     if offset == 0:
         np.testing.assert_allclose(m(params=p, inputs=x).cpu().numpy().reshape(one.shape), one.cpu().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,flags_kw", [(6, {}), (12, {}), (15, {}), (6, {"no_fusion": True, "force_global": True})])
+def test_a_row_does_not_depend_on_its_batch(n, flags_kw):
+    """Rows of a batch are independent circuits (script.py:302-327: vmap over the batch axis): the row of
+    sample b must be the same bits whether it runs alone, at the end of 63 samples, or inside 64 / 65 / 130 --
+    the matrix builder takes whole waves per gate group from 64 samples on and samples-then-groups items
+    below (qmle_matrices.h), with a ragged last wave at 65 and 130; mixed 2x2 / 4x4 groups (RZX, SWAP)."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(640 + n)
+    tape = [("RY", [q], (0.0,)) for q in range(n)] + [("CX", [q, (q + 1) % n], ()) for q in range(n)]
+    tape += [("RZX", [0, n - 1], (0.0,)), ("SWAP", [1, 2], ()), ("Rot", [3], (0.0, 0.0, 0.0)), ("CRX", [2, 0], (0.0,))]
+    tape += [("RZ", [q], (0.0,)) for q in range(n)]
+    ops, angles, consts = tape_to_native(tape, n)
+    plan = N.Plan(ops, n, len(angles), consts, N.plan_flags(**flags_kw) if flags_kw else 0)
+    table = rng.uniform(-6.28, 6.28, (130, len(angles))).astype(np.float32)
+    dev = torch.from_numpy(table).cuda()
+    whole = plan.run(dev, "state").cpu().numpy()
+    zs = plan.run(dev, "expval", list(range(n))).cpu().numpy()
+    for B in (1, 63, 64, 65):
+        part = plan.run(dev[:B].contiguous(), "state").cpu().numpy()
+        assert np.array_equal(part, whole[:B]), B
+        assert np.array_equal(plan.run(dev[:B].contiguous(), "expval", list(range(n))).cpu().numpy(), zs[:B]), B
+    alone = plan.run(dev[129:130].contiguous(), "state").cpu().numpy()
+    assert np.array_equal(alone[0], whole[129])
+    row, k, filled = table[129], 0, []  # (tape_to_native: every float parameter takes the next slot)
+    for g, w, prm in tape:
+        filled.append((g, w, tuple(float(row[k + i]) for i in range(len(prm)))))
+        k += len(prm)
+    want = OE.simulate_pure(filled, n, np.complex128)
+    assert np.abs(whole[129] - want).max() < 1e-6
