@@ -980,7 +980,8 @@ int qmle_build_angles(const float *const *d_leaves, const int64_t *leaf_strides,
   AngleLeaves lv;
   std::memset(&lv, 0, sizeof(lv));
   for (int k = 0; k < n_leaves; ++k) {
-    if (!d_leaves[k] || leaf_div[k] < 1 || leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
+    // (a leaf without elements -- the parameters of an ansatz that has none -- may come as a NULL pointer: no term can refer to it)
+    if ((!d_leaves[k] && leaf_strides[k] != 0) || leaf_div[k] < 1 || leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
     lv.ptr[k] = d_leaves[k];
     lv.stride[k] = leaf_strides[k];
     lv.div[k] = leaf_div[k];
@@ -1025,7 +1026,7 @@ int qmle_run_batch_map(qmle_plan *plan, const qmle_angle_map *map, float *d_angl
   AngleMapSrc src;
   std::memset(&src, 0, sizeof(src));
   for (int k = 0; k < map->n_leaves; ++k) {
-    if (!map->d_leaves[k] || map->leaf_div[k] < 1 || map->leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
+    if ((!map->d_leaves[k] && map->leaf_strides[k] != 0) || map->leaf_div[k] < 1 || map->leaf_mod[k] < 1) return QMLE_ERR_INVALID_ARG;
     src.lv.ptr[k] = map->d_leaves[k];
     src.lv.stride[k] = map->leaf_strides[k];
     src.lv.div[k] = map->leaf_div[k];

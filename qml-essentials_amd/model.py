@@ -797,7 +797,7 @@ class Model:
             if p_leaf:
                 p = params.to(torch.float32)
                 p = (p.unsqueeze(0) if p.dim() == 2 else p).contiguous()
-                B_P = int(p.shape[0])
+                B_P = 1 if 0 in p.shape else int(p.shape[0])  # (model.py:1444: an ansatz without parameters)
                 leaves.append(p); divs.append(1); mods.append(B_P if B_P > 1 else 1)
             if x_leaf:
                 x = inputs.to(torch.float32).contiguous()
@@ -849,7 +849,7 @@ class Model:
             p = params.to(torch.float32)
             p = p.unsqueeze(0) if p.dim() == 2 else p
             p = p.contiguous()
-            B_P = int(p.shape[0])
+            B_P = 1 if 0 in p.shape else int(p.shape[0])  # (model.py:1444: an ansatz without parameters)
         else:
             p = self._params_validation(params)
             B_P = 1 if 0 in p.shape else int(p.shape[0])
