@@ -387,3 +387,39 @@ def test_registers_beyond_28_qubits(n):
     assert abs(float(q) - 2 * (1 - pur.mean())) < 2 * tol
     del st
     torch.cuda.empty_cache()
+
+
+def test_one_gate_passes_at_24_qubits_controls_and_targets_all_over_the_register():
+    """k_direct_1q as the library picks its modes at n >= 24 (round 4: workgroups spread over the state for
+    controls on positions 7 / 8, 4-rows-per-stream bursts of the controlled gate by the measured position
+    rules, bursts of the plain gate from position 21): a state of random single-qubit rotations, then CX /
+    CRX / CRY on control-target pairs that hit every rule -- neighbours above and below, distant pairs, controls
+    on positions 0..3, 4, 7, 8 -- one gate per launch (QMLE_PLAN_NO_FUSION | FORCE_GLOBAL), against the oracle's
+    C port and against the fused default engine."""
+    N = _N()
+    from oracle import c_port
+    from tests.helpers import tape_to_native
+
+    n = 24
+    rng = np.random.default_rng(2404)
+    pos = lambda p: n - 1 - p  # wire of bit position p
+    tape = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    tape += [("RZ", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    pairs = [(22, 23), (23, 22), (20, 21), (21, 17), (16, 17), (18, 17), (10, 11), (12, 11), (9, 10), (11, 10),
+             (7, 8), (8, 9), (8, 20), (7, 23), (4, 5), (4, 22), (3, 21), (2, 23), (0, 12), (1, 6), (15, 14), (13, 14),
+             (19, 12), (12, 19), (5, 16), (23, 9)]
+    kinds = ["CX", "CRX", "CRY"]
+    for i, (pc, pt) in enumerate(pairs):
+        g = kinds[i % 3]
+        tape.append((g, [pos(pc), pos(pt)], () if g == "CX" else (float(rng.uniform(0.3, 2.8)),)))
+        tape.append(("RX", [pos(pt)], (float(rng.uniform(0, 6.28)),)))
+    ops, angles, consts = tape_to_native(tape, n)
+    ang = torch.from_numpy(np.ascontiguousarray(angles[None, :], dtype=np.float32)).cuda()
+    one = N.Plan(ops, n, len(angles), consts, N.plan_flags(no_fusion=True, force_global=True))
+    kinds_run = [s["kind"] for s in one.describe()["stages"]]
+    assert kinds_run.count("direct") >= len(kinds_run) - 8, kinds_run  # (a few low-control pairs are tile passes)
+    got = one.run(ang, "state")[0]
+    fused = N.Plan(ops, n, len(angles), consts).run(ang, "state")[0]
+    assert float((torch.view_as_real(got) - torch.view_as_real(fused)).abs().max()) < 1e-6
+    psi = c_port.simulate(tape, n)
+    assert np.abs(got.cpu().numpy() - psi).max() < 1e-6
