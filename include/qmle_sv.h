@@ -168,9 +168,12 @@ int qmle_plan_destroy(qmle_plan *plan);
  * another tile geometry / order of commuting gates: results agree to float32 rounding.  meas_type:
  * QMLE_MEAS_STATE or QMLE_MEAS_EXPVAL_Z.  chosen[2] (optional) <- candidate index, padding; ms_before /
  * ms_after (optional) <- per-call times of the old and the new schedule.  Plans with a single schedule
- * (whole state in LDS, forced geometry, QMLE_PLAN_NO_FUSION) return QMLE_OK untouched.  A choice is
- * remembered per (tape, flags, measurement, device) for the life of the process.  Callers that cached
- * qmle_workspace_bytes must ask again afterwards. */
+ * (whole state in LDS, forced geometry, QMLE_PLAN_NO_FUSION) return QMLE_OK untouched (chosen = -1, -1).
+ * If the scratch allocation fails the plan keeps its schedule, QMLE_OK is returned and chosen[1] = -2
+ * ("not tuned": the caller may try again later).  A choice is remembered per (executed plan's tape,
+ * flags, batch class, device) for the life of the process: where both measurement types execute the
+ * same plan the first one tuned decides for both.  Callers that cached qmle_workspace_bytes must ask
+ * again afterwards. */
 int qmle_plan_autotune(qmle_plan *plan, int meas_type, int n_obs, int batch, int top_k, int reps,
                        qmle_stream stream, int32_t *chosen, double *ms_before, double *ms_after);
 

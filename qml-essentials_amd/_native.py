@@ -366,7 +366,9 @@ class Plan:
     def autotune(self, meas: str, n_obs: int = 0, batch: int = 32, top_k: int = 4, reps: int = 3) -> dict:
         """Opt-in (``qmle_plan_autotune``): time the cost model's best ``top_k`` schedules for this
         measurement ("state" / "expval") and batch size on the current GPU and keep the fastest.
-        -> ``{"candidate", "padding", "ms_before", "ms_after"}`` (candidate -1: nothing to tune)."""
+        -> ``{"candidate", "padding", "ms_before", "ms_after"}`` (candidate -1: nothing to tune; padding -2:
+        not tuned, the scratch allocation failed).  Choices are remembered per executed plan: where "state"
+        and "expval" run the same plan the first measurement tuned decides for both."""
         require_gpu()
         chosen = (C.c_int32 * 2)(-1, -1)
         before, after = C.c_double(0.0), C.c_double(0.0)
@@ -445,8 +447,9 @@ class Plan:
         tuned = self.__dict__.setdefault("_tuned", set())
         if meas in tuned:
             return False
-        tuned.add(meas)
-        self.autotune(meas, n_obs, batch=B)
+        got = self.autotune(meas, n_obs, batch=B)  # (raises on failure: not remembered, tried again)
+        if got["padding"] != -2:  # -2: no scratch memory next to the caller's buffers -- retry next run
+            tuned.add(meas)
         return True  # (a workspace sized for the old schedule is void)
 
     def run(self, angles, meas: str, obs_wires: Sequence[int] = (), out=None, workspace=None,

@@ -881,7 +881,10 @@ int qmle_plan_autotune(qmle_plan *plan, int meas_type, int n_obs, int batch, int
       ((target->flags >> 8) & 0xffffu))
     return QMLE_OK;  // one schedule only: nothing to tune
   const int batch_class = batch >= 256 ? 2 : batch >= 16 ? 1 : 0;
-  const uint64_t key = tape_hash(target, meas_type, batch_class);
+  // keyed by the TARGET plan, not by the measurement: without a folded child "state" and "expval" execute the
+  // same plan, and two remembered choices for one plan would overwrite each other's schedule (and rebuild the
+  // device image) on every alternation.  The first measurement tuned decides; the other adopts its choice.
+  const uint64_t key = tape_hash(target, owner != plan ? 1 : 0, batch_class);
   {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     auto it = g_tuned.find(key);
@@ -925,6 +928,8 @@ int qmle_plan_autotune(qmle_plan *plan, int meas_type, int n_obs, int batch, int
   const size_t total = align_up(ang_bytes, 256) + align_up(out_bytes, 256) + ws_bytes + 512;
   if (hipMalloc((void **)&scratch, total) != hipSuccess) {
     for (Cand &c : cands) if (c.p) (void)qmle_plan_destroy(c.p);
+    (void)hipGetLastError();
+    if (chosen) chosen[1] = -2;  // "not tuned" (as opposed to -1 / -1: nothing to tune): the caller may try again
     return QMLE_OK;  // no room to tune next to the caller's buffers: keep the model's schedule
   }
   float *d_ang = (float *)scratch;

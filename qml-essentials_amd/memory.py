@@ -61,6 +61,12 @@ def estimate_peak_bytes(n_qubits: int, batch_size: int, type: str, use_density: 
     lds_limit = 13 if x64 else 14
     if general_obs and type == "expval":
         in_flight = 2 * batch_size * state  # psi of every sample + the contraction's temporary
+    elif x64 and n_qubits > lds_limit:
+        # qmle_workspace_bytes_f64 (qmle_f64.hip): above 13 qubits the complex128 engine works
+        # in its own round of state buffers for EVERY measurement type, "state" included
+        in_flight = min(batch_size, max(1, F64_IN_FLIGHT_TARGET_BYTES // state), 65535) * state
+    elif x64 and type == "density":
+        in_flight = batch_size * state  # (n <= 13: psi of every sample before the outer product)
     elif type == "state":
         in_flight = 0  # computed in place in the output
     elif n_qubits <= lds_limit and type in ("probs", "expval"):

@@ -187,12 +187,20 @@ class Model:
         mirror is materialised on first access -- like a ``jax`` device array, which the
         reference's ``params`` are (``model.py:687-693``), turns into NumPy only when asked."""
         if self._params is None:
-            self._params = self._params_dev.detach().cpu().numpy().astype(np.float64)
+            # a read-only snapshot: the live storage is the device tensor, so an in-place edit of
+            # this mirror could not take effect -- it raises instead of being silently ignored
+            # (assign ``model.params = new`` to change them).  Not cached: the device tensor may
+            # be updated in place (an optimizer step) and a cached mirror would go stale.
+            mirror = self._params_dev.detach().cpu().numpy().astype(np.float64)
+            mirror.setflags(write=False)
+            return mirror
         return self._params
 
     @params.setter
     def params(self, value) -> None:
-        if self._is_cuda(value):  # device-resident: no copy, the host mirror is lazy
+        if self._is_cuda(value):  # device-resident: the host mirror is made on demand.  The
+            # tensor is kept BY REFERENCE (no copy: a training loop's in-place updates are meant
+            # to be seen by the next call); ``model.params`` reads it back afresh each time.
             value = value.detach()
             if value.dim() == 2:
                 value = value.unsqueeze(0)
@@ -765,7 +773,10 @@ class Model:
         cc, p_leaf, x_leaf, _b_i, _b_p, _cross, zero_inputs = rec
         if not p_leaf or x_leaf:
             return None
-        self._execution_type = "state"
+        if self._execution_type != "state":  # through the setter: it derives _result_shape
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.execution_type = "state"
         self._zero_inputs = zero_inputs
         self._batch_shape = (1, n_param_sets, 1)
         return cc, [1], [n_param_sets if n_param_sets > 1 else 1], n_param_sets

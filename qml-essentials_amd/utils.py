@@ -101,7 +101,14 @@ def _philox_words(k: PRNGKey) -> np.ndarray:
     """The two 64-bit key words numpy's Philox takes from the key's SeedSequence (cached per key:
     the hash behind ``generate_state`` costs ~10 us, an analysis loop re-seeded with the same key
     every call should not pay it each time)."""
-    ident = (k._seq.entropy, tuple(k._seq.spawn_key), k._seq.pool_size)
+    ent = k._seq.entropy  # (an int, or a sequence of ints: SeedSequence([1, 2, 3]))
+    if isinstance(ent, (list, tuple, np.ndarray)):
+        ent = tuple(int(e) for e in np.asarray(ent).ravel())
+    ident = (ent, tuple(k._seq.spawn_key), k._seq.pool_size)
+    try:
+        hash(ident)
+    except TypeError:  # an entropy of some other unhashable kind: no caching
+        return k._seq.generate_state(2, np.uint64)
     w = _WORDS.get(ident)
     if w is None:
         if len(_WORDS) > 4096:

@@ -267,3 +267,17 @@ def test_real_input_fft_equals_the_complex_transform_and_is_exactly_hermitian():
             got = Coefficients._fft_real(v)
             np.testing.assert_allclose(got, np.fft.fft(v, axis=0) / n, rtol=0, atol=1e-15)
             assert np.array_equal(got[1:], np.conj(got[1:][::-1]))
+
+
+def test_key_with_a_sequence_entropy_draws():
+    """``SeedSequence([1, 2, 3])`` has a list entropy; the cached Philox key words must not
+    need it hashable, and the draw equals numpy's own stream for that sequence."""
+    from qml_essentials_amd import utils
+
+    seq = np.random.SeedSequence([1, 2, 3])
+    k = utils.PRNGKey(seq)
+    got = utils.uniform(k, (7,), 0.0, 1.0)
+    again = utils.uniform(utils.PRNGKey(np.random.SeedSequence([1, 2, 3])), (7,), 0.0, 1.0)
+    assert np.array_equal(np.asarray(got), np.asarray(again))
+    w = utils._philox_words(k)
+    assert np.array_equal(w, seq.generate_state(2, np.uint64))
