@@ -154,8 +154,9 @@ def max_over_ranks(value):
     return [float(v) for v in every.cpu()]
 
 
-def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, profile=True):
-    """`steps` timed calls of Model(n, layers, HE) on B parameter sets per rank under plan flags
+def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, profile=True,
+             circuit="Hardware_Efficient"):
+    """`steps` timed calls of Model(n, layers, circuit) on B parameter sets per rank under plan flags
     `flags`; returns timing, the plan description and the per-stage HIP-event times (rank 0)."""
     from qml_essentials_amd import _native as N
     from qml_essentials_amd import distributed, simulation
@@ -163,11 +164,12 @@ def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, prof
 
     rank = distributed.world()[0]
     with plan_flags(flags):
-        model = Model(n, layers, "Hardware_Efficient", data_reupload=dru)
+        model = Model(n, layers, circuit, data_reupload=dru)
         rng = np.random.default_rng(1000)
         params = rng.uniform(0, 2 * np.pi, (B * size, *model.params.shape[1:])).astype(np.float32)
         inputs = None if x is None else np.full((1, 1), x, dtype=np.float32)
-        tape, _ = model.record_tape(params=params[:2], inputs=inputs)
+        # (two rows: the batched tape, whatever B -- the device path compiles the same affine plan for B = 1)
+        tape, _ = model.record_tape(params=params[:2] if len(params) > 1 else np.repeat(params, 2, 0), inputs=inputs)
         low = simulation.LoweredTape(tape, n)
         top = simulation.get_plan(low)
         folded = top.describe().get("absorbed_ops", 0)
@@ -197,7 +199,7 @@ def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, prof
             stage_ms, stage_cnt, overflow = plan.profile_end()
     per_rank = max_over_ranks(elapsed)
     elapsed = max(per_rank)
-    assert tuple(out.shape) == (B * size, n) and bool(torch.isfinite(out).all())
+    assert tuple(out.reshape(-1, n).shape) == (B * size, n) and bool(torch.isfinite(out).all())
     return {"elapsed": elapsed, "elapsed_per_rank": per_rank, "out": out, "desc": desc,
             "n_gates": len(low.ops), "folded": folded,
             "stage_ms": stage_ms, "stage_cnt": stage_cnt, "overflow": overflow, "params": params,
@@ -374,11 +376,13 @@ def k1_sweep(n=28, reps=24, warmup=8):
     st = torch.view_as_complex(st / st.norm()).contiguous()
     ang = torch.full((1, 1), 1.234, device="cuda")
     out = {}
-    for gate, bytes_per_amp in (("RX", 16), ("RZ", 16), ("CX", 8), ("CRX", 8)):
+    # SURVEY 8-d bytes per amplitude: dense / diagonal 1-qubit 16, controlled 2x2 (CX, CRX, CRZ) 8 -- the
+    # control = 1 half --, controlled phase (CZ, CPhase) 4 -- the |11> quarter (operations.py:1357-1487, 1171-1201)
+    for gate, bytes_per_amp in (("RX", 16), ("RZ", 16), ("CX", 8), ("CRX", 8), ("CRZ", 8), ("CZ", 4), ("CPhase", 4)):
         per_wire = []
         for w in range(n):
             wires = [w] if gate in ("RX", "RZ") else [(w + 1) % n, w]
-            slots = [0] if gate != "CX" else []
+            slots = [0] if gate not in ("CX", "CZ") else []
             plan = N.Plan([(gate, wires, slots, -1)], n, 1, flags=N.PLAN_NO_FUSION)
             ws = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
             for _ in range(warmup):  # (the chip's clock settles over the first milliseconds of a burst)
@@ -393,8 +397,11 @@ def k1_sweep(n=28, reps=24, warmup=8):
         # 128-byte line (16 amplitudes), so both control values share each line and all 16 D bytes must move
         # whatever the kernel does; higher controls select whole lines and 8 D suffices (SURVEY 8-d's figure)
         att = [bytes_per_amp] * n
-        if gate in ("CX", "CRX"):
+        if gate in ("CX", "CRX", "CRZ"):
             att = [16 if (n - 1 - ((w + 1) % n)) <= 3 else 8 for w in range(n)]
+        elif gate in ("CZ", "CPhase"):  # control AND target must select whole lines for the quarter to suffice
+            att = [bytes_per_amp * (2 if (n - 1 - ((w + 1) % n)) <= 3 else 1) * (2 if (n - 1 - w) <= 3 else 1)
+                   for w in range(n)]
         gba = [a * D / t / 1e6 for a, t in zip(att, per_wire)]
         out[gate] = {"bytes_per_amplitude": bytes_per_amp,
                      "attainable_bytes_per_amplitude_per_target_wire": att,
@@ -444,7 +451,40 @@ def _wall(fn, reps):
     return sorted(ts)[len(ts) // 2], out, sorted(gs)[len(gs) // 2]
 
 
-def expressibility_leg(n=12, samples=1024, reps=21):
+def collective_ms(rows_per_rank, cols, reps=15):
+    """The ONE collective of a sharded call by itself: `all_gather_rows` of (rows_per_rank x world, cols) float32
+    results, each rank contributing its block -- median ms over `reps`, max over ranks (None for one rank: a
+    single-rank call runs no collective).  Device tensors under nccl (RCCL), host tensors under a gloo rehearsal."""
+    from qml_essentials_amd import distributed
+
+    rank, size = distributed.world()
+    if size == 1:
+        return None
+    dev = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+    block = torch.full((rows_per_rank, cols) if cols > 1 else (rows_per_rank,), float(rank), dtype=torch.float32, device=dev)
+    ts = []
+    for i in range(reps + 3):
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        distributed.barrier()
+        t0 = time.perf_counter()
+        full = distributed.all_gather_rows(block, rows_per_rank * size)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if i >= 3:
+            ts.append(dt)
+    assert full.shape[0] == rows_per_rank * size
+    return round(max(max_over_ranks(sorted(ts)[len(ts) // 2])) * 1e3, 4)
+
+
+# saturated weak-scaling companions of the two strong-scaling legs (VERDICT r4 item 7): at 8 ranks C3 is 128
+# pairs and C4 512 grid points per GPU -- pure latency; these keep every GPU full whatever the world size
+C3_SATURATED_PAIRS_PER_RANK = 16384
+C4_SATURATED_POINTS_PER_RANK = 32768
+
+
+def expressibility_leg(n=12, samples=1024, reps=21, warm=100, scaling="strong"):
     """BASELINE config 3 (strong scaling): KL-to-Haar, 12 qubits, 1024 pairs (2048 states), HE 3
     layers, no DRU; the PAIRS are split over the ranks, one all-gather of 1024 floats."""
     from qml_essentials_amd import distributed
@@ -453,20 +493,22 @@ def expressibility_leg(n=12, samples=1024, reps=21):
 
     m = Model(n, 3, "Hardware_Efficient", data_reupload=False)
     Expressibility.kl_divergence_to_haar(m, n_samples=max(64, distributed.world()[1]), n_bins=75, random_key=1)
-    for _ in range(100):  # ~20 ms: past the clock transient that follows the HBM-bound headline steps
+    for _ in range(warm):  # ~20 ms: past the clock transient that follows the HBM-bound headline steps
         Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75, random_key=1000)
     sec, kl, gpu_ms = _wall(lambda: Expressibility.kl_divergence_to_haar(m, n_samples=samples, n_bins=75,
                                                                          random_key=1000), reps)
     size = distributed.world()[1]
+    per_rank = [hi - lo for lo, hi in distributed.all_shard_bounds(samples, size)]
     return {"seconds": round(sec, 6), "gpu_ms": round(gpu_ms, 4), "kl": float(np.mean(kl)), "n_qubits": n, "pairs": samples,
-            "pairs_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(samples, size)],
-            "scaling": "strong", "collective": "one all-gather of the fidelities (4 KiB)",
+            "pairs_per_rank": per_rank, "pairs_per_s": round(samples / sec, 1),
+            "scaling": scaling, "collective": f"one all-gather of the fidelities ({samples * 4 / 1024:g} KiB)",
+            "collective_ms": collective_ms(max(per_rank), 1),
             "note": "median of %d calls, max over ranks; the whole call: parameter sampling (on the GPU), 2 x pairs states, "
                     "fidelities, histogram (GPU), one device -> host copy of the 75 counts, KL on the host; gpu_ms = HIP events "
                     "around the call on the launch stream" % reps}
 
 
-def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
+def fourier_grid_leg(n=10, layers=6, points=4096, reps=21, warm=100, scaling="strong"):
     """BASELINE config 4 (strong scaling): Model(10, 6, HE) on the 2^12-point input grid,
     expval averaged over the wires; the GRID is split over the ranks (512 points per GPU at N = 8),
     one all-gather of (4096, 10) floats; the FFT of the 4096 values runs on the host."""
@@ -483,14 +525,16 @@ def fourier_grid_leg(n=10, layers=6, points=4096, reps=21):
         y = m(inputs=x, force_mean=True)
         return Coefficients._fft_real(y.cpu().numpy().astype(np.float64))
 
-    for _ in range(100):  # ~20 ms of warm-up, as for the other legs
+    for _ in range(warm):  # ~20 ms of warm-up, as for the other legs
         call()
     sec, coeffs, gpu_ms = _wall(call, reps)
     size = distributed.world()[1]
+    per_rank = [hi - lo for lo, hi in distributed.all_shard_bounds(points, size)]
     return {"seconds": round(sec, 6), "gpu_ms": round(gpu_ms, 4), "n_qubits": n, "n_layers": layers, "grid_points": points,
-            "points_per_rank": [hi - lo for lo, hi in distributed.all_shard_bounds(points, size)],
+            "points_per_rank": per_rank, "points_per_s": round(points / sec, 1),
             "c0": float(coeffs[0].real), "max_abs_coeff_beyond_degree": float(np.abs(coeffs[layers * n + 1:points // 2]).max()),
-            "scaling": "strong", "collective": "one all-gather of the expectation values (160 KiB)",
+            "scaling": scaling, "collective": f"one all-gather of the expectation values ({points * n * 4 / 1024:g} KiB)",
+            "collective_ms": collective_ms(max(per_rank), n),
             "note": "median of %d calls, max over ranks; circuit batch on the GPU, one device -> host copy of the values, "
                     "float64 FFT on the host; gpu_ms = HIP events around the call on the launch stream" % reps}
 
@@ -646,6 +690,143 @@ def k2_unfused_leg(n, B, steps=2):
                                  "launch of a state also holds the |0..0> initialisation; <Z> is one more "
                                  "read (k_expval_partial), outside this kernel's time"},
             "max_abs_diff_vs_headline_expvals": None, "_out": run["out"]}
+
+
+L2_PEAK_GBPS = 34500.0          # aggregate L2, /opt/skills/guides/MI355X_MICROARCH.md:316
+MALL_GATHER_GBPS = 8600.0       # Infinity-Cache-resident table, measured gather rate, same guide :349
+
+
+def pass_table(run, dense):
+    """Every pass of a profiled run: kernel, register-tile groups, HIP-event time per state, bytes moved per
+    state, rate, and which resource the pass is nearer to: `hbm` when it moves its bytes at >= 0.55 of the
+    8 TB/s peak, else `valu+lds` (the pass spends its time in register-tile groups: packed-FMA issue and LDS
+    round trips, profiles/r05_deep_default_sq.txt), `launch` for passes under 3 us per state-launch."""
+    desc, n, B, steps = run["desc"], run["n"], run["B"], run["steps"]
+    ns = len(desc["stages"])
+    rows = []
+    for i, st in enumerate(desc["stages"]):
+        moved = st["read_bytes_from_zero"] + st["write_bytes_from_zero"]
+        if i == ns - 1 and st["kind"] == "tile":
+            moved = st["read_bytes_from_zero"]
+        us = run["stage_ms"][i] * 1e3 / (B * steps)
+        gbps = moved / us / 1e3 if us > 0 else 0.0
+        groups = len(st.get("fast_groups") or st.get("groups") or [])
+        launch_us = run["stage_ms"][i] * 1e3 / max(1, run["stage_cnt"][i])
+        bound = "hbm" if gbps >= 0.55 * HBM_PEAK_GBPS else ("launch" if launch_us < 3.0 else "valu+lds")
+        rows.append({"pass": i + 1, "kernel": kernel_of_stage(st, i, ns, n, dense), "T": st.get("T"),
+                     "groups": groups, "ops": len(st["src_ops"]), "us_per_state": round(us, 3),
+                     "bytes_moved_per_state": int(moved), "moved_GBps": round(gbps, 1), "bound": bound})
+    return rows
+
+
+def bound_of(rows):
+    """Time-weighted verdict over a pass table: share of the step spent in passes of each kind."""
+    tot = sum(r["us_per_state"] for r in rows) or 1.0
+    share = {}
+    for r in rows:
+        share[r["bound"]] = share.get(r["bound"], 0.0) + r["us_per_state"] / tot
+    top = max(share, key=share.get)
+    return top, {k: round(v, 3) for k, v in sorted(share.items())}
+
+
+def c2_leg(cpu_seconds=6.0):
+    """BASELINE config 2: Model(20, 4, Hardware_Efficient), data re-uploading, input 0.5, expval on all 20 wires
+    (480 reference gates per state, model.py:1572-1737) -- the regime where a state (8 MiB) fits the L2 / the
+    Infinity Cache: single sample, batches of 256 and 1024 parameter sets under the default engine, batch 1024
+    with every amplitude live beside it.  Rates are quoted against BOTH the HBM peak and the L2 figure; bytes
+    are the executed plan's passes.  CPU: the oracle's C/OpenMP port on the same parameter sets, every <Z> row
+    compared (complex64 both sides: 1e-5)."""
+    from oracle import c_port, circuits as OC  # the checker (cpu_baseline leg)
+    from qml_essentials_amd import _native as N
+
+    n, layers = 20, 4
+    out = {"workload": "Model(20, 4, Hardware_Efficient), data re-uploading, input 0.5, <Z> on 20 wires, 480 gates/state"}
+    runs = {}
+    for label, B, steps, fl in (("single_sample", 1, 40, 0), ("batch_256", 256, 8, 0), ("batch_1024", 1024, 4, 0),
+                                ("batch_1024_all_live", 1024, 4, N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)):
+        run = timed_k2(n, B, 1, steps, 3, fl, layers=layers, dru=True, x=0.5)
+        dense = fl != 0
+        sm = summarize(run, dense)
+        rows = pass_table(run, dense)
+        fam = families(run, dense)
+        name = max(fam, key=lambda k: fam[k]["ms"])
+        dom = fam[name]
+        gbps = dom["moved"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
+        top, share = bound_of(rows)
+        kernel_ms = sum(run["stage_ms"]) / steps
+        out[label] = {
+            "batch": B, "steps": steps, "ms_per_step": sm["ms_per_step"], "kernel_ms_per_step": round(kernel_ms, 4),
+            "statevectors_per_s": sm["statevectors_per_s"], "gate_applies_per_s": sm["gate_applies_per_s"],
+            "gates_counted_per_state": sm["gates_counted_per_state"],
+            "operators_executed_per_state": run["desc"]["n_lowered"],
+            "hbm_passes_per_state": sm["hbm_passes_per_state"],
+            "bytes_moved_per_state": sm["hbm_bytes_moved_per_state"],
+            "step_moved_GBps": round(sm["hbm_bytes_moved_per_state"] * B / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
+            "roofline": {"bound": top, "time_share_by_bound": share, "kernel": name,
+                         "achieved": round(gbps, 1), "unit": "GB/s",
+                         "peak": HBM_PEAK_GBPS, "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "peak_l2": L2_PEAK_GBPS, "frac_of_l2": round(gbps / L2_PEAK_GBPS, 4),
+                         "infinity_cache_gather_GBps": MALL_GATHER_GBPS,
+                         "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
+                         "kernel_share_of_step": round(dom["ms"] / (run["elapsed"] * 1e3), 4),
+                         "all_kernels_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
+                         "note": "achieved = bytes the dominant kernel's launches read + wrote (the executed plan's "
+                                 "passes) / their HIP-event time; a 20-qubit state is 8 MiB: one launch's states "
+                                 "(<= 4 GiB in flight) do not fit the 256 MiB Infinity Cache beyond ~32 states, so "
+                                 "batches stream from HBM and the single sample runs out of L2 / Infinity Cache"},
+            "per_pass": rows}
+        runs[label] = run
+    # CPU port on the batch's own parameter sets + parity of every row it computes
+    spec = OC.ModelSpec(n, layers, "Hardware_Efficient")
+    threads = c_port.lib().svc_max_threads()
+    rows_p = runs["batch_256"]["params"]
+    gpu = runs["batch_256"]["out"].reshape(-1, n).cpu().numpy()
+    gpu_live = runs["batch_1024_all_live"]["out"].reshape(-1, n).cpu().numpy()
+    done, worst, worst_live, t0 = 0, 0.0, 0.0, time.perf_counter()
+    while done < min(32, len(rows_p)):
+        tape = OC.model_tape(spec, rows_p[done], [0.5])
+        psi = c_port.simulate(tape, n)
+        ez = c_port.expval_z(psi, n, list(range(n)))
+        worst = max(worst, float(np.abs(ez - gpu[done]).max()))
+        worst_live = max(worst_live, float(np.abs(ez - gpu_live[done]).max()))
+        done += 1
+        if time.perf_counter() - t0 >= cpu_seconds:
+            break
+    el = time.perf_counter() - t0
+    if max(worst, worst_live) > 1e-5:
+        raise SystemExit(f"bench.py: C2 GPU <Z> differs from the CPU oracle port by {max(worst, worst_live):.3e} (> 1e-5)")
+    single = runs["single_sample"]["out"].reshape(-1, n).cpu().numpy()
+    tape = OC.model_tape(spec, runs["single_sample"]["params"][0], [0.5])
+    ez1 = c_port.expval_z(c_port.simulate(tape, n), n, list(range(n)))
+    worst1 = float(np.abs(ez1 - single[0]).max())
+    if worst1 > 1e-5:
+        raise SystemExit(f"bench.py: C2 single-sample GPU <Z> differs from the CPU oracle port by {worst1:.3e}")
+    gates = sum(1 for g in tape if g[0] != "Barrier")
+    out["cpu_baseline"] = {"value": round(done * gates / el, 2), "unit": "gate-applies/s", "cores": threads, "kind": "port",
+                           "statevectors_per_s": round(done / el, 3), "ms_per_state": round(el / done * 1e3, 2),
+                           "sample": f"{done} of the batch's parameter sets (same tape: {gates} gates + <Z> on {n} wires), "
+                                     f"oracle/sv_cpu.c with {threads} OpenMP threads, {el:.1f} s; every row compared with the GPU's",
+                           "max_abs_diff_vs_gpu_expvals": {"batch_256": worst, "batch_1024_all_live": worst_live,
+                                                           "single_sample": worst1}}
+    return out
+
+
+def k2_circuit19_leg(n, B, size, steps, warmup):
+    """SURVEY 8-d K2's second tape: Circuit_19 (RX, RZ per wire + a ring of CRX: 48 one-qubit + 24 CRX gates at
+    n = 24, ansaetze.py:671-683), one layer, no data re-uploading, every amplitude live, batch B."""
+    from qml_essentials_amd import _native as N
+
+    fl = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
+    run = timed_k2(n, B, size, steps, warmup, fl, circuit="Circuit_19")
+    sm = summarize(run, True)
+    rf = roofline_of(run, True, None)
+    sm["operators_executed_per_state"] = run["desc"]["n_lowered"]
+    sm["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches",
+                                          "passes_per_state", "bytes_moved_per_launch", "algorithmic_bytes_per_launch",
+                                          "algorithmic_GBps", "fusion_factor", "kernel_share_of_step", "all_kernels_ms", "per_pass")}
+    sm["workload"] = (f"Model({n}, 1, Circuit_19, data_reupload=False), {run['n_gates']} gates/state, all amplitudes live, "
+                      f"batch {B}, {steps} timed steps")
+    return sm, run
 
 
 def _he_layer_ops(n):
@@ -889,8 +1070,16 @@ def main(argv=None):
     books = rank_bookkeeping(a, rank, size)
     if a.rendezvous_only:
         distributed.barrier()
+        # the one collective of each sharded leg, by itself, on the payloads the legs gather (every rank takes part)
+        legs = {"c3_expressibility_12q_1024pairs": {"rows_per_rank": -(-1024 // size), "cols": 1},
+                "c4_fourier_10q_6l_4096grid": {"rows_per_rank": -(-4096 // size), "cols": 10},
+                "c3_saturated_weak": {"rows_per_rank": C3_SATURATED_PAIRS_PER_RANK, "cols": 1},
+                "c4_saturated_weak": {"rows_per_rank": C4_SATURATED_POINTS_PER_RANK, "cols": 10}}
+        for leg in legs.values():
+            leg["collective_ms"] = collective_ms(leg["rows_per_rank"], leg["cols"], reps=5)
+            leg["payload_bytes_per_rank"] = leg["rows_per_rank"] * leg["cols"] * 4
         if rank == 0:
-            print(json.dumps({"rendezvous_only": True, "n_gpus": size, **books}), flush=True)
+            print(json.dumps({"rendezvous_only": True, "n_gpus": size, **books, "scaling_legs": legs}), flush=True)
         if size > 1:
             torch.distributed.destroy_process_group()
         return
@@ -910,10 +1099,12 @@ def main(argv=None):
     head_flags = DENSE | (N.PLAN_NO_FUSION if a.no_fusion else 0)
     head = timed_k2(n, B, size, a.steps, a.warmup, head_flags)
 
-    c3 = c4 = None
+    c3 = c4 = c3s = c4s = None
     if not a.skip_aux:  # sharded over all ranks -> every rank takes part
         c3 = expressibility_leg()
         c4 = fourier_grid_leg()
+        c3s = expressibility_leg(samples=C3_SATURATED_PAIRS_PER_RANK * size, reps=7, warm=5, scaling="weak")
+        c4s = fourier_grid_leg(points=C4_SATURATED_POINTS_PER_RANK * size, reps=7, warm=5, scaling="weak")
     if rank != 0:
         distributed.barrier()
         return
@@ -951,6 +1142,8 @@ def main(argv=None):
     if c3 is not None:
         result["c3_expressibility_12q_1024pairs"] = c3
         result["c4_fourier_10q_6l_4096grid"] = c4
+        result["c3_saturated_weak"] = c3s
+        result["c4_saturated_weak"] = c4s
     if not a.skip_aux and size == 1 and not a.no_fusion:
         # SURVEY 8-d `achieved_unfused`: one HBM pass per reference gate, no 1-qubit merging
         try:
@@ -975,6 +1168,26 @@ def main(argv=None):
                       "amplitudes are never touched")
         result["exact_shortcuts"] = s2
         del sc
+        # SURVEY 8-d K2, second tape: Circuit_19 (48 one-qubit + 24 CRX), all amplitudes live
+        try:
+            c19, run19 = k2_circuit19_leg(n, B, size, 5, 2)
+            from oracle import c_port, circuits as OC  # the checker: a few rows against the C port
+
+            spec19 = OC.ModelSpec(n, 1, "Circuit_19", data_reupload=False)
+            rows19 = run19["out"][:3].cpu().numpy()
+            worst19 = 0.0
+            for k in range(3):
+                psi = c_port.simulate(OC.model_tape(spec19, run19["params"][k], [0.0]), n)
+                worst19 = max(worst19, float(np.abs(c_port.expval_z(psi, n, list(range(n))) - rows19[k]).max()))
+            if worst19 > 1e-5:
+                raise SystemExit(f"bench.py: Circuit_19 GPU <Z> differs from the CPU oracle port by {worst19:.3e}")
+            c19["max_abs_diff_vs_cpu_port_expvals_3_rows"] = worst19
+            result["k2_circuit19"] = c19
+            del run19
+        except SystemExit:
+            raise
+        except Exception as e:  # pragma: no cover
+            result["k2_circuit19"] = {"error": repr(e)}
         # a deeper circuit: 4 layers with data re-uploading = 5 ansatz + 4 encoding layers
         try:
             deep = {}
@@ -982,10 +1195,16 @@ def main(argv=None):
                 d = timed_k2(n, B, size, 3, 1, fl, layers=4, dru=True, x=0.5)
                 deep[label] = summarize(d, fl != 0)
                 deep[label]["operators_executed_per_state"] = d["desc"]["n_lowered"]
-                if fl:
-                    deep[label]["roofline"] = {k: v for k, v in roofline_of(d, True, None).items()
-                                               if k in ("kernel", "achieved", "frac", "algorithmic_GBps",
-                                                        "fusion_factor", "avg_launch_ms", "launches")}
+                rf = roofline_of(d, fl != 0, None)
+                rows = pass_table(d, fl != 0)
+                top, share = bound_of(rows)
+                deep[label]["roofline"] = {k: v for k, v in rf.items()
+                                           if k in ("kernel", "achieved", "peak", "unit", "frac", "algorithmic_GBps",
+                                                    "fusion_factor", "avg_launch_ms", "launches", "kernel_share_of_step")}
+                # what limits the step: time share of its passes by the resource each is nearer to
+                deep[label]["roofline"]["bound"] = top
+                deep[label]["roofline"]["time_share_by_bound"] = share
+                deep[label]["per_pass"] = rows
                 del d
             deep["workload"] = (f"Model({n}, 4, Hardware_Efficient) with data re-uploading, input 0.5: "
                                 f"{deep['all_live']['gates_counted_per_state']} gates/state, batch {B}, 3 timed steps")
@@ -1012,6 +1231,13 @@ def main(argv=None):
             raise
         except Exception as e:  # pragma: no cover
             result["sampling_loops_cpu_error"] = str(e)
+        # BASELINE config 2 (n = 20: the L2 / Infinity-Cache regime)
+        try:
+            result["c2_model_20q_4l"] = c2_leg()
+        except SystemExit:
+            raise
+        except Exception as e:  # pragma: no cover
+            result["c2_model_20q_4l"] = {"error": repr(e)}
         # LDS-resident regime (n <= 14 is bound by LDS / fp32 VALU, not by HBM)
         try:
             result["lds_regime"] = {
@@ -1035,8 +1261,66 @@ def main(argv=None):
                 raise
             except Exception as e:  # pragma: no cover
                 result["mw_28q"]["cpu_baseline"] = {"error": str(e)}
+    result["summary"] = summary_of(result)  # LAST key: a compact trailer the tail of the line always shows
     distributed.barrier()
     print(json.dumps(result), flush=True)
+
+
+def summary_of(r):
+    """Compact trailer (the LAST key of the line, < 4 KB): one figure per leg, so that a record which keeps only
+    the tail of stdout still shows every leg's number.  Every entry repeats a value that sits in full under the
+    key of the same name earlier in the line."""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    out = {"k2_headline": {"ms_per_step": r.get("ms_per_step"), "gate_applies_per_s": r.get("value"),
+                           "frac": g(r, "roofline", "frac"), "kernel": g(r, "roofline", "kernel"),
+                           "per_pass_ms": [p["avg_launch_ms"] for p in g(r, "roofline", "per_pass", default=[])]}}
+    for key in ("k2_unfused", "k2_circuit19"):
+        if isinstance(r.get(key), dict):
+            out[key] = {"ms_per_step": g(r, key, "ms_per_step"), "frac": g(r, key, "roofline", "frac"),
+                        "kernel": g(r, key, "roofline", "kernel"), "error": g(r, key, "error")}
+    for lab in ("all_live", "default_flags"):
+        if isinstance(g(r, "k2_deep", lab), dict):
+            out["k2_deep_" + lab] = {"ms_per_step": g(r, "k2_deep", lab, "ms_per_step"),
+                                     "frac": g(r, "k2_deep", lab, "roofline", "frac"),
+                                     "bound": g(r, "k2_deep", lab, "roofline", "bound"),
+                                     "time_share_by_bound": g(r, "k2_deep", lab, "roofline", "time_share_by_bound")}
+    c2 = r.get("c2_model_20q_4l")
+    if isinstance(c2, dict):
+        out["c2_model_20q_4l"] = {lab: {"ms_per_step": g(c2, lab, "ms_per_step"), "kernel_ms": g(c2, lab, "kernel_ms_per_step"),
+                                       "frac_hbm": g(c2, lab, "roofline", "frac"), "frac_l2": g(c2, lab, "roofline", "frac_of_l2"),
+                                       "bound": g(c2, lab, "roofline", "bound")}
+                                 for lab in ("single_sample", "batch_256", "batch_1024", "batch_1024_all_live") if lab in c2}
+        out["c2_model_20q_4l"]["cpu_ms_per_state"] = g(c2, "cpu_baseline", "ms_per_state")
+        out["c2_model_20q_4l"]["cpu_cores"] = g(c2, "cpu_baseline", "cores")
+        out["c2_model_20q_4l"]["error"] = c2.get("error")
+    for key in ("c3_expressibility_12q_1024pairs", "c4_fourier_10q_6l_4096grid", "c3_saturated_weak", "c4_saturated_weak"):
+        if isinstance(r.get(key), dict):
+            out[key] = {"seconds": g(r, key, "seconds"), "gpu_ms": g(r, key, "gpu_ms"), "collective_ms": g(r, key, "collective_ms"),
+                        "cpu_seconds": g(r, key, "cpu_baseline", "seconds_full_loop_extrapolated")}
+    lds = r.get("lds_regime")
+    if isinstance(lds, dict):
+        out["lds_regime"] = {k: {"frac_of_valu_peak": v.get("frac_of_valu_peak"), "states_per_s": v.get("states_per_s"),
+                                 "kernel_ms": v.get("kernel_ms")} if isinstance(v, dict) else v for k, v in lds.items()}
+    k1 = r.get("k1_single_gate_28q")
+    if isinstance(k1, dict):
+        out["k1_single_gate_28q"] = {gname: {"frac_min_mean_max": v.get("frac_of_8TBps_min_mean_max"),
+                                             "vs_attainable_min_mean_max": v.get("frac_of_8TBps_vs_attainable_min_mean_max"),
+                                             "wires_ge_0.70_of_attainable": v.get("target_wires_at_0.70_or_more_of_attainable")}
+                                     if isinstance(v, dict) else v for gname, v in k1.items()}
+    mw = r.get("mw_28q")
+    if isinstance(mw, dict):
+        out["mw_28q"] = {"ms": mw.get("ms"), "frac": g(mw, "roofline", "frac"), "moved_frac": g(mw, "roofline", "moved_frac"),
+                         "traffic": g(mw, "roofline", "traffic"), "fused_ms": mw.get("fused_ms"),
+                         "bound": g(mw, "roofline", "bound"), "error": mw.get("error")}
+    out["adjoint_gradient_20q_ms"] = g(r, "adjoint_gradient_20q", "ms")
+    out["cpu_baseline_gate_applies_per_s"] = g(r, "cpu_baseline", "value")
+    return out
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
   // workgroups in flight at any time are then spread over the whole state instead of one window of it
   const uint32_t blk = blk_mul ? (blockIdx.x * blk_mul) & (gridDim.x - 1u) : blockIdx.x;
   const uint64_t k = (uint64_t)blk * 256u + threadIdx.x;
-  if (MODE < 5 && k >= items) return;  // modes 5 .. 8: exact grids, whole waves
+  if ((MODE < 5 || MODE == 9) && k >= items) return;  // modes 5 .. 8: exact grids, whole waves
   const Mat2 m = load_mat2(mats + (size_t)b * mat_floats + mat_off);
   if constexpr (MODE == 0) {
     if constexpr (DIAG) {  // items = all chunks
@@ -192,6 +192,16 @@ k_direct_1q(float4 *__restrict__ states, int n, int pt, int pc,
     for (int u = 0; u < 4; ++u) st4<NT>(st + c0[u], v0[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) st4<NT>(st + (c0[u] | (1ull << (pt - 1))), v1[u]);
+  } else if constexpr (MODE == 9) {
+    // controlled PHASE (CZ, ControlledPhaseShift: diag(1, 1, 1, e^{i phi}), operations.py:1100, 1171-1201), control
+    // and target both on chunk bits: only the |11> quarter of the state changes -- 4 D bytes read, 4 D written
+    // (SURVEY 8-d), where the generic controlled-diagonal path (mode 2) rewrites the whole control = 1 half.
+    // items = chunks / 4.
+    const int lo = pt < pc ? pt - 1 : pc - 1, hi = pt < pc ? pc - 1 : pt - 1;
+    const uint64_t c = ins0_64(ins0_64(k, lo), hi) | (1ull << (pc - 1)) | (1ull << (pt - 1));
+    const float4 v = ld4<NT>(st + c);
+    const float2 x = cmul(m.m11, make_float2(v.x, v.y)), y = cmul(m.m11, make_float2(v.z, v.w));
+    st4<NT>(st + c, make_float4(x.x, x.y, y.x, y.y));
   } else {  // MODE 4: control is the in-chunk bit -> only the odd amplitude
     if constexpr (DIAG) {  // items = all chunks
       float4 v = ld4<NT>(st + k);
@@ -304,6 +314,8 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
       }
     }
   }
+  // CZ / CPhase with control and target on chunk bits: the |11> quarter only (mode 9)
+  if (diag && (op.flags & LF_PHASE) && op.nc == 1 && pc >= 1 && pt >= 1 && !k1_plain) { mode = 9; items = chunks >> 2; }
   if (items == 0) items = 1;
   // streaming (non-temporal) accesses once the working set dwarfs the Infinity Cache
   const bool nt = ((size_t)batch << n) * sizeof(float2) >= ((size_t)1 << 30);
@@ -332,6 +344,7 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     case 6: launch_direct_mode<6>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     case 7: launch_direct_mode<7>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     case 8: launch_direct_mode<8>(false, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
+    case 9: launch_direct_mode<9>(true, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
     default: launch_direct_mode<4>(diag, nt, grid, stream, st, n, pt, pc, mats, p->mat_floats, op.mat_off, items, blk_mul); break;
   }
   HIPCHK(hipGetLastError());

@@ -22,6 +22,7 @@ enum LKind : uint8_t {
 enum LFlag : uint8_t {
   LF_DIAG = 1,     // matrix is diagonal
   LF_PERMX = 2,    // matrix is exactly Pauli-X (CX / CCX / X): a pure swap of amplitudes
+  LF_PHASE = 4,    // diagonal with m00 == 1 exactly (CZ, ControlledPhaseShift): only target = 1 changes
 };
 
 // A run of ops applied in ONE LDS round trip: every thread gathers the 2^4 amplitudes

@@ -577,6 +577,7 @@ int compile_plan(qmle_plan *p) {
     lo.flags = is_diag_opcode(op.opcode) ? LF_DIAG : 0;
     if (op.opcode == QMLE_OP_X || op.opcode == QMLE_OP_CX || op.opcode == QMLE_OP_CCX)
       lo.flags |= LF_PERMX;
+    if (op.opcode == QMLE_OP_CZ || op.opcode == QMLE_OP_CPHASE) lo.flags |= LF_PHASE;  // (operations.py:1100, 1171-1201)
     BuildOp bo{};
     bo.opcode = op.opcode;
     for (int a = 0; a < 3; ++a) bo.slot[a] = op.slot[a];

@@ -30,6 +30,16 @@ def test_gpus_2_spawns_two_ranks_through_the_launcher():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
     assert rec["collective_backend"] == "gloo" and rec["launched_by"] == "bench.py"
     assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr
+    # the one collective of every sharded leg timed by itself, on the payload the leg gathers --
+    # the strong-scaling legs (C3: 1024 pairs, C4: 4096 x 10 values) and their saturated weak-scaling companions
+    legs = rec["scaling_legs"]
+    assert set(legs) == {"c3_expressibility_12q_1024pairs", "c4_fourier_10q_6l_4096grid",
+                         "c3_saturated_weak", "c4_saturated_weak"}
+    assert legs["c3_expressibility_12q_1024pairs"]["rows_per_rank"] == 512
+    assert legs["c4_fourier_10q_6l_4096grid"]["payload_bytes_per_rank"] == 2048 * 10 * 4
+    assert legs["c3_saturated_weak"]["rows_per_rank"] == 16384 and legs["c4_saturated_weak"]["rows_per_rank"] == 32768
+    for leg in legs.values():
+        assert leg["collective_ms"] is not None and 0.0 < leg["collective_ms"] < 5000.0
 
 
 def test_world_size_must_match_gpus():

@@ -153,6 +153,35 @@ def test_controlled_one_gate_passes_every_control_target_pair(burst, monkeypatch
     assert worst > 0.0
 
 
+@pytest.mark.parametrize("n", [3, 5, 12, 16])
+def test_controlled_phase_one_gate_passes_every_control_target_pair(n):
+    """k_direct_1q mode 9 (round 5): CZ / ControlledPhaseShift touch the |11> quarter only when control
+    and target both sit on chunk bits (positions >= 1); CRZ keeps the control = 1 half (mode 2).  Every
+    (control, target) position pair, one gate per launch, against the oracle."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(900 + n)
+    prefix = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    prefix += [("CX", [q, (q + 1) % n], ()) for q in range(n - 1)]
+    prefix += [("RX", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    flags = N.plan_flags(no_fusion=True, force_global=True)
+    worst = 0.0
+    for pc in range(n):
+        for pt in range(n):
+            if pt == pc or (n == 16 and not (pc <= 1 or pt <= 1 or (pc + pt) % 4 == 0)):
+                continue
+            c, t = n - 1 - pc, n - 1 - pt
+            gate = (("CZ", [c, t], ()), ("CPhase", [c, t], (0.7,)), ("CRZ", [c, t], (1.1,)))[(pc + 2 * pt) % 3]
+            tape = prefix + [gate]
+            got, plan = _run(tape, n, "state", flags=flags)
+            assert plan.describe()["stages"][-1]["kind"] == "direct"
+            want = OE.simulate_pure(tape, n, np.complex128)
+            err = np.abs(got[0] - want).max()
+            assert err < 1e-6, (gate, pc, pt, err)
+            worst = max(worst, err)
+    assert worst > 0.0
+
+
 @pytest.mark.parametrize("n", [4, 9, 13, 14])
 def test_every_wire_every_single_gate_kind(n):
     """One gate per circuit on a random state prefix: exercises every target /
