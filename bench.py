@@ -61,6 +61,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md:36
+VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak, same guide
 
 
 def parse_args(argv=None):
@@ -421,9 +422,6 @@ def k1_sweep(n=28, reps=24, warmup=8):
     return out
 
 
-VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak, /opt/skills/guides/MI355X_MICROARCH.md
-
-
 def _wall(fn, reps):
     """Median wall-clock of `fn` over `reps` calls -- `fn` returns HOST values, so a call is complete
     when it returns; each call starts from a synchronised device and a barrier, and counts as the
@@ -698,9 +696,9 @@ MALL_GATHER_GBPS = 8600.0       # Infinity-Cache-resident table, measured gather
 
 def pass_table(run, dense):
     """Every pass of a profiled run: kernel, register-tile groups, HIP-event time per state, bytes moved per
-    state, rate, and which resource the pass is nearer to: `hbm` when it moves its bytes at >= 0.55 of the
-    8 TB/s peak, else `valu+lds` (the pass spends its time in register-tile groups: packed-FMA issue and LDS
-    round trips, profiles/r05_deep_default_sq.txt), `launch` for passes under 3 us per state-launch."""
+    state and nominal flops, each as a rate and as a fraction of its peak (8 TB/s, 157.3 TFLOP/s fp32), and
+    which of the two the pass is nearer to: `hbm` or `valu+lds` (register-tile groups: packed-FMA issue and LDS
+    round trips; counters in profiles/r05_deep_default_sq.txt); `launch` for passes under 3 us per launch."""
     desc, n, B, steps = run["desc"], run["n"], run["B"], run["steps"]
     ns = len(desc["stages"])
     rows = []
@@ -712,11 +710,24 @@ def pass_table(run, dense):
         gbps = moved / us / 1e3 if us > 0 else 0.0
         groups = len(st.get("fast_groups") or st.get("groups") or [])
         launch_us = run["stage_ms"][i] * 1e3 / max(1, run["stage_cnt"][i])
-        bound = "hbm" if gbps >= 0.55 * HBM_PEAK_GBPS else ("launch" if launch_us < 3.0 else "valu+lds")
+        tf = st.get("flops_per_state", 0.0) / us / 1e6 if us > 0 else 0.0  # nominal fp32 flops of the pass's operators
+        hbm_frac, valu_frac = gbps / HBM_PEAK_GBPS, tf / VALU_PEAK_TFLOPS
+        bound = "launch" if launch_us < 3.0 else ("hbm" if hbm_frac >= valu_frac and hbm_frac >= 0.3 else "valu+lds")
         rows.append({"pass": i + 1, "kernel": kernel_of_stage(st, i, ns, n, dense), "T": st.get("T"),
-                     "groups": groups, "ops": len(st["src_ops"]), "us_per_state": round(us, 3),
-                     "bytes_moved_per_state": int(moved), "moved_GBps": round(gbps, 1), "bound": bound})
+                     "groups": groups, "ops": len(st["src_ops"]), "operators": st.get("n_lowered"), "us_per_state": round(us, 3),
+                     "bytes_moved_per_state": int(moved), "moved_GBps": round(gbps, 1), "hbm_frac": round(hbm_frac, 3),
+                     "tflops": round(tf, 1), "valu_frac": round(valu_frac, 3), "bound": bound})
     return rows
+
+
+def valu_roofline(run):
+    """The vector-unit side of a run whose passes are not HBM-bound: nominal fp32 flops of the operators the
+    plan applies (14 per amplitude for a dense 2x2, 6 for a diagonal one, halved per control, 0 for X / CX:
+    plan_flops_per_state; known-zero amplitudes NOT discounted) / the summed HIP-event time of the passes."""
+    sec = sum(run["stage_ms"]) * 1e-3 / (run["B"] * run["steps"])
+    tf = run["desc"]["flops_per_state"] / sec / 1e12 if sec > 0 else 0.0
+    return {"bound": "valu", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / VALU_PEAK_TFLOPS, 4), "fp32_flops_per_state": run["desc"]["flops_per_state"]}
 
 
 def bound_of(rows):
@@ -766,6 +777,7 @@ def c2_leg(cpu_seconds=6.0):
                          "achieved": round(gbps, 1), "unit": "GB/s",
                          "peak": HBM_PEAK_GBPS, "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "peak_l2": L2_PEAK_GBPS, "frac_of_l2": round(gbps / L2_PEAK_GBPS, 4),
+                         "valu": valu_roofline(run),
                          "infinity_cache_gather_GBps": MALL_GATHER_GBPS,
                          "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
                          "kernel_share_of_step": round(dom["ms"] / (run["elapsed"] * 1e3), 4),
@@ -1204,6 +1216,7 @@ def main(argv=None):
                 # what limits the step: time share of its passes by the resource each is nearer to
                 deep[label]["roofline"]["bound"] = top
                 deep[label]["roofline"]["time_share_by_bound"] = share
+                deep[label]["roofline"]["valu"] = valu_roofline(d)
                 deep[label]["per_pass"] = rows
                 del d
             deep["workload"] = (f"Model({n}, 4, Hardware_Efficient) with data re-uploading, input 0.5: "
@@ -1289,11 +1302,13 @@ def summary_of(r):
             out["k2_deep_" + lab] = {"ms_per_step": g(r, "k2_deep", lab, "ms_per_step"),
                                      "frac": g(r, "k2_deep", lab, "roofline", "frac"),
                                      "bound": g(r, "k2_deep", lab, "roofline", "bound"),
+                                     "valu_frac": g(r, "k2_deep", lab, "roofline", "valu", "frac"),
                                      "time_share_by_bound": g(r, "k2_deep", lab, "roofline", "time_share_by_bound")}
     c2 = r.get("c2_model_20q_4l")
     if isinstance(c2, dict):
         out["c2_model_20q_4l"] = {lab: {"ms_per_step": g(c2, lab, "ms_per_step"), "kernel_ms": g(c2, lab, "kernel_ms_per_step"),
                                        "frac_hbm": g(c2, lab, "roofline", "frac"), "frac_l2": g(c2, lab, "roofline", "frac_of_l2"),
+                                       "valu_frac": g(c2, lab, "roofline", "valu", "frac"),
                                        "bound": g(c2, lab, "roofline", "bound")}
                                  for lab in ("single_sample", "batch_256", "batch_1024", "batch_1024_all_live") if lab in c2}
         out["c2_model_20q_4l"]["cpu_ms_per_state"] = g(c2, "cpu_baseline", "ms_per_state")

@@ -1133,6 +1133,23 @@ static double plan_flops_per_state(const qmle_plan *p) {
   return f;
 }
 
+// the same count for the operators of one stage (nominal: known-zero amplitudes are not discounted)
+static double stage_flops_per_state(const qmle_plan *p, const Stage &st) {
+  const double D = std::ldexp(1.0, p->n);
+  double f = 0;
+  for (int i = st.op_begin; i < st.op_end && i < (int)p->dev_ops.size(); ++i) {
+    const LoweredOp &op = p->dev_ops[i];
+    const double live = D / (double)(1u << op.nc);
+    switch (op.kind) {
+      case LK_1Q: f += (op.flags & LF_PERMX) ? 0.0 : (op.flags & LF_DIAG) ? 6.0 * live : 14.0 * live; break;
+      case LK_2Q: f += 30.0 * live; break;
+      case LK_DIAG_ALL: f += 6.0 * D; break;
+      case LK_4Q: f += 126.0 * D; break;
+    }
+  }
+  return f;
+}
+
 std::string describe_plan(const qmle_plan *p) {
   std::ostringstream os;
   os << "{\"n_qubits\":" << p->n << ",\"n_ops\":" << p->ops.size()
@@ -1153,6 +1170,7 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"L\":" << st.L << ",\"lds_round_trips\":" << (st.grp_end - st.grp_begin)
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
+       << ",\"flops_per_state\":" << stage_flops_per_state(p, st)
        << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
        << ",\"product\":" << (st.product_ok ? "true" : "false") << ",\"expval_kernel\":\""
        << (const char *[]){"k_tile", "k_reg_measure", "k_reg_measure_fold", "k_reg_measure_mono"}

@@ -46,5 +46,16 @@ if tag == "mw":
     t[f"meyer_wallach:n{n}"] = {"read": round(rd), "write": round(wr), "hbm_bytes_per_launch": round(rd + wr),
                                 "states_per_launch": 1, "calls_averaged": states, "source": source,
                                 "source_sha16": SHA}
+# fused route (tag "mwfused", `states` = calls profiled by tools/mw_fused_target.py): what is fetched AFTER the circuit
+# = the k_mw_read_later launches of one call (the circuit's own last pass reports the first read's sums)
+if tag == "mwfused":
+    d = pm.get("k_mw_read", {})
+    calls = max(1, states)
+    rd = d.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) * d.get("launches", 0) / calls
+    wr = d.get("hbm_write_bytes_per_launch", 0.0) * d.get("launches", 0) / calls
+    t[f"meyer_wallach_fused:n{n}"] = {"read": round(rd), "write": round(wr), "hbm_bytes_per_launch": round(rd + wr),
+                                      "states_per_launch": 1, "calls_averaged": calls,
+                                      "later_read_launches_per_call": d.get("launches", 0) / calls,
+                                      "source": source, "source_sha16": SHA}
 json.dump(t, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in t.items() if k != "_how"}, indent=1))
