@@ -147,9 +147,10 @@ bool plan_sparse(const qmle_plan *p) {
 static thread_local const AngleMapSrc *tls_angle_map = nullptr;
 
 // per-sample gate matrices for the whole batch: d_mats[b][mat_floats] from d_angles[b][n_slots]
-int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream) {
-  if (p->groups.empty()) return QMLE_OK;
-  const int ng = (int)p->groups.size();
+int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream,
+                          bool forward_only) {
+  const int ng = forward_only ? p->n_groups_needed : (int)p->groups.size();
+  if (ng <= 0) return QMLE_OK;
   if (tls_angle_map && batch >= 64) {
     const uint64_t waves = (uint64_t)ng * (((uint64_t)batch + 63) / 64);
     hipLaunchKernelGGL(k_build_matrices_map, dim3(grid_for(waves * 64, 64)), dim3(64), 0, stream, p->dev.d_build,
@@ -576,7 +577,7 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
   workspace_bytes -= mats_b;
 
   // per-sample gate matrices for the whole batch (tiny)
-  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream);
+  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream, /*forward_only=*/true);
   if (rc != QMLE_OK) return rc;
 
   const size_t D = (size_t)1 << n;
@@ -762,7 +763,7 @@ int qmle_apply_inplace(qmle_plan *plan, const float *d_angles, int batch, void *
   const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
   if (workspace_bytes < mis + ws_mats_bytes(plan, batch)) return QMLE_ERR_WORKSPACE;
   float *d_mats = (float *)(ws + mis);
-  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream);
+  rc = launch_build_matrices(plan, d_angles, d_mats, batch, stream, /*forward_only=*/true);
   if (rc != QMLE_OK) return rc;
   int stage_idx = -1;
   for (const Stage &st : plan->stages) {
@@ -851,6 +852,7 @@ static void adopt_schedule(qmle_plan *dst, qmle_plan *src) {
   dst->stages.swap(src->stages);
   dst->cand_ranking.swap(src->cand_ranking);
   std::swap(dst->mat_floats, src->mat_floats);
+  std::swap(dst->n_groups_needed, src->n_groups_needed);
   std::swap(dst->fold_groups, src->fold_groups);
   std::swap(dst->model_cost, src->model_cost);
   std::swap(dst->chosen_candidate, src->chosen_candidate);

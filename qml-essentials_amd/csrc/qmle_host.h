@@ -61,7 +61,9 @@ int ensure_device_plan(qmle_plan *p);
 bool plan_sparse(const qmle_plan *p);  // known-zero tracking is on for runs of this plan
 size_t ws_mats_bytes(const qmle_plan *p, int batch);
 size_t workspace_bytes_one(const qmle_plan *plan, int batch, int meas_type, int states_in_flight);
-int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream);
+// forward_only: just the matrices the forward tile / direct kernels read (qmle_plan::n_groups_needed)
+int launch_build_matrices(const qmle_plan *p, const float *d_angles, float *d_mats, int batch, hipStream_t stream,
+                          bool forward_only = false);
 int run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int meas_type,
                     const uint32_t *obs_masks, int n_obs, void *d_out, void *d_workspace,
                     size_t workspace_bytes, hipStream_t stream);

@@ -171,7 +171,8 @@ struct qmle_plan {
   std::vector<qmle::Group2> groups2;
   std::vector<uint32_t> tbl2;             // per-thread LDS byte addresses of the Group2 groups
   std::vector<qmle::BuildOp> build_ops;
-  std::vector<qmle::BuildGroup> groups;
+  std::vector<qmle::BuildGroup> groups;   // needed-first: [0, n_groups_needed) are read by the forward tile / direct kernels
+  int n_groups_needed = 0;
   std::vector<qmle::Stage> stages;
   uint32_t mat_floats = 0;                // per-sample matrix row length
   int fold_groups = 0;                    // most gate groups of any Stage::product_ok stage

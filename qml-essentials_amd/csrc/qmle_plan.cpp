@@ -1074,6 +1074,30 @@ int compile_plan(qmle_plan *p) {
     p->chosen_candidate = best;
   }
   p->model_cost = cost();
+  // ---- matrices no forward kernel reads --------------------------------------------------------
+  // An X / CX inside a register-tile group is a swap of amplitudes (reg_dispatch<2>, f_x / f_cx) or a
+  // change of the LDS layout map (build_fast_groups); its 2x2 matrix is never read by a tile pass.  The
+  // per-sample matrix builder spent 46 % of its groups on them in the Fourier-grid model (60 CX of 130
+  // groups, a fifth of a saturated 10-qubit batch with the rest of the builder).  The
+  // build groups are ordered needed-first; the forward engine builds [0, n_groups_needed), the adjoint
+  // sweep and the complex128 engine (which apply a CX through its matrix) all of them.
+  {
+    std::vector<char> unread(p->mat_floats + 1, 0);
+    for (const Stage &st : p->stages) {
+      if (st.kind != ST_TILE || st.T < 4 || (p->flags & QMLE_PLAN_NO_REGTILE)) continue;  // (group_stage_ops: regs_ok)
+      for (int i = st.op_begin; i < st.op_end; ++i) {
+        const LoweredOp &o = p->dev_ops[i];
+        if (o.kind == LK_1Q && o.nc <= 1 && (o.flags & LF_PERMX)) unread[o.mat_off] = 1;
+      }
+    }
+    std::stable_partition(p->groups.begin(), p->groups.end(),
+                          [&](const BuildGroup &g) { return !(g.dim == 2 && unread[g.mat_off]); });
+    p->n_groups_needed = 0;
+    for (const BuildGroup &g : p->groups)
+      if (!(g.dim == 2 && unread[g.mat_off])) ++p->n_groups_needed;
+    static const bool build_all = std::getenv("QMLE_BUILD_ALL_MATRICES") != nullptr;
+    if (build_all) p->n_groups_needed = (int)p->groups.size();
+  }
   return QMLE_OK;
 }
 
