@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define QMLE_SV_VERSION 148 /* 0.1.4.7: qmle_plan_executed (qmle_plan_expval_child = the folded child only); 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
+#define QMLE_SV_VERSION 149 /* 0.1.4.8: qmle_adjoint_gradient_f64, k_direct_1q controlled-phase mode; 0.1.4.7: qmle_plan_executed (qmle_plan_expval_child = the folded child only); 0.1.4.6: qmle_plan_autotune; 0.1.4.5: QMLE_MEAS_MEYER_WALLACH; 0.1.4.4: qmle_philox_uniform_f32_device_key; 0.1.4.3: qmle_philox_uniform_f32_device; 0.1.4.2: qmle_apply_inplace_f64; 0.1.4.1: qmle_philox_uniform_f32 (host-side parameter sampler); 0.1.4: complex128 engine (qmle_run_batch_f64), qmle_meyer_wallach_reads, QMLE_ERR_INTERNAL; 0.1.3: fast tile path (no ABI change; a plan is bound to the device of its first run); 0.1.2: shot sampler; 0.1.1: qmle_op carries 4 wires (MAT4) */
 #define QMLE_MAX_QUBITS 32
 
 typedef struct qmle_plan qmle_plan;
@@ -409,6 +409,18 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
                           int n_grad_slots, void *d_workspace, size_t workspace_bytes,
                           qmle_stream stream);
 size_t qmle_adjoint_workspace_bytes(const qmle_plan *fwd, const qmle_plan *rev, int batch);
+/* The same sweep on the complex128 engine (x64 mode: jax.grad with jax_enable_x64,
+ * /root/reference/tests/test_jaqsi.py:57,131-141,764-786): angles, weights and gradients are float64,
+ * psi and lambda complex128, one streaming launch per operator (no fusion, like qmle_run_batch_f64).
+ * `rev` keeps one source gate per operator (QMLE_PLAN_NO_FUSION or QMLE_PLAN_NO_MERGE); any batch size
+ * (samples are processed in rounds of <= 4 GiB of psi + lambda).  d_grad float64 [batch][n_grad_slots]. */
+int qmle_adjoint_gradient_f64(qmle_plan *fwd, qmle_plan *rev, const double *d_angles_fwd,
+                              const double *d_angles_rev, int batch, const double *d_weights,
+                              const uint32_t *obs_wire_masks, int n_obs,
+                              const qmle_adjoint_term *terms, int n_terms, double *d_grad,
+                              int n_grad_slots, void *d_workspace, size_t workspace_bytes,
+                              qmle_stream stream);
+size_t qmle_adjoint_workspace_bytes_f64(const qmle_plan *fwd, const qmle_plan *rev, int batch);
 
 #ifdef __cplusplus
 }

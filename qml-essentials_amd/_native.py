@@ -187,6 +187,9 @@ SYMBOLS = [
     ("qmle_adjoint_gradient", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
                                    _VP, _I, _VP, _SZ, _VP]),
     ("qmle_adjoint_workspace_bytes", _SZ, [_VP, _VP, _I]),
+    ("qmle_adjoint_gradient_f64", _I, [_VP, _VP, _VP, _VP, _I, _VP, C.POINTER(C.c_uint32), _I, _VP, _I,
+                                       _VP, _I, _VP, _SZ, _VP]),
+    ("qmle_adjoint_workspace_bytes_f64", _SZ, [_VP, _VP, _I]),
     ("qmle_sample_counts", _I, [_VP, _I, _I, _I, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _SZ,
                                 _VP]),
     ("qmle_sample_workspace_bytes", _SZ, [_I, _I]),
@@ -918,10 +921,14 @@ class AdjointTerm(C.Structure):
 @_row_chunked(2, 3, 4, max_rows=32767)  # (psi and lambda of a sample share a launch: 2 B <= 65535)
 def adjoint_gradient(fwd: Plan, rev: Plan, angles_fwd, angles_rev, weights,
                      wire_groups: Sequence[Sequence[int]], terms, n_grad_slots: int):
-    """One backward sweep: d/d(angle) of sum_k weights[b, k] <Z..Z>_k -> float32 [B, n_grad_slots].
+    """One backward sweep: d/d(angle) of sum_k weights[b, k] <Z..Z>_k -> float32 [B, n_grad_slots]
+    (float64 tensors in: the complex128 sweep, ``qmle_adjoint_gradient_f64``, float64 out).
     ``terms``: one ``(out_slot, x_wires, z_wires, proj_wires, n_y, coef, marks_off)`` per op of
     ``rev`` (the reversed, daggered NO_FUSION plan)."""
     torch = require_gpu()
+    f64 = weights.dtype == torch.float64
+    if f64 and (angles_fwd.dtype != torch.float64 or angles_rev.dtype != torch.float64):
+        raise ValueError("the complex128 sweep takes float64 angle tables")
     B, n_obs = int(weights.shape[0]), len(wire_groups)
     if weights.dim() != 2 or weights.shape[1] != n_obs:
         raise ValueError(f"weights must be [B, {n_obs}], got {tuple(weights.shape)}")
@@ -938,6 +945,15 @@ def adjoint_gradient(fwd: Plan, rev: Plan, angles_fwd, angles_rev, weights,
         (arr[i].out_slot, arr[i].x_wires, arr[i].z_wires, arr[i].proj_wires, arr[i].n_y,
          arr[i].coef, arr[i].marks_off) = t
     dev = weights.device
+    if f64:
+        out = torch.empty((B, n_grad_slots), dtype=torch.float64, device=dev)
+        ws = torch.empty(lib().qmle_adjoint_workspace_bytes_f64(fwd._h, rev._h, B), dtype=torch.uint8, device=dev)
+        check(lib().qmle_adjoint_gradient_f64(
+            fwd._h, rev._h, C.c_void_p(angles_fwd.data_ptr()), C.c_void_p(angles_rev.data_ptr()), B,
+            C.c_void_p(weights.data_ptr()), masks, n_obs, arr, len(terms),
+            C.c_void_p(out.data_ptr()), int(n_grad_slots), C.c_void_p(ws.data_ptr()),
+            C.c_size_t(ws.numel()), _stream_ptr()), "qmle_adjoint_gradient_f64")
+        return out
     out = torch.empty((B, n_grad_slots), dtype=torch.float32, device=dev)
     ws = torch.empty(lib().qmle_adjoint_workspace_bytes(fwd._h, rev._h, B), dtype=torch.uint8,
                      device=dev)

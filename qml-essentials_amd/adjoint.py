@@ -32,9 +32,10 @@ class AdjointUnsupported(NotImplementedError):
 
 
 def _dagger_blob(blob: np.ndarray, dim: int) -> np.ndarray:
+    keep = np.float64 if np.asarray(blob).dtype == np.float64 else np.float32  # (x64 mode: full precision)
     m = np.asarray(blob, dtype=np.float64).reshape(dim, dim, 2)
     m = (m[..., 0] + 1j * m[..., 1]).conj().T
-    return np.stack([m.real, m.imag], axis=-1).astype(np.float32).reshape(-1)
+    return np.stack([m.real, m.imag], axis=-1).astype(keep).reshape(-1)
 
 
 def _term(out_slot=-1, x=0, z=0, proj=0, n_y=0, coef=0.0, marks_off=-1):
@@ -44,14 +45,15 @@ def _term(out_slot=-1, x=0, z=0, proj=0, n_y=0, coef=0.0, marks_off=-1):
 _BLOB_LEN = {"MAT1": 8, "MAT2": 32, "MAT4": 512}
 
 
-def _op_blobs(low: LoweredTape) -> List[Optional[np.ndarray]]:
+def _op_blobs(low: LoweredTape, x64: bool = False) -> List[Optional[np.ndarray]]:
     out = []
+    consts = low.consts64 if x64 else low.consts
     for name, _w, _s, off in low.ops:
         if off < 0:
             out.append(None)
         else:
             size = _BLOB_LEN.get(name, 1 << low.n_qubits)  # DIAG_ALL: one mark per amplitude
-            out.append(low.consts[off:off + size])
+            out.append(consts[off:off + size])
     return out
 
 
@@ -90,7 +92,7 @@ def build_reverse(low: LoweredTape, blobs: List[Optional[np.ndarray]], want: Seq
             if d:  # dU = i |11><11| U
                 term = _term(fslot, 0, 0, bit(wires), 0, -2.0)
         elif name == "DIAG_ALL":
-            out_blob = np.asarray(blob, dtype=np.float32)
+            out_blob = np.asarray(blob)
             if d:  # U = exp(-i M x): dU = -i M U
                 term = _term(fslot, coef=2.0, marks_off=0)  # offset patched below
         elif name in _SELF_INVERSE:
@@ -122,7 +124,10 @@ REV_FLAGS_FUSED = (N.PLAN_NO_MERGE | N.PLAN_FORCE_GLOBAL | N.PLAN_NO_ABSORB
 
 def run_sweep(fwd_plan, rev: LoweredTape, a_f, a_r, w, obs_groups, terms, n_grad_slots):
     """The backward sweep with fused tile passes where the engine supports the tape (1-qubit and
-    controlled 1-qubit gates), else with one streaming pass per gate."""
+    controlled 1-qubit gates), else with one streaming pass per gate.  float64 tables: the
+    complex128 sweep (one streaming launch per operator, like the complex128 forward engine)."""
+    if w.dtype == N.require_gpu().float64:
+        return N.adjoint_gradient(fwd_plan, get_plan(rev, REV_FLAGS), a_f, a_r, w, obs_groups, terms, n_grad_slots)
     try:
         return N.adjoint_gradient(fwd_plan, get_plan(rev, REV_FLAGS_FUSED), a_f, a_r, w, obs_groups,
                                   terms, n_grad_slots)
@@ -135,16 +140,17 @@ _REV_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
 def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
-                          weights: np.ndarray, want: Sequence[bool]) -> np.ndarray:
+                          weights: np.ndarray, want: Sequence[bool], x64: bool = False) -> np.ndarray:
     """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
     (columns of slots that are not wanted stay zero).  The reversed tape depends only on the
     STRUCTURE of the forward tape (its angles are the negated forward columns), so it is built
-    once per structure."""
+    once per structure.  ``x64``: float64 angle table, complex128 states, float64 gradients."""
     torch = N.require_gpu()
-    key = (low.key, tuple(bool(x) for x in want))
+    ft, fn = (torch.float64, np.float64) if x64 else (torch.float32, np.float32)
+    key = (low.key, tuple(bool(x) for x in want), bool(x64))
     hit = _REV_CACHE.get(key)
     if hit is None:
-        rev_ops, terms, rev_src = build_reverse(low, _op_blobs(low), want)
+        rev_ops, terms, rev_src = build_reverse(low, _op_blobs(low, x64), want)
         rev = LoweredTape(rev_ops, n_qubits)
         hit = (rev, patch_marks(rev, terms),
                torch.tensor(rev_src if rev_src else [0], dtype=torch.int64, device="cuda"))
@@ -154,11 +160,11 @@ def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_group
     else:
         _REV_CACHE.move_to_end(key)
     rev, fixed, perm = hit
-    a_f = torch.from_numpy(low.angle_table(batch)).cuda()
+    a_f = torch.from_numpy(low.angle_table(batch, dtype=np.float64) if x64 else low.angle_table(batch)).cuda()
     if rev.n_slots:
         a_r = (-a_f.index_select(1, perm)).contiguous()
     else:
-        a_r = torch.zeros((batch, 1), dtype=torch.float32, device=a_f.device)
-    w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()
+        a_r = torch.zeros((batch, 1), dtype=ft, device=a_f.device)
+    w = torch.from_numpy(np.ascontiguousarray(weights, dtype=fn)).cuda()
     return run_sweep(get_plan(low), rev, a_f, a_r, w, obs_groups, fixed,
                      max(1, low.n_slots)).cpu().numpy()[:, : low.n_slots]

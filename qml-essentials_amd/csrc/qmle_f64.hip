@@ -215,6 +215,69 @@ k64_density(const double2 *__restrict__ states, int n, double2 *__restrict__ out
   }
 }
 
+// ---- adjoint differentiation in complex128 (qmle_adjoint_gradient_f64) ------------------------
+// The complex64 sweep of qmle_adjoint.hip restated on the streaming complex128 appliers: forward state,
+// lambda = (sum_k w_k Z..Z_k) psi, then per gate of the reversed, daggered tape the overlap
+// Im <lambda| G |psi> of its generator and the inverse gate on psi and lambda -- one backward sweep for
+// every angle where x64 mode used to contract 2 P shifted circuits (tests/test_jaqsi.py:57,131-141).
+struct F64AdjTerm {
+  uint32_t xmask, zmask, pmask;  // bit positions: flipped / sign / projected onto 1
+  const double *marks;           // != nullptr: G = diag(marks)
+};
+__global__ void __launch_bounds__(256)
+k64_zsum_apply(const double2 *__restrict__ psi, double2 *__restrict__ lam, int n, const double *__restrict__ weights,
+               F64Obs obs, int n_obs) {
+  const int b = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const double *w = weights + (size_t)b * n_obs;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
+    double d = 0.0;
+    for (int o = 0; o < n_obs; ++o) d += (__builtin_popcountll(i & obs.mask[o]) & 1) ? -w[o] : w[o];
+    const double2 v = psi[((size_t)b << n) + i];
+    lam[((size_t)b << n) + i] = make_double2(d * v.x, d * v.y);
+  }
+}
+// partial[b][block] = sum_i conj(lambda_i) (X^x Z^z Pi_p psi)_i   (the phase i^n_y is applied by k64_adj_final)
+__global__ void __launch_bounds__(256)
+k64_adj_overlap(const double2 *__restrict__ psi_all, const double2 *__restrict__ lam_all, int n, F64AdjTerm t,
+                double2 *__restrict__ partial) {
+  __shared__ double red[16];
+  const int b = blockIdx.y;
+  const uint64_t D = (uint64_t)1 << n;
+  const double2 *psi = psi_all + ((size_t)b << n), *lam = lam_all + ((size_t)b << n);
+  double re = 0.0, im = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (uint64_t)gridDim.x * blockDim.x) {
+    if ((i & t.pmask) != t.pmask) continue;
+    const uint64_t j = i ^ t.xmask;
+    const double sg = t.marks ? t.marks[i] : ((__builtin_popcountll(j & t.zmask) & 1) ? -1.0 : 1.0);
+    const double2 l = lam[i], p = psi[j];
+    re += sg * (l.x * p.x + l.y * p.y);
+    im += sg * (l.x * p.y - l.y * p.x);
+  }
+  const double r = block_sum_d(re, red);
+  const double m = block_sum_d(im, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = make_double2(r, m);
+}
+// grad[b][slot] = coef * Im(i^n_y * sum)
+__global__ void __launch_bounds__(256)
+k64_adj_final(const double2 *__restrict__ partial, int n_blocks, int n_y, double coef, double *__restrict__ grad,
+              int n_grad_slots, int slot) {
+  __shared__ double red[16];
+  const int b = blockIdx.x;
+  double re = 0.0, im = 0.0;
+  for (int k = threadIdx.x; k < n_blocks; k += blockDim.x) {
+    const double2 v = partial[(size_t)b * n_blocks + k];
+    re += v.x;
+    im += v.y;
+  }
+  const double r = block_sum_d(re, red);
+  const double i = block_sum_d(im, red);
+  if (threadIdx.x == 0) {
+    const int q = n_y & 3;
+    grad[(size_t)b * n_grad_slots + slot] = coef * (q == 0 ? i : q == 1 ? r : q == 2 ? -i : -r);
+  }
+}
+
 }  // namespace
 
 // ---- complex128 engine: host side ------------------------------------------------------------
@@ -389,6 +452,136 @@ int qmle_run_batch_f64(qmle_plan *plan, const double *d_angles, int batch, int m
     else if (meas_type == QMLE_MEAS_EXPVAL_Z)
       hipLaunchKernelGGL(k64_expval, dim3(bc, n_obs), dim3(256), 0, stream, stc, n, obs, n_obs,
                          (double *)d_out + (size_t)b0 * n_obs);
+    HIPCHK(hipGetLastError());
+  }
+  return QMLE_OK;
+}
+
+// ---- adjoint gradient, complex128 --------------------------------------------------------------
+static int f64_adj_blocks(int n) {
+  const uint64_t D = (uint64_t)1 << n;
+  uint64_t b = (D + 256 * 8 - 1) / (256 * 8);
+  return (int)(b < 1 ? 1 : b > 1024 ? 1024 : b);
+}
+static int f64_adj_in_flight(int n, int batch) {  // psi and lambda of a round of samples: <= 4 GiB
+  size_t s = ((size_t)4 << 30) / ((size_t)32 << n);
+  if (s < 1) s = 1;
+  if (s > (size_t)batch) s = (size_t)batch;
+  if (s > 65535) s = 65535;
+  return (int)s;
+}
+struct F64AdjLayout { size_t fmats, rmats, partial, psi, lam, total; };
+static F64AdjLayout f64_adj_layout(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
+  F64AdjLayout L;
+  const int fl = f64_adj_in_flight(fwd->n, batch);
+  L.fmats = 0;
+  L.rmats = align_up((size_t)batch * (fwd->mat_floats ? fwd->mat_floats : 1) * sizeof(double), 256);
+  L.partial = L.rmats + align_up((size_t)batch * (rev->mat_floats ? rev->mat_floats : 1) * sizeof(double), 256);
+  L.psi = L.partial + align_up((size_t)fl * f64_adj_blocks(fwd->n) * sizeof(double2), 256);
+  L.lam = L.psi + align_up((size_t)fl * ((size_t)16 << fwd->n), 256);
+  L.total = L.lam + align_up((size_t)fl * ((size_t)16 << fwd->n), 256) + 512;
+  return L;
+}
+
+size_t qmle_adjoint_workspace_bytes_f64(const qmle_plan *fwd, const qmle_plan *rev, int batch) {
+  if (!fwd || !rev || batch < 1 || fwd->n != rev->n) return 0;
+  return f64_adj_layout(fwd, rev, batch).total;
+}
+
+int qmle_adjoint_gradient_f64(qmle_plan *fwd, qmle_plan *rev, const double *d_angles_fwd, const double *d_angles_rev,
+                              int batch, const double *d_weights, const uint32_t *obs_wire_masks, int n_obs,
+                              const qmle_adjoint_term *terms, int n_terms, double *d_grad, int n_grad_slots,
+                              void *d_workspace, size_t workspace_bytes, qmle_stream stream_) {
+  if (!fwd || !rev || batch < 1 || !d_weights || !obs_wire_masks || n_obs < 1 || n_obs > QMLE_MAX_QUBITS || !terms ||
+      !d_grad || n_grad_slots < 1 || !d_workspace || fwd->n != rev->n || n_terms != (int)rev->ops.size())
+    return QMLE_ERR_INVALID_ARG;
+  if ((fwd->n_slots > 0 && !d_angles_fwd) || (rev->n_slots > 0 && !d_angles_rev)) return QMLE_ERR_INVALID_ARG;
+  const int n = fwd->n;
+  // one source gate (one generator) per operator of the reverse plan: NO_FUSION or NO_MERGE plans
+  for (const auto &srcs : rev->lowered_src)
+    if (srcs.size() != 1) return QMLE_ERR_INVALID_ARG;
+  F64Obs obs;
+  std::memset(&obs, 0, sizeof(obs));
+  for (int k = 0; k < n_obs; ++k) {
+    const uint32_t in = obs_wire_masks[k];
+    if (in == 0 || (n < 32 && (in >> n))) return QMLE_ERR_WIRE_RANGE;
+    for (int w = 0; w < n; ++w)
+      if (in & (1u << w)) obs.mask[k] |= 1u << (n - 1 - w);
+  }
+  for (int r = 0; r < n_terms; ++r) {
+    if (terms[r].out_slot >= n_grad_slots) return QMLE_ERR_SLOT_RANGE;
+    if (terms[r].out_slot >= 0 && terms[r].marks_off >= 0 &&
+        (size_t)terms[r].marks_off + ((size_t)1 << n) > rev->n_user_consts)
+      return QMLE_ERR_INVALID_ARG;
+  }
+  const F64AdjLayout L = f64_adj_layout(fwd, rev, batch);
+  char *ws = (char *)d_workspace;
+  const size_t mis = (size_t)(256 - ((uintptr_t)ws & 255)) & 255;
+  if (workspace_bytes < mis + L.total) return QMLE_ERR_WORKSPACE;
+  ws += mis;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = ensure_device_plan(fwd);
+  if (rc == QMLE_OK) rc = ensure_device_plan(rev);
+  if (rc == QMLE_OK) rc = ensure_f64(fwd);
+  if (rc == QMLE_OK) rc = ensure_f64(rev);
+  if (rc != QMLE_OK) return rc;
+  auto c64_of = [](const qmle_plan *p) {
+    return (const double *)((char *)p->f64_blob + align_up(p->lowered.size() * sizeof(LoweredOp) + 16, 256));
+  };
+  const double *fc = c64_of(fwd), *rcst = c64_of(rev);
+  double *fmats = (double *)(ws + L.fmats), *rmats = (double *)(ws + L.rmats);
+  auto build = [&](const qmle_plan *p, const double *ang, const double *c64, double *mats) {
+    if (p->groups.empty()) return;
+    const int ng = (int)p->groups.size();
+    if (batch >= 64)
+      hipLaunchKernelGGL(k_build_matrices_f64<true>, dim3(grid_for((uint64_t)ng * (((uint64_t)batch + 63) / 64) * 64, 64)),
+                         dim3(64), 0, stream, p->dev.d_build, p->dev.d_groups, ng, ang, p->n_slots, c64, mats,
+                         p->mat_floats, batch);
+    else
+      hipLaunchKernelGGL(k_build_matrices_f64<false>, dim3(grid_for((uint64_t)batch * ng, 64)), dim3(64), 0, stream,
+                         p->dev.d_build, p->dev.d_groups, ng, ang, p->n_slots, c64, mats, p->mat_floats, batch);
+  };
+  build(fwd, d_angles_fwd, fc, fmats);
+  build(rev, d_angles_rev, rcst, rmats);
+  HIPCHK(hipMemsetAsync(d_grad, 0, (size_t)batch * n_grad_slots * sizeof(double), stream));
+  double2 *psi = (double2 *)(ws + L.psi), *lam = (double2 *)(ws + L.lam);
+  double2 *partial = (double2 *)(ws + L.partial);
+  const size_t D = (size_t)1 << n;
+  const int nb = f64_adj_blocks(n);
+  const int in_flight = f64_adj_in_flight(n, batch);
+  const unsigned gx = grid_for(D / 2 ? D / 2 : 1, 256, 1u << 16);
+  for (int b0 = 0; b0 < batch; b0 += in_flight) {
+    const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
+    const double *af = d_angles_fwd ? d_angles_fwd + (size_t)b0 * fwd->n_slots : nullptr;
+    const double *ar = d_angles_rev ? d_angles_rev + (size_t)b0 * rev->n_slots : nullptr;
+    // forward: psi = U_N .. U_1 |0>
+    hipLaunchKernelGGL(k64_init, dim3(gx, bc), dim3(256), 0, stream, psi, n);
+    for (const LoweredOp &op : fwd->lowered)
+      hipLaunchKernelGGL(k64_op, dim3(gx, bc), dim3(256), 0, stream, psi, n, op, fmats + (size_t)b0 * fwd->mat_floats,
+                         fwd->mat_floats, fc, af, fwd->n_slots);
+    // lambda = (sum_k w_k Z..Z_k) psi
+    hipLaunchKernelGGL(k64_zsum_apply, dim3(gx, bc), dim3(256), 0, stream, (const double2 *)psi, lam, n,
+                       d_weights + (size_t)b0 * n_obs, obs, n_obs);
+    for (size_t r = 0; r < rev->lowered.size(); ++r) {
+      const qmle_adjoint_term &t = terms[rev->lowered_src[r][0]];
+      if (t.out_slot >= 0) {
+        F64AdjTerm a;
+        a.xmask = a.zmask = a.pmask = 0;
+        for (int w = 0; w < n; ++w) {
+          if (t.x_wires & (1u << w)) a.xmask |= 1u << (n - 1 - w);
+          if (t.z_wires & (1u << w)) a.zmask |= 1u << (n - 1 - w);
+          if (t.proj_wires & (1u << w)) a.pmask |= 1u << (n - 1 - w);
+        }
+        a.marks = t.marks_off >= 0 ? rcst + t.marks_off : nullptr;
+        hipLaunchKernelGGL(k64_adj_overlap, dim3(nb, bc), dim3(256), 0, stream, (const double2 *)psi,
+                           (const double2 *)lam, n, a, partial);
+        hipLaunchKernelGGL(k64_adj_final, dim3(bc), dim3(nb >= 256 ? 256 : 64), 0, stream, (const double2 *)partial, nb,
+                           t.n_y, (double)t.coef, d_grad + (size_t)b0 * n_grad_slots, n_grad_slots, t.out_slot);
+      }
+      for (double2 *st : {psi, lam})
+        hipLaunchKernelGGL(k64_op, dim3(gx, bc), dim3(256), 0, stream, st, n, rev->lowered[r],
+                           rmats + (size_t)b0 * rev->mat_floats, rev->mat_floats, rcst, ar, rev->n_slots);
+    }
     HIPCHK(hipGetLastError());
   }
   return QMLE_OK;

@@ -644,20 +644,7 @@ class Model:
                    None, None, None)
         argnum = {"params": 0, "inputs": 1, "enc_params": 4}[wrt]
         kwargs = dict(noise_params=self.noise_params, gate_mode="unitary")
-        if method == "adjoint" and x64_enabled():
-            # the adjoint sweep is a complex64 kernel: in x64 mode the same vector-Jacobian product
-            # comes from the parameter-shift Jacobian of the complex128 engine, contracted here
-            n_out = len(obs)
-            (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
-                                          in_axes=in_axes if B > 1 else None, argnums=(argnum,))
-            if B == 1:
-                jac = jac[None]
-            if cotangent is not None or force_mean:
-                w = (np.full((B, n_out), 1.0 / n_out) if cotangent is None
-                     else np.asarray(cotangent, dtype=np.float64).reshape(B, n_out))
-                jac = np.einsum("bk,bk...->b...", w, jac)[:, None]
-                force_mean = True
-        elif method == "adjoint":
+        if method == "adjoint":  # (x64 mode: Script.vjp runs the complex128 sweep, qmle_adjoint_gradient_f64)
             n_out = len(obs)
             ax = in_axes if B > 1 else None
             if cotangent is not None or force_mean:

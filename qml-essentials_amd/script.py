@@ -394,13 +394,16 @@ class Script:
             obs, args, kwargs, in_axes, argnums)
         if any(isinstance(o, KrausChannel) for o in tape):
             raise adjoint.AdjointUnsupported("adjoint differentiation of noisy circuits")
-        w = np.asarray(cotangent, dtype=np.float32).reshape(B, len(obs))
+        from .utils import x64_enabled
+
+        x64 = x64_enabled()  # complex128 sweep, float64 tables (jax.grad with jax_enable_x64, test_jaqsi.py:57)
+        w = np.asarray(cotangent, dtype=np.float64 if x64 else np.float32).reshape(B, len(obs))
         want = [False] * low.n_slots
         for s_, _rule, _t, _name in slots:
             want[s_] = True
         grads = {k: np.zeros((B,) + tuple(shp)) for k, shp in leaf_shapes.items()}
         if slots:
-            d = adjoint.adjoint_slot_gradient(low, n_qubits, B, masks, w, want)  # [B, n_slots]
+            d = adjoint.adjoint_slot_gradient(low, n_qubits, B, masks, w, want, x64=x64)  # [B, n_slots]
             for s_, _rule, tangent, _name in slots:
                 for lid, flat, coef in tangent:  # gate angles are scalars: one leaf element each
                     g = grads[lid].reshape(B, -1)

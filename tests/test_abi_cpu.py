@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_header_symbols():
     lib = N.lib()
-    assert lib.qmle_sv_version() == 148
+    assert lib.qmle_sv_version() == 149
     header = open(os.path.join(ROOT, "include", "qmle_sv.h")).read()
     declared = set(re.findall(r"\b(qmle_[a-z_0-9]+)\s*\(", header))
     declared -= {"qmle_op", "qmle_plan"}

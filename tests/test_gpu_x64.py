@@ -193,9 +193,10 @@ def test_parameter_shift_gradient_in_x64():
 
 
 def test_adjoint_method_and_model_scope_in_x64():
-    """`method="adjoint"` under x64: the vector-Jacobian product of the complex128 parameter-shift
-    Jacobian (the adjoint sweep itself is complex64) -- equal to the contraction done by hand and
-    to the complex64 adjoint at float32 level; `Model(x64=True).gradient` scopes the mode itself."""
+    """`method="adjoint"` under x64 (round 5: ONE complex128 backward sweep, `qmle_adjoint_gradient_f64`,
+    where rounds 3-4 contracted the parameter-shift Jacobian of 2 P shifted circuits): equal to that
+    Jacobian contracted by hand at 1e-13 and to the complex64 adjoint at float32 level;
+    `Model(x64=True).gradient` scopes the mode itself."""
     from qml_essentials_amd.model import Model
     from qml_essentials_amd.utils import x64_enabled, x64_scope
 
@@ -318,3 +319,120 @@ def test_mixed_observables_and_non_z_gradients_in_x64():
               - np.asarray(sc.execute(type="expval", obs=obs, args=(a, b - h)))) / (2 * h)
     assert np.abs(np.asarray(ga).reshape(-1) - fa).max() < 1e-8
     assert np.abs(np.asarray(gb).reshape(-1) - fb).max() < 1e-8
+
+
+def _central_differences(f, p, eps=1e-4):
+    fd = np.zeros_like(p)
+    for i in np.ndindex(*p.shape):
+        a, b = p.copy(), p.copy()
+        a[i] += eps
+        b[i] -= eps
+        fd[i] = (f(a) - f(b)) / (2 * eps)
+    return fd
+
+
+@pytest.mark.parametrize("circuit", [
+    "No_Ansatz", "Circuit_1", "Circuit_2", "Circuit_3", "Circuit_4", "Circuit_6", "Circuit_9", "Circuit_10",
+    "Circuit_15", "Circuit_16", "Circuit_17", "Circuit_18", "Circuit_19", "No_Entangling", "Strongly_Entangling",
+    "Hardware_Efficient", "Hardware_Efficient_2", "Ghz"])
+def test_complex128_adjoint_sweep_every_ansatz_vs_central_differences(circuit):
+    """`jax.grad` with x64 on (`/root/reference/tests/test_jaqsi.py:57,131-141,764-786`,
+    `tests/test_model.py:1297-1333`): the complex128 adjoint sweep against complex128 central differences
+    of the model itself, every ansatz with parameters at 5 qubits, gradient of a random linear cost of the
+    <Z> outputs with respect to the parameters AND the inputs: 1e-9."""
+    from qml_essentials_amd.ansaetze import Ansaetze
+    from qml_essentials_amd.model import Model
+
+    names = {c.__name__ for c in Ansaetze.get_available()}
+    if circuit not in names:
+        pytest.skip(f"{circuit} is not an ansatz of this front end")
+    m = Model(5, 2, circuit, x64=True)
+    p = np.asarray(m.params, dtype=np.float64).copy()
+    if p.size == 0:
+        pytest.skip("no parameters")
+    rng = np.random.default_rng(11)
+    x = np.array([0.37])
+    n_out = int(np.asarray(m(params=p, inputs=x)).reshape(-1).shape[0])
+    ct = rng.normal(size=(1, n_out))
+    f = lambda q, xx=x: float((np.asarray(m(params=q, inputs=xx)).reshape(-1) * ct[0]).sum())  # noqa: E731
+    g = np.asarray(m.gradient(params=p, inputs=x, method="adjoint", cotangent=ct)).reshape(p.shape)
+    fd = _central_differences(f, p)
+    assert np.abs(g - fd).max() < 1e-9, (circuit, np.abs(g - fd).max())
+    gi = np.asarray(m.gradient(params=p, inputs=x, wrt="inputs", method="adjoint", cotangent=ct)).reshape(-1)
+    fdi = (f(p, x + 1e-4) - f(p, x - 1e-4)) / 2e-4
+    assert abs(float(gi[0]) - fdi) < 1e-9, (circuit, float(gi[0]), fdi)
+
+
+def test_complex128_adjoint_sweep_batches_general_gates_and_streaming_regime():
+    """The sweep on a batch (inputs x parameter sets), on gates beyond the ansatz tables (CPhase, RXX, RZZ, an
+    explicit matrix, Rot) through Script.vjp, and at 15 qubits (states in HBM, not in LDS): against the
+    complex128 parameter-shift Jacobian contracted by hand (1e-12) resp. central differences (1e-9)."""
+    from qml_essentials_amd import operations as op
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.script import Script
+    from qml_essentials_amd.utils import x64_scope
+
+    rng = np.random.default_rng(5)
+    with x64_scope(True):
+        m = Model(4, 2, "Circuit_19", repeat_batch_axis=[False, False, False])  # inputs and parameter sets zipped: B = 3
+        x = np.array([0.1, -0.4, 0.9])
+        P = rng.uniform(0, 6.28, (3, *np.asarray(m.params).shape[1:]))
+        ct = rng.normal(size=(3, 4))
+        J = np.asarray(m.gradient(params=P, inputs=x))
+        a = np.asarray(m.gradient(params=P, inputs=x, method="adjoint", cotangent=ct))
+        assert np.abs(a - np.einsum("bk,bk...->b...", ct, J)).max() < 1e-12
+
+        U = np.linalg.qr(rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)))[0]
+
+        def circuit(t, u, v):
+            op.H(wires=0)
+            op.RX(t, wires=1)
+            op.ControlledPhaseShift(u, wires=[0, 1])
+            op.RXX(v, wires=[1, 2])
+            op.Operation(wires=2, matrix=U)
+            op.RZZ(t * u, wires=[0, 2])
+            op.Rot(t, u, v, wires=1)
+            op.CRY(v, wires=[2, 0])
+
+        sc = Script(circuit, n_qubits=3)
+        obs = [op.PauliZ(wires=0), op.PauliZ(wires=1), op.PauliZ(wires=2)]
+        args = (np.float64(0.4), np.float64(-0.7), np.float64(1.3))
+        w = rng.normal(size=(3,))
+        g = sc.vjp(obs, w, args=args, argnums=(0, 1, 2))
+        f = lambda a_: float((np.asarray(sc.execute(type="expval", obs=obs, args=tuple(np.float64(v) for v in a_))) * w).sum())  # noqa: E731
+        for k in range(3):
+            hi, lo = list(args), list(args)
+            hi[k] += 1e-4
+            lo[k] -= 1e-4
+            assert abs(float(np.asarray(g[k])) - (f(hi) - f(lo)) / 2e-4) < 1e-9, k
+
+        big = Model(15, 1, "Hardware_Efficient")
+        pb = np.asarray(big.params, dtype=np.float64)
+        gb = np.asarray(big.gradient(inputs=np.array([0.2]), method="adjoint", force_mean=True)).reshape(pb.shape)
+        fb = lambda q: float(np.asarray(big(params=q, inputs=np.array([0.2]), force_mean=True)))  # noqa: E731
+        for i in [(0, 0, 0), (0, 1, 7), (0, 0, 44)]:
+            hi, lo = pb.copy(), pb.copy()
+            hi[i] += 1e-4
+            lo[i] -= 1e-4
+            assert abs(gb[i] - (fb(hi) - fb(lo)) / 2e-4) < 1e-9, i
+
+
+def test_model_training_smoke_in_x64():
+    """`Model(x64=True)` in a training loop (`/root/reference/tests/test_model.py:1297-1333`): gradient descent on a
+    mean-squared cost with the complex128 adjoint sweep lowers the cost monotonically over a few steps."""
+    from qml_essentials_amd.model import Model
+
+    m = Model(3, 1, "Circuit_19", x64=True)
+    x = np.linspace(0, 2 * np.pi, 8, endpoint=False)
+    y = 0.5 * np.cos(x)
+    p = np.asarray(m.params, dtype=np.float64).copy()
+    costs = []
+    for _ in range(6):
+        out = np.asarray(m(params=p, inputs=x, force_mean=True)).reshape(-1)
+        costs.append(float(np.mean((out - y) ** 2)))
+        n_out = m.n_qubits if not m.output_qubit or m.output_qubit == -1 else len(np.atleast_1d(m.output_qubit))
+        ct = np.repeat((2.0 * (out - y) / x.size)[:, None], n_out, axis=1) / n_out
+        g = np.asarray(m.gradient(params=p, inputs=x, method="adjoint", cotangent=ct))
+        g = g.reshape(x.size, *p.shape).sum(axis=0) if g.size == x.size * p.size else g.reshape(p.shape)
+        p = p - 0.5 * g
+    assert all(b <= a + 1e-12 for a, b in zip(costs, costs[1:])) and costs[-1] < 0.9 * costs[0], costs
