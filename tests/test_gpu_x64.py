@@ -321,13 +321,19 @@ def test_mixed_observables_and_non_z_gradients_in_x64():
     assert np.abs(np.asarray(gb).reshape(-1) - fb).max() < 1e-8
 
 
-def _central_differences(f, p, eps=1e-4):
+def _d1(g, eps=1e-3):
+    """Fourth-order central difference of the scalar function g at 0: truncation eps^4 / 30 g^(5) ~ 1e-13."""
+    return (8.0 * (g(eps) - g(-eps)) - (g(2 * eps) - g(-2 * eps))) / (12.0 * eps)
+
+
+def _central_differences(f, p):
     fd = np.zeros_like(p)
     for i in np.ndindex(*p.shape):
-        a, b = p.copy(), p.copy()
-        a[i] += eps
-        b[i] -= eps
-        fd[i] = (f(a) - f(b)) / (2 * eps)
+        def g(t, i=i):
+            q = p.copy()
+            q[i] += t
+            return f(q)
+        fd[i] = _d1(g)
     return fd
 
 
@@ -359,7 +365,7 @@ def test_complex128_adjoint_sweep_every_ansatz_vs_central_differences(circuit):
     fd = _central_differences(f, p)
     assert np.abs(g - fd).max() < 1e-9, (circuit, np.abs(g - fd).max())
     gi = np.asarray(m.gradient(params=p, inputs=x, wrt="inputs", method="adjoint", cotangent=ct)).reshape(-1)
-    fdi = (f(p, x + 1e-4) - f(p, x - 1e-4)) / 2e-4
+    fdi = _d1(lambda t: f(p, x + t))
     assert abs(float(gi[0]) - fdi) < 1e-9, (circuit, float(gi[0]), fdi)
 
 
@@ -401,20 +407,22 @@ def test_complex128_adjoint_sweep_batches_general_gates_and_streaming_regime():
         g = sc.vjp(obs, w, args=args, argnums=(0, 1, 2))
         f = lambda a_: float((np.asarray(sc.execute(type="expval", obs=obs, args=tuple(np.float64(v) for v in a_))) * w).sum())  # noqa: E731
         for k in range(3):
-            hi, lo = list(args), list(args)
-            hi[k] += 1e-4
-            lo[k] -= 1e-4
-            assert abs(float(np.asarray(g[k])) - (f(hi) - f(lo)) / 2e-4) < 1e-9, k
+            def gk(t, k=k):
+                a_ = list(args)
+                a_[k] = a_[k] + t
+                return f(a_)
+            assert abs(float(np.asarray(g[k])) - _d1(gk)) < 1e-9, k
 
         big = Model(15, 1, "Hardware_Efficient")
         pb = np.asarray(big.params, dtype=np.float64)
         gb = np.asarray(big.gradient(inputs=np.array([0.2]), method="adjoint", force_mean=True)).reshape(pb.shape)
         fb = lambda q: float(np.asarray(big(params=q, inputs=np.array([0.2]), force_mean=True)))  # noqa: E731
         for i in [(0, 0, 0), (0, 1, 7), (0, 0, 44)]:
-            hi, lo = pb.copy(), pb.copy()
-            hi[i] += 1e-4
-            lo[i] -= 1e-4
-            assert abs(gb[i] - (fb(hi) - fb(lo)) / 2e-4) < 1e-9, i
+            def gi_(t, i=i):
+                q = pb.copy()
+                q[i] += t
+                return fb(q)
+            assert abs(gb[i] - _d1(gi_)) < 1e-9, i
 
 
 def test_model_training_smoke_in_x64():
