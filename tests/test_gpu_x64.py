@@ -380,13 +380,14 @@ def test_complex128_adjoint_sweep_batches_general_gates_and_streaming_regime():
 
     rng = np.random.default_rng(5)
     with x64_scope(True):
-        m = Model(4, 2, "Circuit_19", repeat_batch_axis=[False, False, False])  # inputs and parameter sets zipped: B = 3
+        m = Model(4, 2, "Circuit_19")
         x = np.array([0.1, -0.4, 0.9])
-        P = rng.uniform(0, 6.28, (3, *np.asarray(m.params).shape[1:]))
+        P = rng.uniform(0, 6.28, np.asarray(m.params).shape[1:])
         ct = rng.normal(size=(3, 4))
-        J = np.asarray(m.gradient(params=P, inputs=x))
-        a = np.asarray(m.gradient(params=P, inputs=x, method="adjoint", cotangent=ct))
-        assert np.abs(a - np.einsum("bk,bk...->b...", ct, J)).max() < 1e-12
+        for wrt in ("params", "inputs"):
+            J = np.asarray(m.gradient(params=P, inputs=x, wrt=wrt))
+            a = np.asarray(m.gradient(params=P, inputs=x, wrt=wrt, method="adjoint", cotangent=ct))
+            assert np.abs(a - np.einsum("bk,bk...->b...", ct, J)).max() < 1e-12, wrt
 
         U = np.linalg.qr(rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)))[0]
 
