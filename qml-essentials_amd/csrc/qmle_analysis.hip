@@ -644,6 +644,7 @@ k_parity_final(const float *__restrict__ partial, int n_blocks, int count, int n
 // ---------------------------------------------------------------------------
 constexpr int kMwT = 12, kMwThreads = 256;
 constexpr int kMwRowFirst = 48, kMwRowLater = 16;
+constexpr int kMwRowLaterLow = 24;  // a later read that also reports positions 0..3: [16 + 2 p], [17 + 2 p]
 
 struct MwReadArgs {
   const float2 *states;
@@ -664,8 +665,13 @@ __device__ __forceinline__ void mw_cross16(v2f (&cr)[12], const v2f (&r)[16]) {
   });
 }
 
-template <bool FIRST, bool NT>
+// LOW (later reads behind a fused producing pass, round 5): the read also reports the cross terms of positions
+// 0..3 -- bit 0 out of the halves of its own float4s, bits 1..3 out of one more 16-amplitude gather (local bits
+// 1..4) -- which the producing pass then need not compute: that pass is bound by its vector arithmetic, a later
+// read by HBM with ~55 % of its issue slots free (profiles/r05_mw_sq_resident.txt).
+template <bool FIRST, bool NT, bool LOW = false>
 __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4) {
+  static_assert(!(FIRST && LOW), "the first read reports every low bit anyway");
   const uint32_t sbo = lds_offset_of(smem4);  // 0: no static LDS (launch side checks lds_base_is_zero)
   const uint32_t tid = threadIdx.x;
   const uint32_t jl = 2u * tid;  // local bits 1..8 from tid, 9..11 from u, bit 0 inside the float4
@@ -682,6 +688,7 @@ __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4)
   v2f cr[12];
   static_for<12>([&](auto k) { cr[k] = (v2f){0.f, 0.f}; });
   float zin[4] = {0.f, 0.f, 0.f, 0.f}, tot = 0.f, zw[4] = {0.f, 0.f, 0.f, 0.f};
+  // (LOW: positions 0..3 at cr[8 .. 11] -- the later reads use cr[0 .. 7] only)
 
   for (uint32_t it = 0; it < n_it; ++it) {
     const uint32_t t = tile0 + it;
@@ -709,6 +716,7 @@ __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4)
       tot += tt;
       static_for<4>([&](auto j) { zw[j] += __uint_as_float(__float_as_uint(tt) ^ (((it >> j) & 1u) << 31)); });
     }
+    if (LOW) static_for<8>([&](auto u) { mw_cross(cr[8], lo_[u], hi_[u]); });
     static_for<3>([&](auto k) {
       constexpr int B = FIRST ? 9 + (int)k : 5 + (int)k;
       static_for<4>([&](auto pq) {
@@ -742,7 +750,24 @@ __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4)
         r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
       });
       mw_cross16<gB>(cr, r);
-    } else {  // local bit 8 alone: 8 float4 over local bits {0, 8, 9, 10}; thread index -> 1..7, 11
+    } else {
+      if (LOW) {  // local bits 1..3 (positions 1..3): the gather over local bits 1..4, its first three bits
+        constexpr int gL = 1;
+        const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, gL), gL + 1), gL + 2), gL + 3)) << 3) + sbo;
+        v2f r[16];
+        static_for<16>([&](auto c) {
+          const u64 x = lds_ld64(bs ^ (sw((uint32_t)c << gL) << 3));
+          r[c] = (v2f){__uint_as_float((uint32_t)x), __uint_as_float((uint32_t)(x >> 32))};
+        });
+        static_for<3>([&](auto t) {
+          static_for<8>([&](auto pq) {
+            constexpr int lowm = (1 << t) - 1;
+            constexpr int c = (((int)pq & ~lowm) << 1) | ((int)pq & lowm);
+            mw_cross(cr[9 + (int)t], r[c], r[c | (1 << t)]);
+          });
+        });
+      }
+      // local bit 8 alone: 8 float4 over local bits {0, 8, 9, 10}; thread index -> 1..7, 11
       const uint32_t e0 = ((tg & 127u) << 1) | ((tg >> 7) << 11);
       const uint32_t bs = (sw(e0) << 3) + sbo;
       float4 r[8];
@@ -760,7 +785,7 @@ __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4)
   // first read: [0..23] cross terms of local bit b at 2b, 2b+1; [24..35] signed populations of
   // local bits 0..11; [36] total; [37..40] total signed by bit j of the tile's index in the walk.
   // later reads: [0..15] cross terms of new bit k at 2k, 2k+1.
-  constexpr int NB = FIRST ? 12 : 8, NV = FIRST ? 41 : 16;
+  constexpr int NB = (FIRST || LOW) ? 12 : 8, NV = FIRST ? 41 : LOW ? kMwRowLaterLow : kMwRowLater;
   float red_v[NV];
   static_for<NB>([&](auto k) { red_v[2 * k] = cr[k].x; red_v[2 * k + 1] = cr[k].y; });
   if (FIRST) {
@@ -780,7 +805,7 @@ __device__ __forceinline__ void mw_read_body(const MwReadArgs &a, float4 *smem4)
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kMwThreads / kWave; ++i) s += red[i * NV + tid];
-    a.rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (FIRST ? kMwRowFirst : kMwRowLater) + tid] = s;
+    a.rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (FIRST ? kMwRowFirst : LOW ? kMwRowLaterLow : kMwRowLater) + tid] = s;
   }
 }
 // Two entry points, because the occupancy that suits them differs: the later reads are bound by
@@ -796,6 +821,11 @@ template <bool NT>
 __global__ void __launch_bounds__(kMwThreads) k_mw_read_later(const MwReadArgs a) {
   extern __shared__ float4 smem4[];
   mw_read_body<false, NT>(a, smem4);
+}
+template <bool NT>
+__global__ void __launch_bounds__(kMwThreads) k_mw_read_later_low(const MwReadArgs a) {
+  extern __shared__ float4 smem4[];
+  mw_read_body<false, NT, true>(a, smem4);
 }
 
 // Where the sums of bit position p come from: which later read (0 = the first read) and column.
@@ -869,6 +899,8 @@ struct MwFusedArgs {
   const float *first;       // [batch][rows_first][kMwFusedRowA]
   const float *later[8];    // [batch][rows_later[r]][kMwRowLater]
   uint32_t rows_first, rows_later[8];
+  uint32_t later_stride[8];  // floats per row of later read r (kMwRowLater, or kMwRowLaterLow for the read that reports 0..3)
+  int lean;                  // positions 0..3: cross terms from later read 0 (columns 8 + p), not from the producing pass
   int T, n;
   int lg;                   // a row covers 2^lg consecutive tiles (the producing workgroup's walk): outer index
                             // bits < lg come with their own signed totals at [3T + 1 + i]
@@ -893,18 +925,19 @@ k_mw_purity_fused(const MwFusedArgs a, float *__restrict__ pur_out /* [batch][n]
     const float *row = fr + (size_t)i * kMwFusedRowA;
     const float t = row[3 * T];
     tot += t;
-    if (j >= 0) { cr += row[2 * j]; ci += row[2 * j + 1]; z += row[2 * T + j]; }
+    if (j >= 0) { cr += row[2 * j]; ci += row[2 * j + 1]; z += row[2 * T + j]; }  // (lean: zeros at 2 j for j < 4)
     else if (oi < lg) z += row[3 * T + 1 + oi];  // a bit of the tile's index inside the workgroup's walk
     else z += ((i >> (oi - lg)) & 1u) ? -(double)t : (double)t;
   }
-  if (j < 0) {
+  if (j < 0 || (a.lean && p < 4)) {
     const int r = a.src_read[p], col = a.src_col[p];
-    const float *lr = a.later[r] + (size_t)b * a.rows_later[r] * kMwRowLater;
+    const uint32_t stride = a.later_stride[r];
+    const float *lr = a.later[r] + (size_t)b * a.rows_later[r] * stride;
     const uint32_t perl = (a.rows_later[r] + gridDim.z - 1) / gridDim.z;
     const uint32_t l_lo = blockIdx.z * perl, l_hi = l_lo + perl < a.rows_later[r] ? l_lo + perl : a.rows_later[r];
     for (uint32_t i = l_lo + threadIdx.x; i < l_hi; i += blockDim.x) {
-      cr += lr[(size_t)i * kMwRowLater + 2 * col];
-      ci += lr[(size_t)i * kMwRowLater + 2 * col + 1];
+      cr += lr[(size_t)i * stride + 2 * col];
+      ci += lr[(size_t)i * stride + 2 * col + 1];
     }
   }
   cr = block_sum_d(cr, red);
@@ -1408,11 +1441,22 @@ bool mw_fusable(int n, const Stage &last) {
   return cv.ok && cv.n_later < qmle_meyer_wallach_reads(n);
 }
 
+// Tiled state: positions 0..3 sit in the producing tile AND in the tile of every later read; the later reads are
+// bound by HBM, the producing pass by its arithmetic -- so the first later read reports them (QMLE_MW_NO_LEAN=1: A/B).
+bool mw_lean(int n, const Stage &last) {
+  if (last.kind != ST_TILE || last.T >= n || last.T < 10) return false;
+  if (std::getenv("QMLE_MW_NO_LEAN") != nullptr) return false;  // (read per call)
+  for (int j = 0; j < 4; ++j)
+    if (last.tile_bits[j] != j) return false;
+  const MwCover cv = mw_cover(n, stage_tile_mask(last), 1);
+  return cv.ok && cv.n_later >= 1;
+}
+
 size_t mw_fused_ws_bytes(int n, int batch, const Stage &last) {
   size_t fl = ((size_t)1 << (n - last.T)) * kMwFusedRowA;  // one row per tile
   if (last.T < n) {
     const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
-    for (int r = 0; r < cv.n_later; ++r) fl += (size_t)cv.rows_later[r] * kMwRowLater;
+    for (int r = 0; r < cv.n_later; ++r) fl += (size_t)cv.rows_later[r] * kMwRowLaterLow;  // (either row length fits)
   }
   return ((size_t)batch * fl + (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) +
          (size_t)8192 * 4 * sizeof(double) + 1024;  // + the purity kernel's slices (< 8192 (state, position, slice) sums)
@@ -1442,10 +1486,13 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
     if (FirstUse once{6}; once.first) {
       QMLE_LDS_BASE_CHECK(k_mw_read_later<true>);
       QMLE_LDS_BASE_CHECK(k_mw_read_later<false>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_later_low<true>);
+      QMLE_LDS_BASE_CHECK(k_mw_read_later_low<false>);
       once.done();
     }
     const uint32_t tiles = 1u << (n - kMwT);
     const bool nt = ((uint64_t)batch << (n + 3)) >= (1ull << 30);
+    pa.lean = mw_lean(n, last) ? 1 : 0;
     for (int r = 0; r < cv.n_later; ++r) {
       MwReadArgs a;
       a.states = states;
@@ -1454,14 +1501,21 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
       a.lo = cv.lo[r];
       a.lo2 = cv.lo2[r];
       a.q = cv.q[r];
+      const bool low = pa.lean && r == 0;  // the first later read also reports positions 0..3
       pa.later[r] = ws;
       pa.rows_later[r] = cv.rows_later[r];
-      ws += (size_t)batch * cv.rows_later[r] * kMwRowLater;
+      pa.later_stride[r] = low ? kMwRowLaterLow : kMwRowLater;
+      ws += (size_t)batch * cv.rows_later[r] * pa.later_stride[r];
       const dim3 grid(tiles >> a.q, batch);
-      if (nt) hipLaunchKernelGGL(k_mw_read_later<true>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
+      if (low) {
+        if (nt) hipLaunchKernelGGL(k_mw_read_later_low<true>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
+        else hipLaunchKernelGGL(k_mw_read_later_low<false>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
+      } else if (nt) hipLaunchKernelGGL(k_mw_read_later<true>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
       else hipLaunchKernelGGL(k_mw_read_later<false>, grid, dim3(kMwThreads), (size_t)8 << kMwT, stream, a);
     }
     for (int p = 0; p < n; ++p) { pa.src_read[p] = (int8_t)cv.src_read[p]; pa.src_col[p] = (int8_t)cv.src_col[p]; }
+    if (pa.lean)
+      for (int p = 0; p < 4; ++p) { pa.src_read[p] = 0; pa.src_col[p] = (int8_t)(8 + p); }
   }
   if (last.T == n && pa.rows_first == 1) {
     hipLaunchKernelGGL(k_mw_whole_state_finish, dim3((batch + 63) / 64), dim3(64), 0, stream, pa, batch, d_out);

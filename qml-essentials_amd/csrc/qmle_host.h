@@ -105,6 +105,8 @@ void launch_density(const float2 *states, float2 *d_out, int n, int batch, hipSt
 // Meyer-Wallach behind the pass that produced the state (QMLE_MEAS_MEYER_WALLACH): `last` left one
 // row per tile at the start of `ws` (TM_STORE_MW / TM_MW_ONLY); d_out [batch][n + 1] = (Q, purities by wire)
 bool mw_fusable(int n, const Stage &last);
+// tiled state: the producing pass leaves the cross terms of positions 0..3 to the first later read (TileArgs::mw_lean)
+bool mw_lean(int n, const Stage &last);
 size_t mw_fused_ws_bytes(int n, int batch, const Stage &last);
 int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int row_shift, void *ws,
                  size_t ws_bytes, float *d_out, hipStream_t stream);  // a row covers 2^row_shift tiles

@@ -150,7 +150,7 @@ __global__ void k_tile(const TileArgs a) {
   if (MW) {
     if (a.meas == TM_STORE_MW) tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);  // (its TM_STORE branch)
     tile_mw_row(lds_offset_of(s), T, (uint32_t)tid, reinterpret_cast<float *>(s),
-                reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + tile) * kMwFusedRow);
+                reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + tile) * kMwFusedRow, a.mw_lean != 0);
   } else {
     tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
   }
@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
           for (int u = 0; u < 4; ++u) st4<NT>(reinterpret_cast<float4 *>(st_cur + uoff[h + u] + goff8), w[u]);
         }
       }
-      tile_mw_accumulate(sbo, T, (uint32_t)tid, (uint32_t)i, macc);
+      tile_mw_accumulate(sbo, T, (uint32_t)tid, (uint32_t)i, macc, a.mw_lean != 0);
     } else if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
     } else if (MEASURE) {
@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   }
   if (MW)  // one row per workgroup (= per tile: launch_tile keeps these stages at one tile per workgroup)
     tile_mw_finish(macc, T, (uint32_t)tid, reinterpret_cast<float *>(s),
-                   reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + blockIdx.x) * kMwFusedRow);
+                   reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + blockIdx.x) * kMwFusedRow, a.mw_lean != 0);
   else if (MEASURE && MULTI && !(f.dbg & 2))
     tile_z_finish(reinterpret_cast<float *>(a.out), red, zacc, qsrc, tid, nt, 31 - __builtin_clz((unsigned)tpw),
                   blockIdx.x, gridDim.x, b);
@@ -1565,6 +1565,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   a.nt = !no_nt && st.T < p->n && !(from_zero && st.zero_in) && !init_zero &&
                  ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)
              ? 1 : 0;
+  a.mw_lean = meas == TM_STORE_MW && mw_lean(p->n, st) ? 1 : 0;  // (run_mw_fused asks the same question)
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   if (FirstUse once{0}; once.first) {
     QMLE_LDS_BASE_CHECK(k_tile<false>);

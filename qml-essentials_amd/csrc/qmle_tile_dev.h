@@ -182,6 +182,8 @@ struct TileArgs {
   uint32_t zin_local, zin_outer, tile_free;
   int compact;
   int nt;  // the launch streams >= 1 GiB of states: non-temporal tile loads / stores
+  int mw_lean;  // TM_STORE_MW of a tiled state: no cross terms for local bits 0..3 (= positions 0..3, which every
+                // later read holds too: k_mw_read_later<.., LOW> reports them), populations out of the second gather
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
@@ -611,13 +613,20 @@ __device__ __forceinline__ void tile_mw_clear(MwAcc &m) {
 }
 
 // one tile (in LDS, identity layout) into the work item's sums; `it` = index of the tile in the walk
-template <int T>
+// LEAN (tiled states, round 5): the gather over local bits 0..3 is dropped -- those are positions 0..3, which sit
+// in the tile of every later read as well, and the later reads are HBM-bound with half of their vector issue
+// slots free (profiles/r05_mw_sq_*.txt) while this pass is bound by its arithmetic: 16 LDS reads, 64 packed fmas
+// and 8 of the 39 reduced values less per work item and tile.  The populations then come out of the second
+// gather (register bits = local bits 4..7, thread bits = local bits 0..3 and 8..).
+template <int T, bool LEAN>
 __device__ __forceinline__ void tile_mw_accumulate_t(uint32_t sbo, uint32_t tid, uint32_t it, MwAcc &m) {
   static_assert(T >= 10 && T <= 14, "16 amplitudes per work item, at most 1024 work items");
   constexpr int G = (T + 3) / 4;
+  constexpr int KPOP = LEAN ? 1 : 0;  // the gather the populations are taken from
   uint32_t tg = tid;
   asm volatile("" : "+v"(tg));  // (the gather addresses are not worth keeping across the gate loop)
   static_for<G>([&](auto k) {
+    if constexpr (LEAN && (int)k == 0) return;
     constexpr int B = (4 * (int)k <= T - 4) ? 4 * (int)k : T - 4;
     constexpr int first_new = 4 * (int)k - B;  // bits [B, B + first_new) were reported by the previous gather
     const uint32_t bs = (sw(ins0(ins0(ins0(ins0(tg, B), B + 1), B + 2), B + 3)) << 3) + sbo;
@@ -635,7 +644,7 @@ __device__ __forceinline__ void tile_mw_accumulate_t(uint32_t sbo, uint32_t tid,
         });
       }
     });
-    if constexpr ((int)k == 0) {  // populations: pruned Walsh-Hadamard butterfly over the four register bits
+    if constexpr ((int)k == KPOP) {  // populations: pruned Walsh-Hadamard butterfly over the four register bits
       float pr[16], s1[8], s2[4], s3[2], h0 = 0.f, h1 = 0.f, h2 = 0.f;
       static_for<16>([&](auto c) { const v2f q = r[c] * r[c]; pr[c] = q.x + q.y; });
       static_for<8>([&](auto i) { s1[i] = pr[2 * i] + pr[2 * i + 1]; h0 += pr[2 * i] - pr[2 * i + 1]; });
@@ -652,63 +661,93 @@ __device__ __forceinline__ void tile_mw_accumulate_t(uint32_t sbo, uint32_t tid,
 // local bits, [3T] total, [3T + 1 + k] total signed by walk bit k.  `red`: LDS scratch (may be the tile:
 // the first barrier below makes sure every gather has read it).  (One row per WAVE straight from lane 63
 // -- no barrier, no scratch -- was measured too: the pass no faster, 8 x the rows for the purity kernel.)
-template <int T>
+template <int T, bool LEAN>
 __device__ __forceinline__ void tile_mw_finish_t(const MwAcc &m, uint32_t tid, float *red, float *row_out) {
-  constexpr int NV = 2 * T + 15, NW = 1 << (T - 10);
+  // per-lane values: cross terms of the reported local bits [C0, T), then h0..h3 (populations of the four register
+  // bits of the population gather = local bits [H0, H0 + 4)), the total, the total signed by thread bits 0..5, and
+  // the walk-signed totals
+  constexpr int C0 = LEAN ? 4 : 0, H0 = LEAN ? 4 : 0, NC = 2 * (T - C0);
+  constexpr int NV = NC + 15, NW = 1 << (T - 10);
   float v[NV];
-  static_for<T>([&](auto j) { v[2 * j] = m.cr[j].x; v[2 * j + 1] = m.cr[j].y; });
-  v[2 * T] = m.h0; v[2 * T + 1] = m.h1; v[2 * T + 2] = m.h2; v[2 * T + 3] = m.h3; v[2 * T + 4] = m.tot;
-  static_for<6>([&](auto b) { v[2 * T + 5 + b] = ((tid >> b) & 1u) ? -m.tot : m.tot; });
-  static_for<4>([&](auto k) { v[2 * T + 11 + k] = m.zw[k]; });
+  static_for<T - C0>([&](auto j) { v[2 * j] = m.cr[C0 + j].x; v[2 * j + 1] = m.cr[C0 + j].y; });
+  v[NC] = m.h0; v[NC + 1] = m.h1; v[NC + 2] = m.h2; v[NC + 3] = m.h3; v[NC + 4] = m.tot;
+  static_for<6>([&](auto b) { v[NC + 5 + b] = ((tid >> b) & 1u) ? -m.tot : m.tot; });
+  static_for<4>([&](auto k) { v[NC + 11 + k] = m.zw[k]; });
   wave_sums_dpp63(v);
   __syncthreads();  // every gather (and the store before it) has read the tile: it becomes scratch
   const uint32_t lane = tid & (kWave - 1), w = tid / kWave;
   if (lane == kWave - 1) static_for<NV>([&](auto i) { red[w * NV + i] = v[i]; });
   __syncthreads();
   if (tid < 3u * T + 5u) {
-    // column of the per-wave sums this row entry reads, or (local bits >= 10) the totals signed by a wave-index bit
+    // column of the per-wave sums this row entry reads (-1: not reported, 0), or the totals signed by a wave-index bit
     int col, wbit = -1;
-    if (tid < 2u * T + 4u) col = (int)tid;                 // cross terms, populations of bits 0..3
+    if (tid < 2u * T) col = (int)tid >= 2 * C0 ? (int)tid - 2 * C0 : -1;  // cross terms
     else if (tid < 3u * T) {
-      const int j = (int)tid - 2 * T;                      // local bit j >= 4 = thread-index bit j - 4
-      if (j - 4 < 6) col = 2 * T + 5 + (j - 4);
-      else { col = 2 * T + 4; wbit = j - 10; }
-    } else if (tid == 3u * T) col = 2 * T + 4;             // the total
-    else col = 2 * T + 11 + ((int)tid - 3 * T - 1);        // walk-bit signed totals
+      const int j = (int)tid - 2 * T;                      // population of local bit j
+      if (j >= H0 && j < H0 + 4) col = NC + (j - H0);      // a register bit of the population gather
+      else {
+        const int tb = j < H0 ? j : j - 4;                 // else bit tb of the thread index
+        if (tb < 6) col = NC + 5 + tb;
+        else { col = NC + 4; wbit = tb - 6; }
+      }
+    } else if (tid == 3u * T) col = NC + 4;                // the total
+    else col = NC + 11 + ((int)tid - 3 * T - 1);           // walk-bit signed totals
     float s = 0.f;
+    if (col >= 0) {
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const float x = red[i * NV + col];
-      s += (wbit >= 0 && ((i >> wbit) & 1)) ? -x : x;
+      for (int i = 0; i < NW; ++i) {
+        const float x = red[i * NV + col];
+        s += (wbit >= 0 && ((i >> wbit) & 1)) ? -x : x;
+      }
     }
     row_out[tid] = s;
   }
 }
-// (T is wave-uniform: a kernel argument)
-__device__ __forceinline__ void tile_mw_accumulate(uint32_t sbo, int T, uint32_t tid, uint32_t it, MwAcc &m) {
+// (T and lean are wave-uniform: kernel arguments)
+__device__ __forceinline__ void tile_mw_accumulate(uint32_t sbo, int T, uint32_t tid, uint32_t it, MwAcc &m, bool lean = false) {
+  if (lean) {
+    switch (T) {
+      case 10: tile_mw_accumulate_t<10, true>(sbo, tid, it, m); break;
+      case 11: tile_mw_accumulate_t<11, true>(sbo, tid, it, m); break;
+      case 12: tile_mw_accumulate_t<12, true>(sbo, tid, it, m); break;
+      case 13: tile_mw_accumulate_t<13, true>(sbo, tid, it, m); break;
+      default: tile_mw_accumulate_t<14, true>(sbo, tid, it, m); break;
+    }
+    return;
+  }
   switch (T) {
-    case 10: tile_mw_accumulate_t<10>(sbo, tid, it, m); break;
-    case 11: tile_mw_accumulate_t<11>(sbo, tid, it, m); break;
-    case 12: tile_mw_accumulate_t<12>(sbo, tid, it, m); break;
-    case 13: tile_mw_accumulate_t<13>(sbo, tid, it, m); break;
-    default: tile_mw_accumulate_t<14>(sbo, tid, it, m); break;
+    case 10: tile_mw_accumulate_t<10, false>(sbo, tid, it, m); break;
+    case 11: tile_mw_accumulate_t<11, false>(sbo, tid, it, m); break;
+    case 12: tile_mw_accumulate_t<12, false>(sbo, tid, it, m); break;
+    case 13: tile_mw_accumulate_t<13, false>(sbo, tid, it, m); break;
+    default: tile_mw_accumulate_t<14, false>(sbo, tid, it, m); break;
   }
 }
-__device__ __forceinline__ void tile_mw_finish(const MwAcc &m, int T, uint32_t tid, float *red, float *row_out) {
+__device__ __forceinline__ void tile_mw_finish(const MwAcc &m, int T, uint32_t tid, float *red, float *row_out, bool lean = false) {
+  if (lean) {
+    switch (T) {
+      case 10: tile_mw_finish_t<10, true>(m, tid, red, row_out); break;
+      case 11: tile_mw_finish_t<11, true>(m, tid, red, row_out); break;
+      case 12: tile_mw_finish_t<12, true>(m, tid, red, row_out); break;
+      case 13: tile_mw_finish_t<13, true>(m, tid, red, row_out); break;
+      default: tile_mw_finish_t<14, true>(m, tid, red, row_out); break;
+    }
+    return;
+  }
   switch (T) {
-    case 10: tile_mw_finish_t<10>(m, tid, red, row_out); break;
-    case 11: tile_mw_finish_t<11>(m, tid, red, row_out); break;
-    case 12: tile_mw_finish_t<12>(m, tid, red, row_out); break;
-    case 13: tile_mw_finish_t<13>(m, tid, red, row_out); break;
-    default: tile_mw_finish_t<14>(m, tid, red, row_out); break;
+    case 10: tile_mw_finish_t<10, false>(m, tid, red, row_out); break;
+    case 11: tile_mw_finish_t<11, false>(m, tid, red, row_out); break;
+    case 12: tile_mw_finish_t<12, false>(m, tid, red, row_out); break;
+    case 13: tile_mw_finish_t<13, false>(m, tid, red, row_out); break;
+    default: tile_mw_finish_t<14, false>(m, tid, red, row_out); break;
   }
 }
 // one tile, one row
-__device__ __forceinline__ void tile_mw_row(uint32_t sbo, int T, uint32_t tid, float *red, float *row_out) {
+__device__ __forceinline__ void tile_mw_row(uint32_t sbo, int T, uint32_t tid, float *red, float *row_out, bool lean = false) {
   MwAcc m;
   tile_mw_clear(m);
-  tile_mw_accumulate(sbo, T, tid, 0u, m);
-  tile_mw_finish(m, T, tid, red, row_out);
+  tile_mw_accumulate(sbo, T, tid, 0u, m, lean);
+  tile_mw_finish(m, T, tid, red, row_out, lean);
 }
 
 // Host side: the kernel arguments of stage `st` (positions, known-zero masks, <Z> row sources).

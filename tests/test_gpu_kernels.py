@@ -400,6 +400,12 @@ def test_meyer_wallach_out_of_the_producing_pass(n, monkeypatch):
                 dflt = plan.run(ang, "mw").cpu().numpy()
                 monkeypatch.setenv("QMLE_MW_FUSE_TILED", "1")
                 assert np.abs(dflt - got).max() < 1e-6, (name, flags)
+                # round 5: by default the producing pass leaves positions 0..3 to the first later read
+                # (TileArgs::mw_lean, k_mw_read_later_low); QMLE_MW_NO_LEAN=1 is the round-4 split
+                monkeypatch.setenv("QMLE_MW_NO_LEAN", "1")
+                full = plan.run(ang, "mw").cpu().numpy()
+                monkeypatch.delenv("QMLE_MW_NO_LEAN")
+                assert np.abs(full - got).max() < 1e-6, (name, flags)
 
 
 @pytest.mark.parametrize("n,layers,flags", [(16, 2, 0), (18, 2, 128 | 32), (20, 1, 128 | 32)])
