@@ -1379,6 +1379,7 @@ struct MwCover {
   int src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];
   bool ok = true;
 };
+constexpr int kMwCoverPairing = 0;
 static MwCover mw_cover(int n, uint32_t tile_mask, int batch) {
   MwCover cv;
   for (int p = 0; p < n; ++p) cv.src_read[p] = cv.src_col[p] = -1;
@@ -1398,6 +1399,14 @@ static MwCover mw_cover(int n, uint32_t tile_mask, int batch) {
     while (q < want && (((uint64_t)batch * tiles) >> (q + 1)) >= 2048) ++q;
     return q;
   };
+  // (four runs: which two share a read decides how the read streams -- tools/mw_lean_ab.py with QMLE_MW_PAIRING=0/1/2:
+  // 0 = outermost with innermost (the stand-alone reads' rule), 1 = neighbours, 2 = alternate)
+  if (nc == 4) {
+    const char *e = std::getenv("QMLE_MW_PAIRING");
+    const int mode = e ? atoi(e) : kMwCoverPairing;
+    if (mode == 1) std::swap(chunks[1], chunks[3]);        // (0,1) (2,3): loop pairs (c0,c3') = (0,1), (c1',c2) = (3,2)
+    else if (mode == 2) std::swap(chunks[2], chunks[3]);   // (0,2) (1,3)
+  }
   int i = 0, j = nc - 1;
   while (i <= j) {
     int a = chunks[i], b = i < j ? chunks[j] : -1;

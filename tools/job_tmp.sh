@@ -1,11 +1,13 @@
-set -x
 R=$GRAFT_REPO_ROOT
-export WS_SHAPES=10:6:65536,12:3:32768,10:6:4096,12:3:2048
-python tools/whole_state_bench.py 2>/dev/null | grep "^n=" > gpurun_out/r05_ws_skip_after.txt
-QMLE_BUILD_ALL_MATRICES=1 python tools/whole_state_bench.py 2>/dev/null | grep "^n=" > gpurun_out/r05_ws_skip_before.txt
-cat gpurun_out/r05_ws_skip_before.txt gpurun_out/r05_ws_skip_after.txt
-export PMC_N=24 PMC_B=32 PMC_FLAGS=160
-bash tools/sq_counters.sh k2_headline "k_tile" -- python3 $R/tools/pmc_target.py > /dev/null 2>&1
-grep -v "raw:" gpurun_out/sq_k2_headline.txt
-cd $R
-python -m pytest tests -m gpu -x -q > gpurun_out/r05_gputests_2.log 2>&1; tail -3 gpurun_out/r05_gputests_2.log
+cd /tmp && export TMPDIR=/tmp
+export QMLE_MW_FUSE_TILED=1 MW_REPS=40
+for m in 0 1 2; do
+export QMLE_MW_PAIRING=$m
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/mwpair_$m -o p -- python3 $R/tools/mw_fused_target.py > $R/gpurun_out/mwpair_$m.log 2>&1
+echo "pairing $m"; python3 - $(find $R/gpurun_out/mwpair_$m -name "*kernel_stats.csv" | head -n 1) <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n=r['Name'].replace('(anonymous namespace)::','')[:50]
+    if 'k_mw_read' in n or 'true>(TileArgs' in n or 'k_tile2<false, true' in n: print(f"   {n:50s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us  min {float(r['MinNs'])/1e3:8.1f}")
+PY
+done
