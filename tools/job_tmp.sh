@@ -1,7 +1,8 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 export QMLE_MW_FUSE_TILED=1 MW_REPS=40
-for m in 0 1 2; do
+export QMLE_MW_LOW_LAST=1
+for m in 0 1; do
 export QMLE_MW_PAIRING=$m
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/mwpair_$m -o p -- python3 $R/tools/mw_fused_target.py > $R/gpurun_out/mwpair_$m.log 2>&1
 echo "pairing $m"; python3 - $(find $R/gpurun_out/mwpair_$m -name "*kernel_stats.csv" | head -n 1) <<'PY'
