@@ -1566,6 +1566,13 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
                  ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)
              ? 1 : 0;
   a.mw_lean = meas == TM_STORE_MW && mw_lean(p->n, st) ? 1 : 0;  // (run_mw_fused asks the same question)
+  // the state this pass stores is read back by the later reads only after >= 1 GiB more has been written: streaming
+  // stores keep it from lingering dirty in the Infinity Cache, where its write-back would run into the first
+  // later read (measured n = 28: that read 0.41 ms behind plain stores, 0.31 ms stand-alone) -- QMLE_MW_NT=0: A/B
+  if (meas == TM_STORE_MW && st.T < p->n && !no_nt && ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)) {
+    const char *e = std::getenv("QMLE_MW_NT");
+    if (!e || atoi(e) != 0) a.nt = 1;
+  }
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);
   if (FirstUse once{0}; once.first) {
     QMLE_LDS_BASE_CHECK(k_tile<false>);
