@@ -883,10 +883,11 @@ def mw_28q_leg(n=28, reps=100, warmup=25):
     ws_s = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
     ws_m = torch.empty(plan.workspace_bytes(1, "mw"), dtype=torch.uint8, device="cuda")
     circ_ms, _ = timed(lambda: plan.run(ang, "state", out=st, workspace=ws_s))
-    dflt_ms, qd = timed(lambda: plan.run(ang, "mw", workspace=ws_m))  # tiled state: the stand-alone reads behind the circuit
-    os.environ["QMLE_MW_FUSE_TILED"] = "1"  # (read per call) the last pass reports its tile's sums, two reads remain
+    # the default route since round 5: the last pass reports its tile's sums (lean epilogue, streaming stores), two reads remain
+    both_ms, qf = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
+    os.environ["QMLE_MW_FUSE_TILED"] = "0"  # (read per call) the three stand-alone reads behind the circuit
     try:
-        both_ms, qf = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
+        dflt_ms, qd = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
     finally:
         del os.environ["QMLE_MW_FUSE_TILED"]
     fused_ms = both_ms - circ_ms
@@ -901,20 +902,30 @@ def mw_28q_leg(n=28, reps=100, warmup=25):
     return {"ms": round(ms, 4), "Q": float(q[0]), "n_qubits": n, "state_bytes": int(D8),
             "reads_of_the_state_per_call": reads, "calls_timed": reps, "calls_warmup": warmup,
             "fused_ms": round(fused_ms, 4), "circuit_ms": round(circ_ms, 4), "circuit_plus_mw_ms": round(both_ms, 4),
-            "after_circuit_ms_default_route": round(dflt_ms - circ_ms, 4), "Q_default_route": float(qd[0, 0]),
-            "fused_adopted_for_tiled_states": False,
-            "fused_note": "QMLE_MEAS_MEYER_WALLACH fuses by default only when the producing pass holds the whole state "
-                          "(n <= 14: no statevector is stored at all); for tiled states the epilogue's arithmetic costs "
-                          "the last pass what the saved read costs (fused_ms vs ms), so the default route is the three "
-                          "stand-alone reads; fused_ms = the fused tiled path, measured behind QMLE_MW_FUSE_TILED=1",
+            "after_circuit_ms_stand_alone_reads": round(dflt_ms - circ_ms, 4), "Q_stand_alone_reads": float(qd[0, 0]),
+            "fused_adopted_for_tiled_states": True,
+            "fused_note": "QMLE_MEAS_MEYER_WALLACH (what Entanglement.meyer_wallach runs): the circuit's last pass reports the "
+                          "sums of its own tile from LDS -- for tiled states the cross terms of its 8 positions above 3 and "
+                          "the populations; positions 0..3 come from the first of the two later reads, which is HBM-bound "
+                          "with issue slots to spare -- and stores the state with streaming stores, so the later reads do "
+                          "not run into its write-back.  fused_ms = (circuit + Meyer-Wallach) - (circuit alone); "
+                          "after_circuit_ms_stand_alone_reads = the same with QMLE_MW_FUSE_TILED=0 (three reads of the stored state); "
+                          "ms = qmle_meyer_wallach on a state that already lies in HBM (three reads)",
             "fused_reads_after_the_circuit": reads - 1, "Q_fused": float(qf[0, 0]),
-            "fused_roofline": {"bound": "hbm", "kernel": "tile_mw_row in the circuit's last pass + 2 x k_mw_read_later",
+            "fused_roofline": {"bound": "hbm+valu", "kernel": "tile_mw_row in the circuit's last pass + k_mw_read_later_low + k_mw_read_later",
+                               "byte_floor_ms": round((reads - 1) * D8 / (HBM_PEAK_GBPS * 1e6), 4),
+                               "valu_issue_floor_ms_of_the_epilogue": round((1 << n) / 16 / 64 / 1024 * (2 * 64 + 31 * 6 + 60) * 4 / 2.1e6, 4),
                                "achieved": round(D8 / fused_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(D8 / fused_ms / 1e6 / HBM_PEAK_GBPS, 4),
                                "moved_frac": round((reads - 1) * D8 / fused_ms / 1e6 / HBM_PEAK_GBPS, 4),
                                "traffic": f_traffic, "traffic_source": f_source, "traffic_error": f_terr,
                                "note": "time after the circuit = (circuit + Meyer-Wallach) - (circuit alone), same plan, "
-                                       "HIP events over back-to-back calls; traffic = PMC bytes fetched by the two later reads"},
+                                       "HIP events over back-to-back calls; traffic = PMC bytes fetched by the two later reads.  "
+                                       "byte_floor = the two later reads at 8 TB/s; the epilogue's issue floor = its vector "
+                                       "instructions per work item and tile (128 packed fmas of cross terms, 31 values x 6 "
+                                       "DPP adds of the wave reduction, ~60 for populations / addresses) x 4 cycles on 1024 SIMDs "
+                                       "at 2.1 GHz: the producing pass issues vector instructions 76 % of its cycles "
+                                       "(profiles/r05_mw_sq_fused.txt), so the epilogue is paid in full"},
             "roofline": {"bound": "hbm", "kernel": "k_mw_read_first + 2 x k_mw_read_later", "achieved": round(D8 / ms / 1e6, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
                          "moved_GBps": round(reads * D8 / ms / 1e6, 1),
@@ -1331,7 +1342,8 @@ def summary_of(r):
     mw = r.get("mw_28q")
     if isinstance(mw, dict):
         out["mw_28q"] = {"ms": mw.get("ms"), "frac": g(mw, "roofline", "frac"), "moved_frac": g(mw, "roofline", "moved_frac"),
-                         "traffic": g(mw, "roofline", "traffic"), "fused_ms": mw.get("fused_ms"),
+                         "traffic": g(mw, "roofline", "traffic"), "fused_ms": mw.get("fused_ms"), "fused_frac": g(mw, "fused_roofline", "frac"),
+                         "fused_traffic": g(mw, "fused_roofline", "traffic"), "stand_alone_after_circuit_ms": mw.get("after_circuit_ms_stand_alone_reads"),
                          "bound": g(mw, "roofline", "bound"), "error": mw.get("error")}
     out["adjoint_gradient_20q_ms"] = g(r, "adjoint_gradient_20q", "ms")
     out["cpu_baseline_gate_applies_per_s"] = g(r, "cpu_baseline", "value")

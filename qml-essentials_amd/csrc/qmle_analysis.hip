@@ -1510,9 +1510,7 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
       a.lo = cv.lo[r];
       a.lo2 = cv.lo2[r];
       a.q = cv.q[r];
-      static const bool low_last_env = std::getenv("QMLE_MW_LOW_LAST") != nullptr;  // (A/B)
-      const int low_r = low_last_env ? cv.n_later - 1 : 0;
-      const bool low = pa.lean && r == low_r;  // one later read also reports positions 0..3
+      const bool low = pa.lean && r == 0;  // the first later read also reports positions 0..3
       pa.later[r] = ws;
       pa.rows_later[r] = cv.rows_later[r];
       pa.later_stride[r] = low ? kMwRowLaterLow : kMwRowLater;
@@ -1526,10 +1524,7 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
     }
     for (int p = 0; p < n; ++p) { pa.src_read[p] = (int8_t)cv.src_read[p]; pa.src_col[p] = (int8_t)cv.src_col[p]; }
     if (pa.lean)
-      for (int p = 0; p < 4; ++p) {
-        pa.src_read[p] = (int8_t)(std::getenv("QMLE_MW_LOW_LAST") ? cv.n_later - 1 : 0);
-        pa.src_col[p] = (int8_t)(8 + p);
-      }
+      for (int p = 0; p < 4; ++p) { pa.src_read[p] = 0; pa.src_col[p] = (int8_t)(8 + p); }
   }
   if (last.T == n && pa.rows_first == 1) {
     hipLaunchKernelGGL(k_mw_whole_state_finish, dim3((batch + 63) / 64), dim3(64), 0, stream, pa, batch, d_out);

@@ -1569,8 +1569,12 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   // the state this pass stores is read back by the later reads only after >= 1 GiB more has been written: streaming
   // stores keep it from lingering dirty in the Infinity Cache, where its write-back would run into the first
   // later read (measured n = 28: that read 0.41 ms behind plain stores, 0.31 ms stand-alone) -- QMLE_MW_NT=0: A/B
-  if (meas == TM_STORE_MW && st.T < p->n && !no_nt && ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)) {
-    const char *e = std::getenv("QMLE_MW_NT");
+  // The same holds for the LAST storing pass of any run whose states exceed the caches (TM_STORE, no tile stage
+  // behind it): whatever reads them next -- the stand-alone Meyer-Wallach reads, a <Z> sweep, the caller -- finds
+  // HBM idle instead of a write-back in progress.  QMLE_LAST_PASS_NT=0: A/B (read per launch).
+  if ((meas == TM_STORE_MW || (meas == TM_STORE && !st.next_tile && !init_zero)) && st.T < p->n && !no_nt &&
+      ((uint64_t)batch << (p->n + 3)) >= (1ull << 30)) {
+    const char *e = std::getenv("QMLE_LAST_PASS_NT");
     if (!e || atoi(e) != 0) a.nt = 1;
   }
   const size_t lds = tile_lds_bytes(st.T, st.L, a.slots_in_lds ? a.n_ops : 0);

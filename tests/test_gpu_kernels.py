@@ -363,9 +363,9 @@ def test_meyer_wallach_out_of_the_producing_pass(n, monkeypatch):
     from tests.helpers import random_tape, tape_to_native
     from tests.test_abi_cpu import he_layer_ops
 
-    # (tiled states take the stand-alone reads by default -- the fused epilogue costs a tiled pass what
-    # the saved read costs; the fused tiled path stays in the library behind this switch)
-    monkeypatch.setenv("QMLE_MW_FUSE_TILED", "1")
+    # (round 5: tiled states fuse by default too -- lean epilogue + streaming stores of the producing pass;
+    # QMLE_MW_FUSE_TILED=0 selects the stand-alone reads of the stored state)
+    monkeypatch.delenv("QMLE_MW_FUSE_TILED", raising=False)
     rng = np.random.default_rng(100 + n)
     B = 3 if n <= 16 else 1
     cases = []
@@ -395,10 +395,10 @@ def test_meyer_wallach_out_of_the_producing_pass(n, monkeypatch):
             want_q = 2 * (1 - want_p.mean(axis=1))
             assert np.abs(got[:, 1:] - want_p).max() < 1e-6, (name, flags, np.abs(got[:, 1:] - want_p).max())
             assert np.abs(got[:, 0] - want_q).max() < 1e-6, (name, flags)
-            if n > 14:  # the default route (stand-alone reads of the stored state): the same numbers
-                monkeypatch.delenv("QMLE_MW_FUSE_TILED")
+            if n > 14:  # the stand-alone reads of the stored state: the same numbers
+                monkeypatch.setenv("QMLE_MW_FUSE_TILED", "0")
                 dflt = plan.run(ang, "mw").cpu().numpy()
-                monkeypatch.setenv("QMLE_MW_FUSE_TILED", "1")
+                monkeypatch.delenv("QMLE_MW_FUSE_TILED")
                 assert np.abs(dflt - got).max() < 1e-6, (name, flags)
                 # round 5: by default the producing pass leaves positions 0..3 to the first later read
                 # (TileArgs::mw_lean, k_mw_read_later_low); QMLE_MW_NO_LEAN=1 is the round-4 split

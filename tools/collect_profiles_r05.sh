@@ -41,17 +41,15 @@ if has mw; then
   python3 $R/tools/parse_pmc.py $OUT/${TAG}_pmc_mw_n28.json $(find $OUT/mwrd $OUT/mwwr -name "*counter_collection.csv") > $OUT/parse_mw.log
   (cd $R && python3 tools/update_traffic.py $OUT/${TAG}_pmc_mw_n28.json 28 0 mw \
     "profiles/${TAG}_pmc_mw_n28.json: every k_mw_* launch of one qmle_meyer_wallach call (rocprofv3 --pmc, separate read / write passes, on tools/mw_bench.py 28 with MW_REPS=8), averaged over the calls of the run)" > $OUT/traffic2.log)
-  export QMLE_MW_FUSE_TILED=1
   rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/mwfrd -o rd -- \
     python3 $R/tools/mw_fused_target.py > $OUT/mwfrd.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/mwfwr -o wr -- \
     python3 $R/tools/mw_fused_target.py > $OUT/mwfwr.log 2>&1
   python3 $R/tools/parse_pmc.py $OUT/${TAG}_pmc_mw_fused_n28.json $(find $OUT/mwfrd $OUT/mwfwr -name "*counter_collection.csv") > $OUT/parse_mwf.log
   (cd $R && python3 tools/update_traffic.py $OUT/${TAG}_pmc_mw_fused_n28.json 28 8 mwfused \
-    "profiles/${TAG}_pmc_mw_fused_n28.json: the k_mw_read_later launches of one fused call (QMLE_MW_FUSE_TILED=1, rocprofv3 --pmc, separate read / write passes, tools/mw_fused_target.py with MW_REPS=8): bytes fetched after the circuit" > $OUT/traffic3.log)
+    "profiles/${TAG}_pmc_mw_fused_n28.json: the k_mw_read_later launches of one fused call (the default route, rocprofv3 --pmc, separate read / write passes, tools/mw_fused_target.py with MW_REPS=8): bytes fetched after the circuit" > $OUT/traffic3.log)
   export MW_REPS=30
   stats_of mw_fused python3 $R/tools/mw_fused_profile.py
-  unset QMLE_MW_FUSE_TILED
   export MW_REPS=100
   python3 $R/tools/mw_bench.py 28 24 2>/dev/null | grep "^n=" > $OUT/${TAG}_mw_n28.txt || true
   cp $R/profiles/traffic.json $OUT/traffic.json
@@ -61,10 +59,8 @@ if has sq; then
   export MW_REPS=4
   bash $R/tools/sq_counters.sh mw_resident "k_mw_read" -- python3 $R/tools/mw_bench.py 28
   cp $R/gpurun_out/sq_mw_resident.txt $OUT/${TAG}_mw_sq_resident.txt
-  export QMLE_MW_FUSE_TILED=1
   bash $R/tools/sq_counters.sh mw_fused "k_mw_read|k_tile2" -- python3 $R/tools/mw_fused_target.py
   cp $R/gpurun_out/sq_mw_fused.txt $OUT/${TAG}_mw_sq_fused.txt
-  unset QMLE_MW_FUSE_TILED
   export DT_N=24 DT_LAYERS=4 DT_B=32 DT_FLAGS=0 DT_REPS=2
   bash $R/tools/sq_counters.sh deep_default "k_tile" -- python3 $R/tools/deep_target.py
   cp $R/gpurun_out/sq_deep_default.txt $OUT/${TAG}_deep_default_sq.txt

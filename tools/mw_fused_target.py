@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counter target: MW_REPS calls of the circuit + Meyer-Wallach through QMLE_MEAS_MEYER_WALLACH at n = 28 (the
-fused tiled route when QMLE_MW_FUSE_TILED=1 is exported, else the default route) -- nothing else on the GPU."""
+fused tiled route -- the default since round 5; QMLE_MW_FUSE_TILED=0 selects the stand-alone reads) -- nothing else on the GPU."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

@@ -32,14 +32,13 @@ def timed(fn, reps=100, warm=25):
 for rnd in range(2):
     circ, _ = timed(lambda: plan.run(ang, "state", out=st, workspace=ws_s))
     res, q0 = timed(lambda: N.meyer_wallach(st))
-    os.environ.pop("QMLE_MW_FUSE_TILED", None)
+    os.environ["QMLE_MW_FUSE_TILED"] = "0"
     dflt, qd = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
-    os.environ["QMLE_MW_FUSE_TILED"] = "1"
+    del os.environ["QMLE_MW_FUSE_TILED"]
     os.environ["QMLE_MW_NO_LEAN"] = "1"
     full, qf = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
     del os.environ["QMLE_MW_NO_LEAN"]
     lean, ql = timed(lambda: plan.run(ang, "mw", workspace=ws_m))
-    del os.environ["QMLE_MW_FUSE_TILED"]
-    print(f"n={n} round {rnd}: circuit {circ:.4f} ms | resident (3 reads) {res:.4f} ms | after the circuit: default route {dflt - circ:.4f}, "
+    print(f"n={n} round {rnd}: circuit {circ:.4f} ms | resident (3 reads) {res:.4f} ms | after the circuit: stand-alone reads {dflt - circ:.4f}, "
           f"fused full epilogue {full - circ:.4f}, fused lean epilogue {lean - circ:.4f} ms | "
           f"Q {float(q0[0]):.7f} {float(qd[0, 0]):.7f} {float(qf[0, 0]):.7f} {float(ql[0, 0]):.7f}", flush=True)
