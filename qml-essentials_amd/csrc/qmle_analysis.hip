@@ -1379,7 +1379,7 @@ struct MwCover {
   int src_read[QMLE_MAX_QUBITS], src_col[QMLE_MAX_QUBITS];
   bool ok = true;
 };
-constexpr int kMwCoverPairing = 0;
+constexpr int kMwCoverPairing = 1;  // measured at n = 28 behind the K2-style last tile {0..6, 23..27}: 0.792 ms after the circuit (0: 0.801, 2: 0.801; profiles/r05_mw_pairing_nt.txt)
 static MwCover mw_cover(int n, uint32_t tile_mask, int batch) {
   MwCover cv;
   for (int p = 0; p < n; ++p) cv.src_read[p] = cv.src_col[p] = -1;
