@@ -252,10 +252,13 @@ k_init_zero(float4 *__restrict__ states, int n) {
 // zeros).  ONE plain store per thread and no loop: 6.79 TB/s on 4 GiB; four stores per thread
 // 6.29, sixteen 5.71, a grid-stride loop 5.35, hipMemsetAsync 6.59, non-temporal stores a little
 // below each (tools/fill_bench.hip) -- and one workgroup per 32 KiB tile inside k_tile2 6.0.
+template <bool NT>
 __global__ void __launch_bounds__(256) k_fill_zero(float4 *__restrict__ p, uint64_t count) {
   const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (k < count) p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < count) st4<NT>(p + k, make_float4(0.f, 0.f, 0.f, 0.f));
 }
+
+constexpr bool kFillNtDefault = false;
 
 template <int MODE>
 void launch_direct_mode(bool diag, bool nt, dim3 grid, hipStream_t stream, float4 *st, int n,
@@ -368,8 +371,15 @@ void launch_diag_all(float2 *states, int n, int batch, const float *marks, const
 void launch_fill_zero(float2 *states, uint64_t count, hipStream_t stream) {
   for (uint64_t done = 0; done < count;) {
     const uint64_t part = std::min<uint64_t>(count - done, (uint64_t)1 << 38);
-    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((part + 255u) / 256u)), dim3(256), 0, stream,
-                       reinterpret_cast<float4 *>(states) + done, part);
+    // (QMLE_FILL_NT=1: streaming stores -- the fill by itself is a little slower with them, tools/fill_bench.hip; the
+    // pass that reads the zeros next does not run into their write-back.  Read per launch: A/B)
+    const char *e = std::getenv("QMLE_FILL_NT");
+    if (e ? atoi(e) != 0 : kFillNtDefault)
+      hipLaunchKernelGGL(k_fill_zero<true>, dim3((unsigned)((part + 255u) / 256u)), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(states) + done, part);
+    else
+      hipLaunchKernelGGL(k_fill_zero<false>, dim3((unsigned)((part + 255u) / 256u)), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(states) + done, part);
     done += part;
   }
 }

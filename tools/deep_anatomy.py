@@ -8,10 +8,10 @@ from qml_essentials_amd import _native as N
 from qml_essentials_amd import simulation
 from qml_essentials_amd.model import Model
 
-n, B = 24, int(os.environ.get("DEEP_B", "64"))
+n, B = int(os.environ.get("DEEP_N", "24")), int(os.environ.get("DEEP_B", "64"))
 flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB if os.environ.get("DEEP_DEFAULT") is None else int(os.environ["DEEP_DEFAULT"]) & ~1
 simulation.PLAN_FLAGS = flags
-model = Model(n, 4, "Hardware_Efficient", data_reupload=True)
+model = Model(n, int(os.environ.get("DEEP_LAYERS", "4")), os.environ.get("DEEP_CIRCUIT", "Hardware_Efficient"), data_reupload=True)
 rng = np.random.default_rng(1000)
 params = rng.uniform(0, 2 * np.pi, (B, *model.params.shape[1:])).astype(np.float32)
 x = np.full((1, 1), 0.5, dtype=np.float32)

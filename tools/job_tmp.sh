@@ -1,5 +1,8 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-for m in 0 1 2; do echo "pairing $m"; QMLE_MW_PAIRING=$m python tools/mw_lean_ab.py 2>/dev/null | tail -1; done
-echo "last-pass NT off:"; QMLE_LAST_PASS_NT=0 python tools/mw_lean_ab.py 2>/dev/null | tail -1
-python -m pytest tests -m gpu -x -q > gpurun_out/r05_gputests_7.log 2>&1; tail -3 gpurun_out/r05_gputests_7.log
+for v in 0 1 0 1; do echo "QMLE_FILL_NT=$v"; QMLE_FILL_NT=$v python bench.py --steps 10 --warmup 3 --skip-aux 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['ms_per_step'], [p['avg_launch_ms'] for p in d['roofline']['per_pass']], d['roofline']['frac'])"; done
+for fl in 0 32; do echo "deep n=24 flags=$fl"; DEEP_DEFAULT=$fl python tools/deep_anatomy.py 2>/dev/null | tail -1; done
+for fl in 0 32; do echo "c2 n=20 flags=$fl"; DEEP_N=20 DEEP_B=256 DEEP_DEFAULT=$fl python tools/deep_anatomy.py 2>/dev/null | tail -1; done
