@@ -333,8 +333,11 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
   // in ascending order (+2 ... +15 % with any multiplier), so only these two get it.
   // QMLE_K1_BLOCK_MUL=<odd | 0> overrides (read per launch).
   uint32_t blk_mul = 0;
-  if (op.nc && mode == 2 && (grid.x & (grid.x - 1u)) == 0 && items == (uint64_t)grid.x * 256u) {
+  if (op.nc && (mode == 2 || mode == 9) && (grid.x & (grid.x - 1u)) == 0 && items == (uint64_t)grid.x * 256u) {
     if (!diag && (pc == 7 || pc == 8) && n >= 24 && grid.x > 4097u) blk_mul = 4097u;
+    // (round 5, K1 CRZ / CZ / CPhase: the diagonal forms show the same pattern -- CRZ 0.46 ms with the control on
+    // position 8, CZ 0.23-0.25 ms with control or target on 7 / 8 where their neighbours take 0.33 / 0.17)
+    if (diag && n >= 24 && grid.x > 4097u && (pc == 7 || pc == 8 || (mode == 9 && (pt == 7 || pt == 8)))) blk_mul = 4097u;
     const char *e = std::getenv("QMLE_K1_BLOCK_MUL");
     if (e) blk_mul = atoi(e) > 0 ? ((uint32_t)atoi(e) | 1u) : 0u;
   }

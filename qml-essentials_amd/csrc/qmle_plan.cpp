@@ -852,7 +852,10 @@ int compile_plan(qmle_plan *p) {
                              m0.kind == LK_1Q &&
                              (m0.nc == 0 ||
                               (m0.nc == 1 && (m0.c0 == 0 || m0.c0 >= 4 ||
-                                              (!(m0.flags & LF_DIAG) && n >= 14 && m0.t0 >= 1 && m0.t0 <= 6))));
+                                              (!(m0.flags & LF_DIAG) && n >= 14 && m0.t0 >= 1 && m0.t0 <= 6) ||
+                                              // a controlled PHASE rewrites the |11> quarter only (k_direct_1q mode 9):
+                                              // with the target above the line that is half the lines, not all of them
+                                              ((m0.flags & LF_PHASE) && m0.t0 >= 4))));
       if (direct_ok) {
         st.kind = ST_DIRECT;
         p->dev_ops.push_back(m0);
