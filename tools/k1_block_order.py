@@ -19,7 +19,7 @@ for mul in muls:
     os.environ["QMLE_K1_BLOCK_MUL"] = str(mul)  # (0 = ascending order, also where the library would pick 4097)
     row = []
     for w in wires:
-        plan = N.Plan([("CX", [(w + int(os.environ.get("K1_CTRL_DELTA", "1"))) % n, w], [], -1)], n, 1, flags=N.PLAN_NO_FUSION)
+        plan = N.Plan([(os.environ.get("K1_GATE", "CX"), [(w + int(os.environ.get("K1_CTRL_DELTA", "1"))) % n, w], [], -1)], n, 1, flags=N.PLAN_NO_FUSION)
         ws = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
         for _ in range(8):
             N.apply_inplace(plan, ang, st, ws)
