@@ -138,7 +138,7 @@ def kernel_of_stage(st, i, n_stages, n, dense):
     if st.get("product") and 0 < i < n_stages - 1:
         live = bin(~st["zero_in"] & ((1 << n) - 1)).count("1")
         return "k_product_stream" if live >= 9 and not st["zero_in"] & 1 else "k_tile_product"
-    return "k_tile2" if st.get("fast") and st["zero_in"] == 0 else "k_tile"
+    return "k_tile2" if st.get("fast") else "k_tile"  # (the fast tile path takes known-zero stages too: launch_tile)
 
 
 def max_over_ranks(value):
