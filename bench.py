@@ -710,7 +710,10 @@ def pass_table(run, dense):
         gbps = moved / us / 1e3 if us > 0 else 0.0
         groups = len(st.get("fast_groups") or st.get("groups") or [])
         launch_us = run["stage_ms"][i] * 1e3 / max(1, run["stage_cnt"][i])
-        tf = st.get("flops_per_state", 0.0) / us / 1e6 if us > 0 else 0.0  # nominal fp32 flops of the pass's operators
+        # fp32 flops of the pass's operators: nominal for all-live plans, else charged for the amplitudes that can
+        # be non-zero when each operator is applied (qmle_plan.cpp stage_flops_per_state)
+        fl = st.get("flops_per_state", 0.0) if dense else st.get("flops_live_per_state", st.get("flops_per_state", 0.0))
+        tf = fl / us / 1e6 if us > 0 else 0.0
         hbm_frac, valu_frac = gbps / HBM_PEAK_GBPS, tf / VALU_PEAK_TFLOPS
         bound = "launch" if launch_us < 3.0 else ("hbm" if hbm_frac >= valu_frac and hbm_frac >= 0.3 else "valu+lds")
         rows.append({"pass": i + 1, "kernel": kernel_of_stage(st, i, ns, n, dense), "T": st.get("T"),
@@ -720,14 +723,18 @@ def pass_table(run, dense):
     return rows
 
 
-def valu_roofline(run):
-    """The vector-unit side of a run whose passes are not HBM-bound: nominal fp32 flops of the operators the
-    plan applies (14 per amplitude for a dense 2x2, 6 for a diagonal one, halved per control, 0 for X / CX:
-    plan_flops_per_state; known-zero amplitudes NOT discounted) / the summed HIP-event time of the passes."""
+def valu_roofline(run, dense):
+    """The vector-unit side of a run whose passes are not HBM-bound: fp32 flops of the operators the plan applies
+    (14 per amplitude for a dense 2x2, 6 for a diagonal one, halved per control, 0 for X / CX) -- for plans that
+    track known zeros charged only for the amplitudes that can be non-zero when the operator is applied
+    (stage_flops_per_state in qmle_plan.cpp) -- / the summed HIP-event time of the passes."""
     sec = sum(run["stage_ms"]) * 1e-3 / (run["B"] * run["steps"])
-    tf = run["desc"]["flops_per_state"] / sec / 1e12 if sec > 0 else 0.0
+    key = "flops_per_state" if dense else "flops_live_per_state"
+    flops = sum(st.get(key, st.get("flops_per_state", 0.0)) for st in run["desc"]["stages"])
+    tf = flops / sec / 1e12 if sec > 0 else 0.0
     return {"bound": "valu", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / VALU_PEAK_TFLOPS, 4), "fp32_flops_per_state": run["desc"]["flops_per_state"]}
+            "frac": round(tf / VALU_PEAK_TFLOPS, 4), "fp32_flops_per_state": flops,
+            "flops_counted": "nominal (every amplitude live)" if dense else "live amplitudes only (known zeros discounted)"}
 
 
 def bound_of(rows):
@@ -777,7 +784,7 @@ def c2_leg(cpu_seconds=6.0):
                          "achieved": round(gbps, 1), "unit": "GB/s",
                          "peak": HBM_PEAK_GBPS, "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "peak_l2": L2_PEAK_GBPS, "frac_of_l2": round(gbps / L2_PEAK_GBPS, 4),
-                         "valu": valu_roofline(run),
+                         "valu": valu_roofline(run, dense),
                          "infinity_cache_gather_GBps": MALL_GATHER_GBPS,
                          "avg_launch_ms": round(dom["ms"] / max(1, dom["launches"]), 5), "launches": dom["launches"],
                          "kernel_share_of_step": round(dom["ms"] / (run["elapsed"] * 1e3), 4),
@@ -924,7 +931,7 @@ def mw_28q_leg(n=28, reps=100, warmup=25):
                                        "byte_floor = the two later reads at 8 TB/s; the epilogue's issue floor = its vector "
                                        "instructions per work item and tile (128 packed fmas of cross terms, 31 values x 6 "
                                        "DPP adds of the wave reduction, ~60 for populations / addresses) x 4 cycles on 1024 SIMDs "
-                                       "at 2.1 GHz: the producing pass issues vector instructions 76 % of its cycles "
+                                       "at 2.1 GHz: the producing pass issues vector instructions 85 % of its cycles "
                                        "(profiles/r05_mw_sq_fused.txt), so the epilogue is paid in full"},
             "roofline": {"bound": "hbm", "kernel": "k_mw_read_first + 2 x k_mw_read_later", "achieved": round(D8 / ms / 1e6, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(D8 / ms / 1e6 / HBM_PEAK_GBPS, 4),
@@ -1227,7 +1234,7 @@ def main(argv=None):
                 # what limits the step: time share of its passes by the resource each is nearer to
                 deep[label]["roofline"]["bound"] = top
                 deep[label]["roofline"]["time_share_by_bound"] = share
-                deep[label]["roofline"]["valu"] = valu_roofline(d)
+                deep[label]["roofline"]["valu"] = valu_roofline(d, fl != 0)
                 deep[label]["per_pass"] = rows
                 del d
             deep["workload"] = (f"Model({n}, 4, Hardware_Efficient) with data re-uploading, input 0.5: "

@@ -1160,19 +1160,39 @@ static double plan_flops_per_state(const qmle_plan *p) {
   return f;
 }
 
-// the same count for the operators of one stage (nominal: known-zero amplitudes are not discounted)
-static double stage_flops_per_state(const qmle_plan *p, const Stage &st) {
+// the same count for the operators of one stage.  `live`: in a run from |0..0> with known-zero tracking, an
+// operator is charged for the amplitudes that can be non-zero when it is applied (every known-zero position
+// outside its own bits halves them; a known-zero CONTROL leaves nothing to do; a gate that is not diagonal takes its
+// target out of the set) -- what the kernels skip at wave granularity; else nominal, the whole register.
+static double stage_flops_per_state(const qmle_plan *p, const Stage &st, bool live_only) {
   const double D = std::ldexp(1.0, p->n);
   double f = 0;
+  const bool sparse = live_only && !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
+  uint32_t Z = sparse ? st.zero_in : 0u;
+  auto gpos = [&](int local) { return st.kind == ST_TILE && local >= 0 ? (int)st.tile_bits[local] : local; };
   for (int i = st.op_begin; i < st.op_end && i < (int)p->dev_ops.size(); ++i) {
     const LoweredOp &op = p->dev_ops[i];
-    const double live = D / (double)(1u << op.nc);
-    switch (op.kind) {
-      case LK_1Q: f += (op.flags & LF_PERMX) ? 0.0 : (op.flags & LF_DIAG) ? 6.0 * live : 14.0 * live; break;
-      case LK_2Q: f += 30.0 * live; break;
-      case LK_DIAG_ALL: f += 6.0 * D; break;
-      case LK_4Q: f += 126.0 * D; break;
+    uint32_t own = 0, ctl = 0;
+    if (op.kind != LK_DIAG_ALL) {
+      own |= 1u << gpos(op.t0);
+      if (op.t1 >= 0) own |= 1u << gpos(op.t1);
+      if (op.kind == LK_4Q) { own |= 1u << gpos(op.c0); own |= 1u << gpos(op.c1); }
+      else {
+        if (op.nc >= 1) ctl |= 1u << gpos(op.c0);
+        if (op.nc >= 2) ctl |= 1u << gpos(op.c1);
+      }
     }
+    double amps = D / (double)(1u << op.nc);
+    if (Z & ctl) amps = 0.0;
+    else amps /= (double)(1ull << __builtin_popcount(Z & ~own & ~ctl));
+    switch (op.kind) {
+      case LK_1Q: f += (op.flags & LF_PERMX) ? 0.0 : (op.flags & LF_DIAG) ? 6.0 * amps : 14.0 * amps; break;
+      case LK_2Q: f += 30.0 * amps; break;
+      case LK_DIAG_ALL: f += 6.0 * amps; break;
+      case LK_4Q: f += 126.0 * amps; break;
+    }
+    if (op.kind == LK_DIAG_ALL || (op.kind == LK_1Q && (op.flags & LF_DIAG))) continue;
+    Z &= ~own;  // mixed positions are live from here on
   }
   return f;
 }
@@ -1197,7 +1217,8 @@ std::string describe_plan(const qmle_plan *p) {
        << ",\"L\":" << st.L << ",\"lds_round_trips\":" << (st.grp_end - st.grp_begin)
        << ",\"algo_bytes_per_state\":"
        << st.algo_bytes_per_state + (s + 1 == p->stages.size() ? p->extra_algo_last_stage : 0.0)
-       << ",\"flops_per_state\":" << stage_flops_per_state(p, st)
+       << ",\"flops_per_state\":" << stage_flops_per_state(p, st, false)
+       << ",\"flops_live_per_state\":" << stage_flops_per_state(p, st, true)
        << ",\"zero_in\":" << st.zero_in << ",\"next_tile\":" << (st.next_tile ? "true" : "false")
        << ",\"product\":" << (st.product_ok ? "true" : "false") << ",\"expval_kernel\":\""
        << (const char *[]){"k_tile", "k_reg_measure", "k_reg_measure_fold", "k_reg_measure_mono"}

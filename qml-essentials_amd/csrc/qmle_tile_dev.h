@@ -187,6 +187,7 @@ struct TileArgs {
   int8_t tile_bits[QMLE_MAX_QUBITS];
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
+  uint16_t obs_local[QMLE_MAX_QUBITS]; // the same restricted to the tile, in LOCAL bits (bit j <=> Z on tile_bits[j])
   // TM_EXPVAL_PARTIAL, full-size tiles: where thread q finds <Z> of global bit position q among the
   // per-wave sums: 0..5 lane bit, 6..9 iteration bit, 10 total (q = 32), 16 + k wave-index bit k,
   // 32 + i outer position i (sign = tile-index bit i), 64 unused
@@ -493,10 +494,14 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
     const uint32_t cnt = 1u << T;
     if (cnt == 16u * nt && nt >= 64) {
       // element e = tid + it * nt: lane = local bits 0..5, wave = bits 6..T-5, it = top 4 bits.
-      // Walsh-Hadamard transform of the tile's probabilities over the 4 iteration bits (in
-      // registers) and the 6 lane bits (cross-lane butterflies): afterwards lane l, register
-      // i of wave w holds sum_{lane', it} (-1)^{|lane' & l| + |it & i|} p(w, lane', it), i.e.
-      // EVERY parity over those 10 bits at once; the observables pick theirs.
+      // Walsh-Hadamard transform of the work item's 16 probabilities over the 4 iteration bits (in registers):
+      // w[i] = sum_it (-1)^{|it & i|} p(it).  An observable then needs ONE of the 16 (its iteration-bit mask),
+      // signed by the parity of the lane index under its lane mask and summed over the wave: a wave-uniform pick,
+      // one select and six DPP adds per observable -- eight observables per round of wave sums, nothing on the LDS
+      // crossbar.  (Until round 5 the transform went on across the six lane bits -- 96 cross-lane exchanges + 16 LDS
+      // stores per work item and tile for all 1024 parities of the wave, of which <= 32 were read: that epilogue
+      // made the measuring pass of folded-CX plans LDS-bound, 47 % LDS busy with 22 % bank conflicts,
+      // profiles/r05_deep_default_sq.txt.)
       float w[16];
 #pragma unroll
       for (int it = 0; it < 16; ++it) w[it] = norm2(s[sw(tid + it * nt)]);
@@ -511,33 +516,46 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
         }
       }
       const int lane = tid & (kWave - 1), wv = tid / kWave, nw = nt / kWave;
+      // (through the kernel argument segment: indexing the by-value struct with a run-time index makes hipcc copy it
+      // to scratch)
+      const uint16_t QMLE_CONSTANT *ol =
+          (const uint16_t QMLE_CONSTANT *)((const char QMLE_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs, obs_local));
+      const int n_obs = a.n_obs;
+      tile_sync<RAW>();  // all amplitudes have been read: the tile buffer becomes scratch
+      float *C = reinterpret_cast<float *>(s);  // [n_obs][nw]
+      for (int k0 = 0; k0 < n_obs; k0 += 8) {
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const bool hi = (lane >> j) & 1;
+        for (int k = 0; k < 8; ++k) {
+          v[k] = 0.f;
+          if (k0 + k < n_obs) {  // (wave-uniform)
+            const uint32_t lm = ol[k0 + k];
+            float sel;
+            switch (lm >> (T - 4)) {  // the observable's iteration-bit mask: wave-uniform
+              case 0: sel = w[0]; break; case 1: sel = w[1]; break; case 2: sel = w[2]; break; case 3: sel = w[3]; break;
+              case 4: sel = w[4]; break; case 5: sel = w[5]; break; case 6: sel = w[6]; break; case 7: sel = w[7]; break;
+              case 8: sel = w[8]; break; case 9: sel = w[9]; break; case 10: sel = w[10]; break; case 11: sel = w[11]; break;
+              case 12: sel = w[12]; break; case 13: sel = w[13]; break; case 14: sel = w[14]; break; default: sel = w[15]; break;
+            }
+            v[k] = (__popc((uint32_t)lane & lm & 63u) & 1) ? -sel : sel;
+          }
+        }
+        wave_sums_dpp63(v);
+        if (lane == kWave - 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float o = __shfl_xor(w[i], 1 << j, kWave);
-          w[i] = hi ? o - w[i] : w[i] + o;
+          for (int k = 0; k < 8; ++k)
+            if (k0 + k < n_obs) C[(k0 + k) * nw + wv] = v[k];
         }
       }
-      tile_sync<RAW>();  // all amplitudes have been read: the tile buffer becomes scratch
-      float *C = reinterpret_cast<float *>(s);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) C[(wv * 16 + i) * kWave + lane] = w[i];
       tile_sync<RAW>();
-      if (tid < a.n_obs) {
+      if (tid < n_obs) {
         const uint32_t m = a.obs_mask[tid];
-        uint32_t ml = 0, mw = 0, mi = 0, par = 0;
-        for (int j = 0; j < T; ++j) {
-          const uint32_t bitv = (m >> a.tile_bits[j]) & 1u;
-          if (j < 6) ml |= bitv << j;
-          else if (j < T - 4) mw |= bitv << (j - 6);
-          else mi |= bitv << (j - (T - 4));
-        }
+        const uint32_t mw = ((uint32_t)ol[tid] >> 6) & ((1u << (T - 10)) - 1u);
+        uint32_t par = 0;
         for (int i = 0; i < a.n - T; ++i) par ^= ((m >> a.outer_bits[i]) & 1u) & ((tile >> i) & 1u);
         float r = 0.f;
         for (int v = 0; v < nw; ++v) {
-          const float c = C[(v * 16 + (int)mi) * kWave + (int)ml];
+          const float c = C[tid * nw + v];
           r += (__popc((uint32_t)v & mw) & 1) ? -c : c;
         }
         po[tid] = par ? -r : r;
@@ -776,7 +794,14 @@ static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *stat
   a.n_obs = n_obs;
   std::memcpy(a.tile_bits, st.tile_bits, sizeof(a.tile_bits));
   std::memcpy(a.outer_bits, st.outer_bits, sizeof(a.outer_bits));
-  if (obs_masks) std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
+  if (obs_masks) {
+    std::memcpy(a.obs_mask, obs_masks, (size_t)n_obs * sizeof(uint32_t));
+    for (int k = 0; k < n_obs && k < QMLE_MAX_QUBITS; ++k) {
+      uint32_t lm = 0;
+      for (int j = 0; j < st.T && j < 16; ++j) lm |= ((obs_masks[k] >> st.tile_bits[j]) & 1u) << j;
+      a.obs_local[k] = (uint16_t)lm;
+    }
+  }
   a.op_begin = st.op_begin;
   for (int q = 0; q <= QMLE_MAX_QUBITS; ++q) a.qsrc[q] = 64;
   a.qsrc[QMLE_MAX_QUBITS] = 10;
