@@ -422,11 +422,16 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
     // bit 0 of the table entry: the work item's 16 amplitudes are known zeros at this point.
     // Wave-uniform use only: a wave of idle work items skips the group; an idle work item inside
     // a busy wave runs it on the zeros its slots hold (no per-lane branch around the gates)
-    const bool busy = !use_skip || __builtin_amdgcn_ballot_w64(!(addr & 1u)) != 0ull;
+    // (kept in an SGPR through readfirstlane: as a plain bool hipcc carried it across the gate loop as a lane mask
+    // and re-materialised it with v_cndmask + v_cmp per GATE -- 2 of the 66 vector instructions of a dense gate)
+    uint32_t busy_u = 1u;
+    if (use_skip) busy_u = __builtin_amdgcn_ballot_w64(!(addr & 1u)) != 0ull ? 1u : 0u;
+    int busy = __builtin_amdgcn_readfirstlane((int)busy_u);
+    asm volatile("" : "+s"(busy));  // (an integer in an SGPR, compared where it is used: not an i1 lane mask)
     addr = (addr & ~7u) + sb;
     A16 r;
     uint32_t ka[16];  // KEEP: the slot addresses (indexed with literals only)
-    if (busy || relayout) {  // (a relayout stores every slot of the new layout, zeros included)
+    if (busy != 0 || relayout) {  // (a relayout stores every slot of the new layout, zeros included)
       if (KEEP) {
 #define QMLE_LD(c) ka[c] = addr ^ QMLE_OFF(c, o1, o2, o4, o8); r.v##c = lds_ld64(ka[c]);
         QMLE_X16(QMLE_LD)
@@ -453,7 +458,7 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
       // gate's operands HERE puts that wait in front of the next prefetch instead of behind it
       asm volatile("" : "+s"(M0.m00), "+s"(M0.m01), "+s"(M0.m10), "+s"(M0.m11), "+s"(w0.y), "+s"(w1.z) :: "memory");
       if (f.dbg & 12) {  // timing anatomy only (wrong results): 4 = no per-gate scalar loads, 8 = + no dispatch
-        if (busy) {
+        if (busy != 0) {
           if (f.dbg & 8) f_dense<1>(r, M0);
           else fast_dispatch(r, (int)(w0.y >> 24), M0);
         }
@@ -462,7 +467,8 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
       const u64 QMLE_CONSTANT *mn = mrow + (w1.z >> 1);
       const Mat2S Mn = {mn[0], mn[1], mn[2], mn[3]};
       const v4u w2 = op[k + 2 < last ? k + 2 : last];
-      if (busy) fast_dispatch(r, (int)(w0.y >> 24), M0);
+      asm volatile("" : "+s"(busy));  // (re-read per gate: hoisted out of the loop the compare becomes a lane mask again)
+      if (busy != 0) fast_dispatch(r, (int)(w0.y >> 24), M0);
       w0 = w1;
       w1 = w2;
       M0 = Mn;
@@ -476,7 +482,7 @@ __device__ __forceinline__ void tile2_groups(uint32_t sb, uint32_t addr, const T
       QMLE_X16(QMLE_ST)
 #undef QMLE_ST
       if (more) addr_next = f.tbl[grp[1].tbl + tid];
-    } else if (busy) {
+    } else if (busy != 0) {
       if (KEEP) {
 #define QMLE_ST(c) lds_st64(ka[c], r.v##c);
         QMLE_X16(QMLE_ST)
