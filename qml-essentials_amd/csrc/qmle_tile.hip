@@ -1848,7 +1848,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     // reduces while amplitudes are still being read and gets its own 288 floats
     // (whole_state_expval: one float per observable and wave -- 128 B at 10 qubits instead of the
     // 1152 B of round 2's epilogue: 18-19 instead of 17 single-wave workgroups per CU)
-    const size_t lds2 = ((size_t)8 << st.T) +
+    // (QMLE_T2_LDS_PAD=<bytes>: occupancy experiment -- fewer workgroups per CU; read per launch)
+    const char *pad_env = std::getenv("QMLE_T2_LDS_PAD");
+    const size_t lds2 = ((size_t)8 << st.T) + (pad_env ? (size_t)atoi(pad_env) : 0) +
                         (meas == TM_EXPVAL ? (size_t)QMLE_MAX_QUBITS * (threads >= kWave ? threads / kWave : 1) * sizeof(float) : 0);
     const bool measure = !(meas == TM_STORE || meas == TM_PROBS);
 #define QMLE_T2_GO(NT, ME, MU) \
