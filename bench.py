@@ -36,6 +36,12 @@ with several ranks on one GPU) or the run exits non-zero.  Besides the weak-scal
 carries the strong-scaling legs BASELINE names: C3 (1024 Expressibility pairs split over the ranks)
 and C4 (the 4096-point Fourier grid, 512 points per GPU at N = 8).
 
+Legs riding in the same line (N = 1; each with its own roofline object, parity check and CPU timing where a CPU form
+exists): `c2_model_20q_4l` (BASELINE config 2: rates against HBM and L2), `c3_…` / `c4_…` (configs 3 / 4, sharded over the
+ranks) with `c3_/c4_saturated_weak` companions and `collective_ms`, `mw_28q` (config 5), `k1_single_gate_28q` (RX RZ CX
+CRX CRZ CZ CPhase on every wire), `k2_unfused`, `k2_circuit19`, `k2_deep` (per-pass bound), `exact_shortcuts`,
+`lds_regime`, `adjoint_gradient_20q` -- and `summary`, the LAST key: one figure per leg in ~3 KB.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
 ``roofline`` (dominant kernel, timed live with HIP events on the launch stream) and
 ``cpu_baseline`` (the oracle's C/OpenMP port on a bounded sample, N=1 only; its <Z> values are
