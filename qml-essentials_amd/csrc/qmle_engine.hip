@@ -397,12 +397,13 @@ static size_t expval_partial_rows(const qmle_plan *p) {
 }
 
 // Meyer-Wallach measurement: can the plan's last pass report its tile's sums (tile_mw_row)?
-// Policy (measured on MI355X, DESIGN 9d): when the last pass holds the WHOLE state (n <= 14) the sums cost
-// one epilogue and no statevector is ever stored -- always taken.  For tiled states the epilogue's
-// arithmetic (208 packed fmas + a 41-value wave reduction per work item and tile, the pass without the
-// next-tile prefetch) costs the pass as much as the read it saves: n = 28, 0.68 ms instead of 0.47 for the
-// pass + two reads = 1.01 ms after the circuit against 0.99 ms for the three reads of the stand-alone
-// kernels -- so tiled plans keep the stand-alone reads unless QMLE_MW_FUSE_TILED=1 (read per call: A/B, tests).
+// Policy (measured on MI355X, DESIGN 9d / 9e): when the last pass holds the WHOLE state (n <= 14) the sums cost
+// one epilogue and no statevector is ever stored -- always taken.  For tiled states the round-4 epilogue (208
+// packed fmas + a 41-value wave reduction per work item and tile) cost the pass what the saved read was worth
+// (n = 28: 0.99 ms after the circuit either way) and stayed opt-in; since round 5 the producing pass leaves positions
+// 0..3 to the first later read (lean epilogue) and streams its stores, so that the later reads do not run into its
+// write-back: 0.79 ms after the circuit against 0.92-1.0 for the stand-alone reads -- taken by default
+// (QMLE_MW_FUSE_TILED=0: the stand-alone reads; read per call: A/B, tests).
 static bool plan_mw_fusable(const qmle_plan *p, bool whatever_the_switches = false) {
   if (p->stages.empty()) return false;
   const Stage &last = p->stages.back();

@@ -1169,9 +1169,26 @@ static double stage_flops_per_state(const qmle_plan *p, const Stage &st, bool li
   double f = 0;
   const bool sparse = live_only && !(p->flags & (QMLE_PLAN_NO_SPARSE | QMLE_PLAN_PREFETCH));
   uint32_t Z = sparse ? st.zero_in : 0u;
-  auto gpos = [&](int local) { return st.kind == ST_TILE && local >= 0 ? (int)st.tile_bits[local] : local; };
+  // bit indices of a tile stage's ops: GROUP-local (0..3) inside a register-tile group, else tile-local
+  std::vector<const OpGroup *> group_of(st.op_end > st.op_begin ? st.op_end - st.op_begin : 0, nullptr);
+  if (st.kind == ST_TILE)
+    for (int g = st.grp_begin; g < st.grp_end; ++g) {
+      const OpGroup &og = p->op_groups[g];
+      if (og.kind != GK_REG4) continue;
+      for (int k = 0; k < (int)og.n_ops; ++k) {
+        const int idx = (int)og.op_begin + k - st.op_begin;
+        if (idx >= 0 && idx < (int)group_of.size()) group_of[idx] = &og;
+      }
+    }
+  const OpGroup *cur = nullptr;
+  auto gpos = [&](int b) {
+    if (st.kind != ST_TILE || b < 0) return b;
+    const int local = cur ? (int)cur->bits[b & 3] : b;
+    return (int)st.tile_bits[local];
+  };
   for (int i = st.op_begin; i < st.op_end && i < (int)p->dev_ops.size(); ++i) {
     const LoweredOp &op = p->dev_ops[i];
+    cur = group_of.empty() ? nullptr : group_of[i - st.op_begin];
     uint32_t own = 0, ctl = 0;
     if (op.kind != LK_DIAG_ALL) {
       own |= 1u << gpos(op.t0);
@@ -1206,6 +1223,7 @@ std::string describe_plan(const qmle_plan *p) {
      << ",\"autotuned\":" << (p->autotuned ? "true" : "false")
      << ",\"zero_run\":" << ((p->flags & QMLE_PLAN_INTERNAL_ZERO_RUN) ? "true" : "false") << ",\"tile_bits\":" << p->tile_T << ",\"low_bits\":" << p->tile_L
      << ",\"mat_floats\":" << p->mat_floats
+     << ",\"build_groups\":" << p->groups.size() << ",\"build_groups_needed\":" << p->n_groups_needed
      << ",\"algo_bytes_per_state\":" << p->algo_bytes_per_state
      << ",\"flops_per_state\":" << plan_flops_per_state(p) << ",\"stages\":[";
   for (size_t s = 0; s < p->stages.size(); ++s) {

@@ -387,3 +387,20 @@ def test_round4_entry_points_refuse_bad_arguments_before_touching_a_device():
     assert lib.qmle_plan_autotune(null, 0, 0, 1, 2, 2, null, chosen, C.byref(a), C.byref(b)) == -1
     assert lib.qmle_plan_executed(null, 0) is None
     assert plan.executed("state").stats()["n_ops"] == plan.stats()["n_ops"]
+
+
+def test_matrices_of_folded_cx_gates_are_not_built():
+    """Round 5: an X / CX inside a register-tile group is a swap of amplitudes or a change of the LDS layout
+    map -- no tile kernel reads its 2x2 matrix, so the forward engine's matrix builder skips those build
+    groups (`build_groups_needed` of `qmle_plan_describe`; the adjoint sweep and the complex128 engine build all).
+    Direct (one gate per launch) stages apply a CX through its matrix: there every group stays needed."""
+    ops, slots = he_layer_ops(10)
+    plan = N.Plan(ops, 10, slots)
+    d = plan.describe()
+    n_cx = sum(1 for o in ops if o[0] == "CX")
+    assert d["build_groups"] - d["build_groups_needed"] == n_cx > 0
+    ops24, slots24 = he_layer_ops(16)
+    unfused = N.Plan(ops24, 16, slots24, flags=N.PLAN_NO_FUSION | N.PLAN_FORCE_GLOBAL).describe()
+    direct_cx = sum(1 for st in unfused["stages"] if st["kind"] == "direct")
+    assert direct_cx > 0 and unfused["build_groups"] - unfused["build_groups_needed"] < n_cx + 100
+    assert unfused["build_groups_needed"] >= direct_cx
