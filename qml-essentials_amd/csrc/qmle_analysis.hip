@@ -966,6 +966,76 @@ k_mw_purity_final(const double *__restrict__ partial, int n, int batch, int slic
   const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
   pur_out[i] = (float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));
 }
+// ---- the same sums in two coalesced steps (round 5; tiled producing passes) ---------------------
+// k_mw_purity_fused walks the rows once per POSITION: 28 blocks re-read the 12.6 MB of rows of an n = 28 state
+// through the L2 with 4 floats used of every 192-byte row (33 us + 11 us for the slices + 5 us to pack: 6 % of the
+// fused call).  k_mw_colsum sums EVERY column of a row matrix in one coalesced sweep (thread = column, block = a
+// slice of the rows; the totals signed by the bits of the row index ride along as extra "columns"), for the
+// producing pass's rows and each later read's in one launch (blockIdx.z); k_mw_finish_cols turns a state's
+// column sums into its purities and Q.
+struct MwColsumArgs {
+  const float *rows[9];   // [0] the producing pass's rows, [1 + r] later read r
+  uint32_t n_rows[9], stride[9];
+  int n_cols[9];
+  int tot_col, n_signed;  // matrix 0 only: column of the row total, number of row-index bits to sign it by
+  int slices;
+  double *out[9];         // [batch][slices][n_cols + n_signed]
+};
+__global__ void __launch_bounds__(128)
+k_mw_colsum(const MwColsumArgs a) {
+  const int m = blockIdx.z, b = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+  const int nc = a.n_cols[m], ns = m == 0 ? a.n_signed : 0;
+  if (t >= nc + ns) return;
+  const uint32_t per = (a.n_rows[m] + a.slices - 1) / a.slices;
+  const uint32_t lo = sl * per, hi = lo + per < a.n_rows[m] ? lo + per : a.n_rows[m];
+  const float *base = a.rows[m] + (size_t)b * a.n_rows[m] * a.stride[m];
+  double acc = 0.0;
+  if (t < nc) {
+    for (uint32_t i = lo; i < hi; ++i) acc += (double)base[(size_t)i * a.stride[m] + t];
+  } else {
+    const int k = t - nc;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const double v = (double)base[(size_t)i * a.stride[m] + a.tot_col];
+      acc += ((i >> k) & 1u) ? -v : v;
+    }
+  }
+  a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + t] = acc;
+}
+// one block per state, thread p = bit position: purity from the column sums, Q through a wave sum
+__global__ void __launch_bounds__(64)
+k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, float *__restrict__ out /* [batch][n + 1] */) {
+  const int b = blockIdx.x, p = threadIdx.x;
+  const int T = a.T, n = a.n, lg = a.lg;
+  double pur = 0.0;
+  if (p < n) {
+    const int w0 = c.n_cols[0] + c.n_signed;
+    auto col0 = [&](int col) {
+      double s = 0.0;
+      const double *o = c.out[0] + (size_t)b * c.slices * w0 + col;
+      for (int sl = 0; sl < c.slices; ++sl) s += o[(size_t)sl * w0];
+      return s;
+    };
+    const int j = a.loc[p], oi = a.outer_idx[p];
+    const double tot = col0(3 * T);
+    double cr = 0.0, ci = 0.0, z;
+    if (j >= 0) {
+      z = col0(2 * T + j);
+      if (!(a.lean && p < 4)) { cr = col0(2 * j); ci = col0(2 * j + 1); }
+    } else if (oi < lg) z = col0(3 * T + 1 + oi);
+    else z = col0(c.n_cols[0] + (oi - lg));
+    if (j < 0 || (a.lean && p < 4)) {
+      const int r = a.src_read[p], col = a.src_col[p], wr = c.n_cols[1 + r];
+      const double *o = c.out[1 + r] + (size_t)b * c.slices * wr;
+      for (int sl = 0; sl < c.slices; ++sl) { cr += o[(size_t)sl * wr + 2 * col]; ci += o[(size_t)sl * wr + 2 * col + 1]; }
+    }
+    const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
+    pur = (double)(float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));  // (rounded like k_mw_purity_fused's store)
+    out[(size_t)b * (n + 1) + 1 + (n - 1 - p)] = (float)pur;  // index by wire
+  }
+  const double sum = wave_sum_d(pur);
+  if (p == 0) out[(size_t)b * (n + 1)] = (float)(2.0 * (1.0 - sum / n));
+}
+
 // Whole-state plans: ONE row per state and every position local to the producing tile -- purities and Q of a
 // state from its row in one work item (the same fp64 arithmetic as k_mw_purity_fused + k_mw_pack, whose
 // 24 576 one-row workgroups took 16 + 5 us of the 12-qubit sampling loop's 185)
@@ -1435,6 +1505,12 @@ static MwCover mw_cover(int n, uint32_t tile_mask, int batch) {
   return cv;
 }
 
+static int mw_colsum_slices(uint32_t most_rows) {  // >= 64 rows per block, <= 256 blocks per state and matrix
+  int slices = 1;
+  while (slices < 256 && (most_rows >> 6) > (uint32_t)slices) slices *= 2;
+  return slices;
+}
+
 static uint32_t stage_tile_mask(const Stage &st) {
   uint32_t m = 0;
   for (int j = 0; j < st.T; ++j) m |= 1u << st.tile_bits[j];
@@ -1467,8 +1543,16 @@ size_t mw_fused_ws_bytes(int n, int batch, const Stage &last) {
     const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
     for (int r = 0; r < cv.n_later; ++r) fl += (size_t)cv.rows_later[r] * kMwRowLaterLow;  // (either row length fits)
   }
+  size_t colsum = 0;  // k_mw_colsum's slices (tiled producing passes only)
+  if (last.T < n) {
+    const MwCover cv = mw_cover(n, stage_tile_mask(last), batch);
+    uint32_t most = 1u << (n - last.T);
+    for (int r = 0; r < cv.n_later; ++r) most = std::max(most, cv.rows_later[r]);
+    colsum = (size_t)batch * mw_colsum_slices(most) * (kMwFusedRowA + QMLE_MAX_QUBITS + (size_t)cv.n_later * kMwRowLaterLow) *
+                 sizeof(double) + 64;
+  }
   return ((size_t)batch * fl + (size_t)batch * QMLE_MAX_QUBITS) * sizeof(float) +
-         (size_t)8192 * 4 * sizeof(double) + 1024;  // + the purity kernel's slices (< 8192 (state, position, slice) sums)
+         (size_t)8192 * 4 * sizeof(double) + 1024 + colsum;  // + the purity kernel's slices (< 8192 (state, position, slice) sums)
 }
 
 // rows_first = ws (filled by the producing pass: [batch][tiles][kMwFusedRowA]); the later reads' rows and
@@ -1528,6 +1612,34 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
   }
   if (last.T == n && pa.rows_first == 1) {
     hipLaunchKernelGGL(k_mw_whole_state_finish, dim3((batch + 63) / 64), dim3(64), 0, stream, pa, batch, d_out);
+    HIPCHK(hipGetLastError());
+    return QMLE_OK;
+  }
+  static const bool old_purity = std::getenv("QMLE_MW_OLD_PURITY") != nullptr;  // (A/B: the per-position walk)
+  if (last.T < n && !old_purity && 3 * last.T + 5 <= kMwFusedRowA) {
+    MwColsumArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    uint32_t most = pa.rows_first;
+    for (int r = 0; r < 8; ++r) most = std::max(most, pa.rows_later[r]);
+    const int slices = mw_colsum_slices(most);
+    ca.slices = slices;
+    ca.rows[0] = pa.first; ca.n_rows[0] = pa.rows_first; ca.stride[0] = kMwFusedRowA; ca.n_cols[0] = kMwFusedRowA;
+    ca.tot_col = 3 * last.T;
+    ca.n_signed = n - last.T - pa.lg > 0 ? n - last.T - pa.lg : 0;
+    int n_mats = 1;
+    for (int r = 0; r < 8 && pa.later[r]; ++r) {
+      ca.rows[1 + r] = pa.later[r]; ca.n_rows[1 + r] = pa.rows_later[r]; ca.stride[1 + r] = pa.later_stride[r];
+      ca.n_cols[1 + r] = (int)pa.later_stride[r];
+      n_mats = 2 + r;
+    }
+    double *dp = (double *)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
+    for (int m = 0; m < n_mats; ++m) {
+      ca.out[m] = dp;
+      dp += (size_t)batch * slices * (ca.n_cols[m] + (m == 0 ? ca.n_signed : 0));
+    }
+    if ((size_t)((char *)dp - (char *)ws_) > ws_bytes) return QMLE_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k_mw_colsum, dim3(slices, batch, n_mats), dim3(128), 0, stream, ca);
+    hipLaunchKernelGGL(k_mw_finish_cols, dim3(batch), dim3(64), 0, stream, pa, ca, d_out);
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }
