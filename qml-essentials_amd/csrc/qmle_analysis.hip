@@ -1001,32 +1001,49 @@ k_mw_colsum(const MwColsumArgs a) {
   }
   a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + t] = acc;
 }
-// one block per state, thread p = bit position: purity from the column sums, Q through a wave sum
-__global__ void __launch_bounds__(64)
-k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, float *__restrict__ out /* [batch][n + 1] */) {
-  const int b = blockIdx.x, p = threadIdx.x;
-  const int T = a.T, n = a.n, lg = a.lg;
+// one block per state: the slices of every matrix are summed by all 1024 threads (thread = column x one of 8
+// slice lanes: coalesced, 32 independent loads each at 256 slices), then thread p = bit position turns the sums
+// into its purity and a wave sum into Q.  (A first form with one thread per position walking the slices itself
+// was latency-bound: 1800 dependent loads, 0.43 ms.)
+constexpr int kMwColsMax = 128;
+__global__ void __launch_bounds__(1024)
+k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, int n_mats, float *__restrict__ out /* [batch][n + 1] */) {
+  __shared__ double lane_sum[8][kMwColsMax];
+  __shared__ double fin[9][kMwColsMax];
+  const int b = blockIdx.x, t = threadIdx.x, col = t & (kMwColsMax - 1), q = t / kMwColsMax;
+  for (int m = 0; m < n_mats; ++m) {
+    const int w = c.n_cols[m] + (m == 0 ? c.n_signed : 0);
+    double acc = 0.0;
+    if (col < w) {
+      const double *o = c.out[m] + (size_t)b * c.slices * w + col;
+      for (int sl = q; sl < c.slices; sl += 8) acc += o[(size_t)sl * w];
+    }
+    lane_sum[q][col] = acc;
+    __syncthreads();
+    if (q == 0 && col < w) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += lane_sum[k][col];
+      fin[m][col] = s;
+    }
+    __syncthreads();
+  }
+  const int p = t, T = a.T, n = a.n, lg = a.lg;
+  if (t >= kWave) return;
   double pur = 0.0;
   if (p < n) {
-    const int w0 = c.n_cols[0] + c.n_signed;
-    auto col0 = [&](int col) {
-      double s = 0.0;
-      const double *o = c.out[0] + (size_t)b * c.slices * w0 + col;
-      for (int sl = 0; sl < c.slices; ++sl) s += o[(size_t)sl * w0];
-      return s;
-    };
     const int j = a.loc[p], oi = a.outer_idx[p];
-    const double tot = col0(3 * T);
+    const double tot = fin[0][3 * T];
     double cr = 0.0, ci = 0.0, z;
     if (j >= 0) {
-      z = col0(2 * T + j);
-      if (!(a.lean && p < 4)) { cr = col0(2 * j); ci = col0(2 * j + 1); }
-    } else if (oi < lg) z = col0(3 * T + 1 + oi);
-    else z = col0(c.n_cols[0] + (oi - lg));
+      z = fin[0][2 * T + j];
+      if (!(a.lean && p < 4)) { cr = fin[0][2 * j]; ci = fin[0][2 * j + 1]; }
+    } else if (oi < lg) z = fin[0][3 * T + 1 + oi];
+    else z = fin[0][c.n_cols[0] + (oi - lg)];
     if (j < 0 || (a.lean && p < 4)) {
-      const int r = a.src_read[p], col = a.src_col[p], wr = c.n_cols[1 + r];
-      const double *o = c.out[1 + r] + (size_t)b * c.slices * wr;
-      for (int sl = 0; sl < c.slices; ++sl) { cr += o[(size_t)sl * wr + 2 * col]; ci += o[(size_t)sl * wr + 2 * col + 1]; }
+      const int r = a.src_read[p], cc = a.src_col[p];
+      cr += fin[1 + r][2 * cc];
+      ci += fin[1 + r][2 * cc + 1];
     }
     const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
     pur = (double)(float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));  // (rounded like k_mw_purity_fused's store)
@@ -1639,7 +1656,8 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
     }
     if ((size_t)((char *)dp - (char *)ws_) > ws_bytes) return QMLE_ERR_WORKSPACE;
     hipLaunchKernelGGL(k_mw_colsum, dim3(slices, batch, n_mats), dim3(128), 0, stream, ca);
-    hipLaunchKernelGGL(k_mw_finish_cols, dim3(batch), dim3(64), 0, stream, pa, ca, d_out);
+    if (ca.n_cols[0] + ca.n_signed > kMwColsMax) return QMLE_ERR_INTERNAL;
+    hipLaunchKernelGGL(k_mw_finish_cols, dim3(batch), dim3(1024), 0, stream, pa, ca, n_mats, d_out);
     HIPCHK(hipGetLastError());
     return QMLE_OK;
   }
