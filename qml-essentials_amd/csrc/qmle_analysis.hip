@@ -989,17 +989,26 @@ k_mw_colsum(const MwColsumArgs a) {
   const uint32_t per = (a.n_rows[m] + a.slices - 1) / a.slices;
   const uint32_t lo = sl * per, hi = lo + per < a.n_rows[m] ? lo + per : a.n_rows[m];
   const float *base = a.rows[m] + (size_t)b * a.n_rows[m] * a.stride[m];
-  double acc = 0.0;
-  if (t < nc) {
-    for (uint32_t i = lo; i < hi; ++i) acc += (double)base[(size_t)i * a.stride[m] + t];
-  } else {
-    const int k = t - nc;
-    for (uint32_t i = lo; i < hi; ++i) {
-      const double v = (double)base[(size_t)i * a.stride[m] + a.tot_col];
-      acc += ((i >> k) & 1u) ? -v : v;
-    }
+  // eight rows in flight per thread (one load per iteration left the sweep bound by the latency of 256 dependent
+  // round trips: 0.13 ms at n = 28)
+  const bool signedc = t >= nc;
+  const int k = signedc ? t - nc : 0;
+  const uint32_t cidx = signedc ? (uint32_t)a.tot_col : (uint32_t)t, stride = a.stride[m];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t i = lo;
+  for (; i + 8 <= hi; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(i + u) * stride + cidx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += (signedc && (((i + u) >> k) & 1u)) ? -(double)v[u] : (double)v[u];
   }
-  a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + t] = acc;
+  for (; i < hi; ++i) {
+    const double v = (double)base[(size_t)i * stride + cidx];
+    acc[0] += (signedc && ((i >> k) & 1u)) ? -v : v;
+  }
+  a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + t] =
+      ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 // one block per state: the slices of every matrix are summed by all 1024 threads (thread = column x one of 8
 // slice lanes: coalesced, 32 independent loads each at 256 slices), then thread p = bit position turns the sums
@@ -1016,7 +1025,14 @@ k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, int n_mats, float *_
     double acc = 0.0;
     if (col < w) {
       const double *o = c.out[m] + (size_t)b * c.slices * w + col;
-      for (int sl = q; sl < c.slices; sl += 8) acc += o[(size_t)sl * w];
+      double a4[4] = {0, 0, 0, 0};
+      int sl = q;
+      for (; sl + 24 < c.slices; sl += 32) {  // four independent loads per round
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += o[(size_t)(sl + 8 * u) * w];
+      }
+      for (; sl < c.slices; sl += 8) a4[0] += o[(size_t)sl * w];
+      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     lane_sum[q][col] = acc;
     __syncthreads();
