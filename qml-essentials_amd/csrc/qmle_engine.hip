@@ -686,7 +686,7 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
                          last_fused ? d_partial : nullptr, last_fused ? obs_masks : nullptr,
                          last_fused ? n_obs : 0, stream, /*from_zero=*/true,
                          d_cols ? d_cols + (size_t)b0 * plan->fold_groups * 16 : nullptr,
-                         last_fused && single_bits ? &tile_row_shift : nullptr);
+                         last_fused && (single_bits || tm == TM_EXPVAL_MASKS) ? &tile_row_shift : nullptr);
         initialised = true;
       } else {
         if (!initialised) {

@@ -578,6 +578,88 @@ __device__ __forceinline__ void tile_z_finish(float *out, float *red, float (&ac
   }
 }
 
+// Z-parity observables (TM_EXPVAL_MASKS) for the multi-tile measuring variant (round 5).  Folded CX tails turn <Z_w>
+// into parities, and until now such a last pass kept one tile per workgroup with the full epilogue (two barriers, a
+// round of wave sums, a row) per tile: 58 us per state for the three groups of the deep default plan at n = 24, where
+// the single-bit form above takes 23 for the same work.  Per tile the work item squares its 16 amplitudes, runs the
+// 16-point Walsh-Hadamard butterfly over the iteration bits and adds, per observable, the ONE sum it needs (a
+// wave-uniform pick) -- signed by the parity of this tile's index under the observable's outer bits (wave-uniform) --
+// into the observable's own accumulator; lane signs, wave sums, wave-index signs and the row come once per walk.
+constexpr int kMaskMultiObs = 24;  // accumulators per work item (observables of a launch; more: one tile per workgroup)
+__device__ __forceinline__ float pick16(const float (&w)[16], uint32_t i) {  // i is wave-uniform
+  switch (i) {
+    case 0: return w[0]; case 1: return w[1]; case 2: return w[2]; case 3: return w[3];
+    case 4: return w[4]; case 5: return w[5]; case 6: return w[6]; case 7: return w[7];
+    case 8: return w[8]; case 9: return w[9]; case 10: return w[10]; case 11: return w[11];
+    case 12: return w[12]; case 13: return w[13]; case 14: return w[14]; default: return w[15];
+  }
+}
+__device__ __forceinline__ void tile_m_accumulate(uint32_t sbo, int T, int tid, uint32_t tile, int n_obs,
+                                                  const uint16_t QMLE_CONSTANT *ol, const uint32_t QMLE_CONSTANT *oo,
+                                                  float (&acc)[kMaskMultiObs]) {
+  uint32_t tid_e = (uint32_t)tid;
+  asm volatile("" : "+v"(tid_e));  // (keeps the 16 addresses out of loop-carried registers)
+  const uint32_t e0 = (sw(tid_e) << 3) + sbo;
+  float w[16];
+#pragma unroll
+  for (int h = 0; h < 16; h += 8) {
+    u64 amp[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) amp[it] = lds_ld64(e0 ^ (sw((uint32_t)(h + it) << (T - 4)) << 3));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      w[h + it] = norm2(make_float2(__uint_as_float((uint32_t)amp[it]), __uint_as_float((uint32_t)(amp[it] >> 32))));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i & h) continue;
+      const float x = w[i], y = w[i | h];
+      w[i] = x + y;
+      w[i | h] = x - y;
+    }
+  }
+  static_for<kMaskMultiObs>([&](auto k) {
+    if ((int)k < n_obs) {  // (wave-uniform)
+      const float sel = pick16(w, (uint32_t)ol[(int)k] >> (T - 4));
+      const uint32_t flip = (uint32_t)(__builtin_popcount(tile & oo[(int)k]) & 1) << 31;
+      acc[k] += __uint_as_float(__float_as_uint(sel) ^ flip);
+    }
+  });
+}
+// one row [QMLE_MAX_QUBITS + 1] per workgroup: column k = observable k (like the one-tile epilogue's rows)
+__device__ __forceinline__ void tile_m_finish(float *out, float *red, const float (&acc)[kMaskMultiObs], int n_obs,
+                                              const uint16_t QMLE_CONSTANT *ol, int T, int tid, int nt, uint32_t row,
+                                              uint32_t n_rows, int b) {
+  const int lane = tid & (kWave - 1), wv = tid / kWave, nw = (nt + kWave - 1) / kWave;
+  __syncthreads();  // every amplitude of the last tile has been read: the tile buffer is scratch
+  static_for<kMaskMultiObs / 8>([&](auto r8) {
+    if (8 * (int)r8 < n_obs) {
+      float v[8];
+      static_for<8>([&](auto k) {
+        constexpr int kk = 8 * (int)r8 + (int)k;
+        const uint32_t ml = kk < n_obs ? ((uint32_t)ol[kk] & 63u) : 0u;
+        v[k] = (__popc((uint32_t)lane & ml) & 1) ? -acc[kk] : acc[kk];
+      });
+      wave_sums_dpp63(v);
+      if (lane == kWave - 1) static_for<8>([&](auto k) { red[(8 * (int)r8 + (int)k) * nw + wv] = v[k]; });
+    }
+  });
+  __syncthreads();
+  if (tid < n_obs) {
+    const uint32_t mw = ((uint32_t)ol[tid] >> 6) & ((1u << (T - 10)) - 1u);
+    float r = 0.f;
+    for (int v = 0; v < nw; ++v) {
+      const float c = red[tid * nw + v];
+      r += (__popc((uint32_t)v & mw) & 1) ? -c : c;
+    }
+    out[((size_t)b * n_rows + row) * (QMLE_MAX_QUBITS + 1) + tid] = r;
+  }
+}
+
 // TM_EXPVAL of k_tile2's whole-state tile (T == n >= 10: the tile index IS the amplitude index).
 // Every work item squares its 16 amplitudes once, in the load stage's layout: slot 2u + e has
 // index bit 0 = e and bits T-3.. = u, the lane holds bits 1..6, the wave index bits 7..T-4.  The
@@ -642,8 +724,9 @@ __device__ __forceinline__ void whole_state_expval(const TileArgs &a, uint32_t s
 // MW (with MEASURE, without MULTI): a.meas is TM_STORE_MW / TM_MW_ONLY -- the tile's Meyer-Wallach
 // row (tile_mw_row) behind the store; its own instantiations, so that the 40 sums it keeps per work item
 // do not enter the register budget of the others.
-template <bool NT, bool MEASURE, bool MULTI, bool WS = false, bool MW = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k_tile2(const TileArgs a, const Tile2Args f) {
+// MASKS (with MEASURE and MULTI): a.meas is TM_EXPVAL_MASKS, <= kMaskMultiObs observables (tile_m_accumulate / _finish).
+template <bool NT, bool MEASURE, bool MULTI, bool WS = false, bool MW = false, bool MASKS = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MASKS ? 4 : 5))) k_tile2(const TileArgs a, const Tile2Args f) {
   extern __shared__ float4 smem4[];
   float2 *s = reinterpret_cast<float2 *>(smem4);
   const int T = a.T;
@@ -767,6 +850,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   if (plain) load_tile(st);
   const uint32_t sl_outer = sl;
   float zacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // MEASURE && MULTI: tile_z_accumulate
+  float pacc[MASKS ? kMaskMultiObs : 1];                      // MASKS: tile_m_accumulate
+  if (MASKS) static_for<kMaskMultiObs>([&](auto k) { pacc[MASKS ? (int)k : 0] = 0.f; });
+  const uint16_t QMLE_CONSTANT *m_ol =
+      (const uint16_t QMLE_CONSTANT *)((const char QMLE_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs, obs_local));
+  const uint32_t QMLE_CONSTANT *m_oo =
+      (const uint32_t QMLE_CONSTANT *)((const char QMLE_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs, obs_outer));
   MwAcc macc;                                                 // MW: tile_mw_accumulate
   if (MW) tile_mw_clear(macc);
   for (int i = 0; i < tpw; ++i) {
@@ -825,6 +914,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
         }
       }
       tile_mw_accumulate(sbo, T, (uint32_t)tid, (uint32_t)i, macc, a.mw_lean != 0);
+    } else if (MEASURE && MULTI && MASKS) {  // (TM_EXPVAL_MASKS: launch_tile)
+      if constexpr (MASKS) tile_m_accumulate(sbo, T, tid, tile + (uint32_t)i, a.n_obs, m_ol, m_oo, pacc);
     } else if (MEASURE && MULTI) {  // (TM_EXPVAL_PARTIAL only: launch_tile)
       if (!(f.dbg & 2)) tile_z_accumulate(sbo, T, tid, i, zacc);
     } else if (MEASURE) {
@@ -863,7 +954,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) k
   if (MW)  // one row per workgroup (= per tile: launch_tile keeps these stages at one tile per workgroup)
     tile_mw_finish(macc, T, (uint32_t)tid, reinterpret_cast<float *>(s),
                    reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + blockIdx.x) * kMwFusedRow, a.mw_lean != 0);
-  else if (MEASURE && MULTI && !(f.dbg & 2))
+  else if (MEASURE && MULTI && MASKS) {
+    if constexpr (MASKS)
+      tile_m_finish(reinterpret_cast<float *>(a.out), red, pacc, a.n_obs, m_ol, T, tid, nt, blockIdx.x, gridDim.x, b);
+  } else if (MEASURE && MULTI && !(f.dbg & 2))
     tile_z_finish(reinterpret_cast<float *>(a.out), red, zacc, qsrc, tid, nt, 31 - __builtin_clz((unsigned)tpw),
                   blockIdx.x, gridDim.x, b);
 }
@@ -1744,6 +1838,12 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
       QMLE_T2_LDS(false, false, true); QMLE_T2_LDS(true, false, true);
       QMLE_T2_LDS(false, true, true); QMLE_T2_LDS(true, true, true);
 #undef QMLE_T2_LDS
+      QMLE_LDS_BASE_CHECK((k_tile2<true, true, true, false, false, true>));
+      QMLE_LDS_BASE_CHECK((k_tile2<false, true, true, false, false, true>));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<true, true, true, false, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void *)k_tile2<false, true, true, false, false, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       QMLE_LDS_BASE_CHECK((k_tile2<false, false, false, true>));
       QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, true>));
       QMLE_LDS_BASE_CHECK((k_tile2<false, true, false, false, true>));
@@ -1813,14 +1913,17 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     // (Meyer-Wallach rows keep one tile per workgroup: a walk of 4-16 tiles that carries the ~40 sums in
     // registers and reduces once was built and measured at n = 28 -- 128 VGPRs + 64 B of scratch, no room
     // for the next tile's prefetch: 792 us for the pass against 678 with a row per tile, 473 without sums)
-    const int tpw_max = tpw_env > 0 ? tpw_env : meas == TM_EXPVAL_PARTIAL ? 8 : 4;
+    const int tpw_max = tpw_env > 0 ? tpw_env : (meas == TM_EXPVAL_PARTIAL || meas == TM_EXPVAL_MASKS) ? 8 : 4;
     const uint64_t min_wgs = 5120;
     f.tpw = 1;
     f.tile_stride = 0;
     // (known zeros inside the tile are fine -- the walk's loads skip them; known-zero TILES are not)
     const bool multi_zin = std::getenv("QMLE_NO_MULTI_ZIN") == nullptr;  // (read per launch: the A/B test toggles it)
+    // (Z-parity observables walk too -- tile_m_accumulate -- when the caller can take rows per walk; QMLE_NO_MASKS_MULTI=1: A/B)
+    static const bool no_masks_multi = std::getenv("QMLE_NO_MASKS_MULTI") != nullptr;
+    const bool masks_walk = meas == TM_EXPVAL_MASKS && n_obs <= kMaskMultiObs && row_shift && st.T >= 10 && !no_masks_multi;
     if (!a.init_zero && (!a.zin_local || multi_zin) && !a.zin_outer && !a.compact && st.T < p->n &&
-        (meas == TM_STORE || meas == TM_PROBS || meas == TM_EXPVAL_PARTIAL)) {
+        (meas == TM_STORE || meas == TM_PROBS || meas == TM_EXPVAL_PARTIAL || masks_walk)) {
       // (consecutive tile indices differ in the lowest run of outer bit positions only)
       int run0 = 1;
       while (run0 < p->n - st.T && st.outer_bits[run0] == st.outer_bits[0] + run0) ++run0;
@@ -1831,7 +1934,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
         grid.x /= 2u;
       }
     }
-    if (meas == TM_EXPVAL_PARTIAL && f.tpw > 1) {
+    if ((meas == TM_EXPVAL_PARTIAL || meas == TM_EXPVAL_MASKS) && f.tpw > 1) {
       if (!row_shift || f.tpw > 8) {  // the caller must know the row layout
         grid.x *= (unsigned)f.tpw;
         f.tpw = 1;
@@ -1864,6 +1967,9 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     } else if (st.T == p->n && !multi && !a.nt && !no_ws) {  // the whole state in one tile (10..13 qubits)
       if (measure) hipLaunchKernelGGL((k_tile2<false, true, false, true>), grid, dim3(threads), lds2, stream, a, f);
       else hipLaunchKernelGGL((k_tile2<false, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
+    } else if (measure && multi && meas == TM_EXPVAL_MASKS) {
+      if (a.nt) hipLaunchKernelGGL((k_tile2<true, true, true, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
+      else hipLaunchKernelGGL((k_tile2<false, true, true, false, false, true>), grid, dim3(threads), lds2, stream, a, f);
     } else if (measure) {
       if (multi) { if (a.nt) QMLE_T2_GO(true, true, true); else QMLE_T2_GO(false, true, true); }
       else { if (a.nt) QMLE_T2_GO(true, true, false); else QMLE_T2_GO(false, true, false); }

@@ -188,6 +188,7 @@ struct TileArgs {
   int8_t outer_bits[QMLE_MAX_QUBITS];
   uint32_t obs_mask[QMLE_MAX_QUBITS];  // per observable: bit p set <=> Z on bit position p
   uint16_t obs_local[QMLE_MAX_QUBITS]; // the same restricted to the tile, in LOCAL bits (bit j <=> Z on tile_bits[j])
+  uint32_t obs_outer[QMLE_MAX_QUBITS]; // ... and to the outer positions, in TILE-INDEX bits (bit i <=> Z on outer_bits[i])
   // TM_EXPVAL_PARTIAL, full-size tiles: where thread q finds <Z> of global bit position q among the
   // per-wave sums: 0..5 lane bit, 6..9 iteration bit, 10 total (q = 32), 16 + k wave-index bit k,
   // 32 + i outer position i (sign = tile-index bit i), 64 unused
@@ -800,6 +801,9 @@ static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *stat
       uint32_t lm = 0;
       for (int j = 0; j < st.T && j < 16; ++j) lm |= ((obs_masks[k] >> st.tile_bits[j]) & 1u) << j;
       a.obs_local[k] = (uint16_t)lm;
+      uint32_t om = 0;
+      for (int i = 0; i < p->n - st.T && i < 32; ++i) om |= ((obs_masks[k] >> st.outer_bits[i]) & 1u) << i;
+      a.obs_outer[k] = om;
     }
   }
   a.op_begin = st.op_begin;
