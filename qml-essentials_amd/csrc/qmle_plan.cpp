@@ -92,6 +92,8 @@ double algo_bytes(const qmle_op &op, int n) {
   }
 }
 
+constexpr bool kSmallLastTileDefault = false;
+
 // Partition the ops of one tile stage into register-tile groups (<= 4 tile-local bits
 // per group, dependency order preserved: an op may only move ahead of ops it shares no
 // bit with).  Rewrites dev_ops[st.op_begin, st.op_end) into group order.
@@ -875,7 +877,16 @@ int compile_plan(qmle_plan *p) {
           if (pad_high_env >= 2 && popc(Q) < T) Q |= bit(pad_high_env);  // (one chosen low position)
           for (int b = n - 1; b >= 0 && popc(Q) < T; --b) Q |= bit(b);
         }
-        for (int b = 0; b < n && popc(Q) < T; ++b) Q |= bit(b);
+        // The LAST stage of a 2^13-tile schedule whose gates need <= 12 positions takes a 2^12 tile: five 32 KiB
+        // workgroups per CU overlap their loads and their groups where two 64 KiB ones do not (the measuring pass
+        // of the 4-layer n = 24 model: experiment QMLE_SMALL_LAST_TILE)
+        int Tpad = T;
+        {
+          const char *e = std::getenv("QMLE_SMALL_LAST_TILE");
+          const bool on = e ? atoi(e) != 0 : kSmallLastTileDefault;
+          if (on && T == 13 && !p->stages.empty() && n_done + members.size() == nl && popc(Q) <= 12 && !no_fusion) Tpad = 12;
+        }
+        for (int b = 0; b < n && popc(Q) < Tpad; ++b) Q |= bit(b);
         st.T = popc(Q);
         int nt = 0, no = 0;
         int8_t local_of[64];
