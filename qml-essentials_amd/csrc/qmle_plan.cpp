@@ -92,7 +92,7 @@ double algo_bytes(const qmle_op &op, int n) {
   }
 }
 
-constexpr bool kSmallLastTileDefault = false;
+constexpr bool kSmallLastTileDefault = true;  // (measured: profiles/r05_small_last_tile_ab.txt)
 
 // Partition the ops of one tile stage into register-tile groups (<= 4 tile-local bits
 // per group, dependency order preserved: an op may only move ahead of ops it shares no
