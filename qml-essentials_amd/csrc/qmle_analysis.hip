@@ -981,50 +981,66 @@ struct MwColsumArgs {
   int slices;
   double *out[9];         // [batch][slices][n_cols + n_signed]
 };
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 k_mw_colsum(const MwColsumArgs a) {
+  // thread = (column, one of four row lanes); eight rows in flight per thread -- with one load per iteration the
+  // sweep was bound by the latency of 256 dependent round trips (0.13 ms at n = 28), with one row lane by 32
+  __shared__ double part[4][64];
   const int m = blockIdx.z, b = blockIdx.y, sl = blockIdx.x, t = threadIdx.x;
+  const int c = t & 63, lane = t >> 6;
   const int nc = a.n_cols[m], ns = m == 0 ? a.n_signed : 0;
-  if (t >= nc + ns) return;
   const uint32_t per = (a.n_rows[m] + a.slices - 1) / a.slices;
   const uint32_t lo = sl * per, hi = lo + per < a.n_rows[m] ? lo + per : a.n_rows[m];
   const float *base = a.rows[m] + (size_t)b * a.n_rows[m] * a.stride[m];
-  // eight rows in flight per thread (one load per iteration left the sweep bound by the latency of 256 dependent
-  // round trips: 0.13 ms at n = 28)
-  const bool signedc = t >= nc;
-  const int k = signedc ? t - nc : 0;
-  const uint32_t cidx = signedc ? (uint32_t)a.tot_col : (uint32_t)t, stride = a.stride[m];
-  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t i = lo;
-  for (; i + 8 <= hi; i += 8) {
-    float v[8];
+  double sum = 0.0;
+  if (c < nc + ns) {
+    const bool signedc = c >= nc;
+    const int k = signedc ? c - nc : 0;
+    const uint32_t cidx = signedc ? (uint32_t)a.tot_col : (uint32_t)c, stride = a.stride[m];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t i = lo + (uint32_t)lane;
+    for (; i + 28 < hi; i += 32) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(i + u) * stride + cidx];
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(i + 4 * u) * stride + cidx];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += (signedc && (((i + u) >> k) & 1u)) ? -(double)v[u] : (double)v[u];
+      for (int u = 0; u < 8; ++u) acc[u] += (signedc && (((i + 4 * u) >> k) & 1u)) ? -(double)v[u] : (double)v[u];
+    }
+    for (; i < hi; i += 4) {
+      const double v = (double)base[(size_t)i * stride + cidx];
+      acc[0] += (signedc && ((i >> k) & 1u)) ? -v : v;
+    }
+    sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
-  for (; i < hi; ++i) {
-    const double v = (double)base[(size_t)i * stride + cidx];
-    acc[0] += (signedc && ((i >> k) & 1u)) ? -v : v;
-  }
-  a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + t] =
-      ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  part[lane][c] = sum;
+  __syncthreads();
+  if (lane == 0 && c < nc + ns)
+    a.out[m][((size_t)b * a.slices + sl) * (nc + ns) + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
-// one block per state: the slices of every matrix are summed by all 1024 threads (thread = column x one of 8
-// slice lanes: coalesced, 32 independent loads each at 256 slices), then thread p = bit position turns the sums
-// into its purity and a wave sum into Q.  (A first form with one thread per position walking the slices itself
-// was latency-bound: 1800 dependent loads, 0.43 ms.)
+// one block per state: the slices of EVERY matrix are summed at once by all 1024 threads (thread = one of the <= 128
+// columns of all matrices side by side x one of 8 slice lanes: coalesced, four loads in flight), then thread p = bit
+// position turns the sums into its purity and a wave sum into Q.  (A first form with one thread per position walking
+// the slices itself was latency-bound: 1800 dependent loads, 0.43 ms.)
 constexpr int kMwColsMax = 128;
 __global__ void __launch_bounds__(1024)
 k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, int n_mats, float *__restrict__ out /* [batch][n + 1] */) {
   __shared__ double lane_sum[8][kMwColsMax];
-  __shared__ double fin[9][kMwColsMax];
+  __shared__ double fin[kMwColsMax];
+  __shared__ int off[10];
   const int b = blockIdx.x, t = threadIdx.x, col = t & (kMwColsMax - 1), q = t / kMwColsMax;
-  for (int m = 0; m < n_mats; ++m) {
-    const int w = c.n_cols[m] + (m == 0 ? c.n_signed : 0);
+  if (t == 0) {
+    int o = 0;
+    for (int m = 0; m < n_mats; ++m) { off[m] = o; o += c.n_cols[m] + (m == 0 ? c.n_signed : 0); }
+    off[n_mats] = o;
+  }
+  __syncthreads();
+  {
+    int m = 0;
+    while (m + 1 < n_mats && col >= off[m + 1]) ++m;
     double acc = 0.0;
-    if (col < w) {
-      const double *o = c.out[m] + (size_t)b * c.slices * w + col;
+    if (col < off[n_mats]) {
+      const int w = off[m + 1] - off[m];
+      const double *o = c.out[m] + (size_t)b * c.slices * w + (col - off[m]);
       double a4[4] = {0, 0, 0, 0};
       int sl = q;
       for (; sl + 24 < c.slices; sl += 32) {  // four independent loads per round
@@ -1035,31 +1051,31 @@ k_mw_finish_cols(const MwFusedArgs a, const MwColsumArgs c, int n_mats, float *_
       acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     lane_sum[q][col] = acc;
-    __syncthreads();
-    if (q == 0 && col < w) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s += lane_sum[k][col];
-      fin[m][col] = s;
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  if (q == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += lane_sum[k][col];
+    fin[col] = s;
+  }
+  __syncthreads();
   const int p = t, T = a.T, n = a.n, lg = a.lg;
   if (t >= kWave) return;
   double pur = 0.0;
   if (p < n) {
     const int j = a.loc[p], oi = a.outer_idx[p];
-    const double tot = fin[0][3 * T];
+    const double tot = fin[3 * T];
     double cr = 0.0, ci = 0.0, z;
     if (j >= 0) {
-      z = fin[0][2 * T + j];
-      if (!(a.lean && p < 4)) { cr = fin[0][2 * j]; ci = fin[0][2 * j + 1]; }
-    } else if (oi < lg) z = fin[0][3 * T + 1 + oi];
-    else z = fin[0][c.n_cols[0] + (oi - lg)];
+      z = fin[2 * T + j];
+      if (!(a.lean && p < 4)) { cr = fin[2 * j]; ci = fin[2 * j + 1]; }
+    } else if (oi < lg) z = fin[3 * T + 1 + oi];
+    else z = fin[c.n_cols[0] + (oi - lg)];
     if (j < 0 || (a.lean && p < 4)) {
       const int r = a.src_read[p], cc = a.src_col[p];
-      cr += fin[1 + r][2 * cc];
-      ci += fin[1 + r][2 * cc + 1];
+      cr += fin[off[1 + r] + 2 * cc];
+      ci += fin[off[1 + r] + 2 * cc + 1];
     }
     const double pa = 0.5 * (tot + z), pd = 0.5 * (tot - z);
     pur = (double)(float)(pa * pa + pd * pd + 2.0 * (cr * cr + ci * ci));  // (rounded like k_mw_purity_fused's store)
@@ -1649,7 +1665,9 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
     return QMLE_OK;
   }
   static const bool old_purity = std::getenv("QMLE_MW_OLD_PURITY") != nullptr;  // (A/B: the per-position walk)
-  if (last.T < n && !old_purity && 3 * last.T + 5 <= kMwFusedRowA) {
+  int colsum_w0 = kMwFusedRowA + (n - last.T - pa.lg > 0 ? n - last.T - pa.lg : 0), colsum_w = colsum_w0;
+  for (int r = 0; r < 8 && pa.later[r]; ++r) colsum_w += (int)pa.later_stride[r];
+  if (last.T < n && !old_purity && 3 * last.T + 5 <= kMwFusedRowA && colsum_w0 <= 64 && colsum_w <= kMwColsMax) {
     MwColsumArgs ca;
     std::memset(&ca, 0, sizeof(ca));
     uint32_t most = pa.rows_first;
@@ -1671,8 +1689,7 @@ int run_mw_fused(const float2 *states, int n, int batch, const Stage &last, int 
       dp += (size_t)batch * slices * (ca.n_cols[m] + (m == 0 ? ca.n_signed : 0));
     }
     if ((size_t)((char *)dp - (char *)ws_) > ws_bytes) return QMLE_ERR_WORKSPACE;
-    hipLaunchKernelGGL(k_mw_colsum, dim3(slices, batch, n_mats), dim3(128), 0, stream, ca);
-    if (ca.n_cols[0] + ca.n_signed > kMwColsMax) return QMLE_ERR_INTERNAL;
+    hipLaunchKernelGGL(k_mw_colsum, dim3(slices, batch, n_mats), dim3(256), 0, stream, ca);
     hipLaunchKernelGGL(k_mw_finish_cols, dim3(batch), dim3(1024), 0, stream, pa, ca, n_mats, d_out);
     HIPCHK(hipGetLastError());
     return QMLE_OK;
