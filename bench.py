@@ -1190,6 +1190,28 @@ def main(argv=None):
             del out_uf
         except Exception as e:  # pragma: no cover
             result["k2_unfused"] = {"error": str(e)}
+        # the same all-live step after the product's opt-in plan autotuner (qmle_plan_autotune: the cost model's best
+        # schedules x the last stage's paddings timed on this device, the fastest kept -- the headline above is the
+        # model's own choice, untuned)
+        try:
+            N.set_autotune(True)
+            try:
+                tn = timed_k2(n, B, size, 5, 2, head_flags)
+            finally:
+                N.set_autotune(False)
+            ts = summarize(tn, True)
+            result["k2_autotuned"] = {
+                "ms_per_step": ts["ms_per_step"], "gate_applies_per_s": ts["gate_applies_per_s"],
+                "moved_frac_of_8TBps": ts["moved_frac_of_8TBps"], "candidate": tn["desc"].get("candidate"),
+                "autotuned": tn["desc"].get("autotuned"),
+                "per_pass": [{k: p_[k] for k in ("pass", "avg_launch_ms", "moved_GBps")} for p_ in per_pass(tn, True)],
+                "last_stage_bits": tn["desc"]["stages"][-1]["bits"],
+                "max_abs_diff_vs_headline_expvals": float((tn["out"] - head["out"]).abs().max()),
+                "note": "QMLE_AUTOTUNE / set_autotune(True): opt-in, one-off timing of the candidates on the first run of a "
+                        "plan; the headline does not use it"}
+            del tn
+        except Exception as e:  # pragma: no cover
+            result["k2_autotuned"] = {"error": repr(e)}
         # the default engine on the same workload: exact, but specific to what a one-layer circuit
         # from |0..0> leaves untouched (known zeros never read / computed / stored, trailing CX layer
         # folded into Z-parity observables) -- NOT a throughput figure for gate application
@@ -1317,6 +1339,8 @@ def summary_of(r):
     out = {"k2_headline": {"ms_per_step": r.get("ms_per_step"), "gate_applies_per_s": r.get("value"),
                            "frac": g(r, "roofline", "frac"), "kernel": g(r, "roofline", "kernel"),
                            "per_pass_ms": [p["avg_launch_ms"] for p in g(r, "roofline", "per_pass", default=[])]}}
+    if isinstance(r.get("k2_autotuned"), dict):
+        out["k2_autotuned"] = {"ms_per_step": g(r, "k2_autotuned", "ms_per_step"), "error": g(r, "k2_autotuned", "error")}
     for key in ("k2_unfused", "k2_circuit19"):
         if isinstance(r.get(key), dict):
             out[key] = {"ms_per_step": g(r, key, "ms_per_step"), "frac": g(r, key, "roofline", "frac"),
