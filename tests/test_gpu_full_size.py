@@ -423,3 +423,39 @@ def test_one_gate_passes_at_24_qubits_controls_and_targets_all_over_the_register
     assert float((torch.view_as_real(got) - torch.view_as_real(fused)).abs().max()) < 1e-6
     psi = c_port.simulate(tape, n)
     assert np.abs(got.cpu().numpy() - psi).max() < 1e-6
+
+
+def test_diagonal_controlled_passes_at_24_qubits_all_over_the_register():
+    """Round 5: CZ / CPhase run as the |11>-quarter pass (k_direct_1q mode 9) and CRZ as the diagonal controlled
+    pass; at n >= 24 both take the spread workgroup order when the control or the target sits on position 7 / 8
+    (qmle_direct.hip, blk_mul 4097) -- an order the small-register sweeps of test_gpu_kernels never reach.  One
+    gate per launch over pairs on every rule (positions 7 / 8 as control and as target, neighbours, distant
+    pairs, low controls that fall back to the tile pass), against the oracle's C port and the fused engine."""
+    N = _N()
+    from oracle import c_port
+    from tests.helpers import tape_to_native
+
+    n = 24
+    rng = np.random.default_rng(2405)
+    pos = lambda p: n - 1 - p
+    tape = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    tape += [("RX", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
+    pairs = [(7, 8), (8, 7), (7, 20), (20, 7), (8, 23), (23, 8), (7, 4), (4, 8), (8, 12), (12, 7), (22, 23),
+             (16, 17), (5, 6), (6, 5), (9, 10), (21, 4), (4, 21), (2, 8), (7, 1), (0, 23), (3, 2), (13, 19)]
+    kinds = ["CZ", "CPhase", "CRZ"]
+    for i, (pc, pt) in enumerate(pairs):
+        for j in range(3 if pc in (7, 8) or pt in (7, 8) else 1):
+            g = kinds[(i + j) % 3]
+            tape.append((g, [pos(pc), pos(pt)], () if g == "CZ" else (float(rng.uniform(0.3, 2.8)),)))
+        tape.append(("RY", [pos(pt)], (float(rng.uniform(0, 6.28)),)))
+        tape.append(("RX", [pos(pc)], (float(rng.uniform(0, 6.28)),)))
+    ops, angles, consts = tape_to_native(tape, n)
+    ang = torch.from_numpy(np.ascontiguousarray(angles[None, :], dtype=np.float32)).cuda()
+    one = N.Plan(ops, n, len(angles), consts, N.plan_flags(no_fusion=True, force_global=True))
+    kinds_run = [s["kind"] for s in one.describe()["stages"]]
+    assert kinds_run.count("direct") >= len(kinds_run) - 8, kinds_run
+    got = one.run(ang, "state")[0]
+    fused = N.Plan(ops, n, len(angles), consts).run(ang, "state")[0]
+    assert float((torch.view_as_real(got) - torch.view_as_real(fused)).abs().max()) < 1e-6
+    psi = c_port.simulate(tape, n)
+    assert np.abs(got.cpu().numpy() - psi).max() < 1e-6
