@@ -338,6 +338,10 @@ int launch_direct(const qmle_plan *p, const LoweredOp &op, float2 *states, const
     // (round 5, K1 CRZ / CZ / CPhase: the diagonal forms show the same pattern -- CRZ 0.46 ms with the control on
     // position 8, CZ 0.23-0.25 ms with control or target on 7 / 8 where their neighbours take 0.33 / 0.17)
     if (diag && n >= 24 && grid.x > 4097u && (pc == 7 || pc == 8 || (mode == 9 && (pt == 7 || pt == 8)))) blk_mul = 4097u;
+    // (the |11> quarter of a pair inside positions 16..18 -- byte-address bits 19..21, 0.5-2 MiB on, the rest of
+    // every 4 MiB off -- streams at 0.21-0.26 ms in ascending order where its neighbours take 0.17; workgroups 17
+    // blocks apart: 0.19-0.20.  Every other pair is fastest ascending: profiles/r05_k1_cz_order.txt)
+    if (mode == 9 && n >= 24 && grid.x > 4097u && pc >= 16 && pc <= 18 && pt >= 16 && pt <= 18) blk_mul = 17u;
     const char *e = std::getenv("QMLE_K1_BLOCK_MUL");
     if (e) blk_mul = atoi(e) > 0 ? ((uint32_t)atoi(e) | 1u) : 0u;
   }

@@ -441,10 +441,11 @@ def test_diagonal_controlled_passes_at_24_qubits_all_over_the_register():
     tape = [("RY", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
     tape += [("RX", [q], (float(rng.uniform(0, 6.28)),)) for q in range(n)]
     pairs = [(7, 8), (8, 7), (7, 20), (20, 7), (8, 23), (23, 8), (7, 4), (4, 8), (8, 12), (12, 7), (22, 23),
-             (16, 17), (5, 6), (6, 5), (9, 10), (21, 4), (4, 21), (2, 8), (7, 1), (0, 23), (3, 2), (13, 19)]
+             (16, 17), (5, 6), (6, 5), (9, 10), (21, 4), (4, 21), (2, 8), (7, 1), (0, 23), (3, 2), (13, 19),
+             (17, 18), (18, 16), (16, 18)]  # (pairs inside 16..18: workgroups 17 blocks apart)
     kinds = ["CZ", "CPhase", "CRZ"]
     for i, (pc, pt) in enumerate(pairs):
-        for j in range(3 if pc in (7, 8) or pt in (7, 8) else 1):
+        for j in range(3 if pc in (7, 8) or pt in (7, 8) or (16 <= pc <= 18 and 16 <= pt <= 18) else 1):
             g = kinds[(i + j) % 3]
             tape.append((g, [pos(pc), pos(pt)], () if g == "CZ" else (float(rng.uniform(0.3, 2.8)),)))
         tape.append(("RY", [pos(pt)], (float(rng.uniform(0, 6.28)),)))

@@ -13,13 +13,14 @@ wires = [int(x) for x in sys.argv[1:]] or [14, 16, 17, 18, 19, 20]
 st = torch.randn((1, 1 << n, 2), device="cuda", dtype=torch.float32)
 st = torch.view_as_complex(st / st.norm()).contiguous()
 ang = torch.zeros((1, 1), device="cuda")
-muls = [int(m) for m in os.environ.get("K1_MULS", "0,3,17,257,4097,65537,9973,40503").split(",")]
+muls = [m if m == "lib" else int(m) for m in os.environ.get("K1_MULS", "0,3,17,257,4097,65537,9973,40503").split(",")]  # "lib": the library's own rule
 print("target wire:", " ".join(f"{w:7d}" for w in wires))
 for mul in muls:
-    os.environ["QMLE_K1_BLOCK_MUL"] = str(mul)  # (0 = ascending order, also where the library would pick 4097)
+    if mul == "lib": os.environ.pop("QMLE_K1_BLOCK_MUL", None)
+    else: os.environ["QMLE_K1_BLOCK_MUL"] = str(mul)  # (0 = ascending order, also where the library would pick 4097)
     row = []
     for w in wires:
-        plan = N.Plan([(os.environ.get("K1_GATE", "CX"), [(w + int(os.environ.get("K1_CTRL_DELTA", "1"))) % n, w], [], -1)], n, 1, flags=N.PLAN_NO_FUSION)
+        plan = N.Plan([(os.environ.get("K1_GATE", "CX"), [(w + int(os.environ.get("K1_CTRL_DELTA", "1"))) % n, w], [] if os.environ.get("K1_GATE", "CX") in ("CX", "CY", "CZ") else [0], -1)], n, 1, flags=N.PLAN_NO_FUSION)
         ws = torch.empty(plan.workspace_bytes(1, "state"), dtype=torch.uint8, device="cuda")
         for _ in range(8):
             N.apply_inplace(plan, ang, st, ws)
@@ -30,4 +31,4 @@ for mul in muls:
         e1.record()
         torch.cuda.synchronize()
         row.append(e0.elapsed_time(e1) / 24)
-    print(f"mul {mul:6d}:", " ".join(f"{t:7.4f}" for t in row), " ms per launch (8 D bytes = %.3f GB)" % (8 * (1 << n) / 1e9), flush=True)
+    print(f"mul {str(mul):>6s}:", " ".join(f"{t:7.4f}" for t in row), " ms per launch (8 D bytes = %.3f GB)" % (8 * (1 << n) / 1e9), flush=True)
