@@ -519,7 +519,7 @@ int qmle_adjoint_gradient(qmle_plan *fwd, qmle_plan *rev, const float *d_angles_
       once.done();
     }
     bool has_dense4 = false;
-    for (int g = fst.grp_begin; g < fst.grp_end; ++g) has_dense4 |= fwd->op_groups[g].kind == GK_DENSE4;
+    for (int g = fst.grp_begin; g < fst.grp_end; ++g) has_dense4 |= fwd->op_groups[g].kind == GK_DENSE4 || fwd->op_groups[g].kind == GK_REG4X;
     // all loops are strided, so the sweeps may use more threads than the 2^(n-4) register-tile
     // work items of the forward groups: one 64-lane wave per 256 amplitudes, at least 4 waves
     int threads = tile_threads(n);

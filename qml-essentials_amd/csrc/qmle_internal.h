@@ -30,7 +30,10 @@ enum LFlag : uint8_t {
 enum GKind : uint8_t {
   GK_SWEEP = 0,   // one op, LDS sweep
   GK_REG4 = 1,    // run of (controlled) 2x2 ops on <= 4 bits, in registers
-  GK_DENSE4 = 2   // one LK_4Q op: gather over its 4 bits, 16x16 matrix-vector product
+  GK_DENSE4 = 2,  // one LK_4Q op: gather over its 4 bits, 16x16 matrix-vector product
+  GK_REG4X = 3    // a GK_REG4 run that also holds uncontrolled LK_2Q ops (dense 4x4 on two of the group's bits:
+                  // the 1-wire Kraus superoperators of vec(rho), RXX ...); t0 / t1 are GROUP-local too.  Only the
+                  // DENSE4 instantiations of the tile kernels run it (the common ones keep their register budget)
 };
 struct OpGroup {
   uint8_t kind;
@@ -60,7 +63,7 @@ static_assert(sizeof(LoweredOp) == 16, "LoweredOp layout");
 // One source gate feeding the per-sample matrix builder (24 bytes).
 struct BuildOp {
   uint16_t opcode;
-  uint16_t pad;
+  uint16_t pad;       // inside a dim-4 group: 0 = a 4x4 source, 1 / 2 = a 2x2 source on the pair's first / second wire
   int32_t slot[3];
   int32_t const_off;
   uint32_t pad2;

@@ -227,9 +227,23 @@ __device__ __forceinline__ void build_matrices_body(const BuildOp *__restrict__ 
     return;
   }
   cd M[16], S[16], R[16];
-  source_matrix(build[grp.begin], ang, consts, M, dim);
+  // (BuildOp::pad = 1 / 2: a 2x2 source on the first / second wire of the pair, U (x) I / I (x) U -- row = 2 * bit[t0] + bit[t1])
+  auto source4 = [&](const BuildOp &bo, cd *X) {
+    if (dim != 4 || bo.pad == 0) {
+      source_matrix(bo, ang, consts, X, dim);
+      return;
+    }
+    const M2 U = source_2x2(bo, ang, consts);
+    for (int i = 0; i < 16; ++i) X[i] = {0.0, 0.0};
+    if (bo.pad == 1) {
+      X[0] = U.a; X[2] = U.b; X[5] = U.a; X[7] = U.b; X[8] = U.c; X[10] = U.d; X[13] = U.c; X[15] = U.d;
+    } else {
+      X[0] = U.a; X[1] = U.b; X[4] = U.c; X[5] = U.d; X[10] = U.a; X[11] = U.b; X[14] = U.c; X[15] = U.d;
+    }
+  };
+  source4(build[grp.begin], M);
   for (uint32_t k = grp.begin + 1; k < grp.end; ++k) {
-    source_matrix(build[k], ang, consts, S, dim);
+    source4(build[k], S);
     for (int r = 0; r < dim; ++r)
       for (int c = 0; c < dim; ++c) {
         cd acc = {0, 0};

@@ -107,7 +107,14 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
   out.reserve(nops);
   std::vector<char> done(nops, 0);
   const bool regs_ok = st.T >= 4 && !(p->flags & QMLE_PLAN_NO_REGTILE);
-  auto groupable = [&](const LoweredOp &o) { return regs_ok && o.kind == LK_1Q && o.nc <= 1; };
+  // (round 5: an uncontrolled dense 4x4 joins a register-tile run as well -- the noisy model's superoperators sit
+  // between every pair of gates and cost an LDS sweep each otherwise; QMLE_NO_REG2Q=1: A/B.  Plans that keep every
+  // gate its own operator (QMLE_PLAN_NO_MERGE: the adjoint sweep's, whose tile kernel knows GK_REG4 only) do not)
+  static const bool no_reg2q = std::getenv("QMLE_NO_REG2Q") != nullptr;
+  const bool reg2q = regs_ok && !no_reg2q && !(p->flags & QMLE_PLAN_NO_MERGE);
+  auto groupable = [&](const LoweredOp &o) {
+    return regs_ok && ((o.kind == LK_1Q && o.nc <= 1) || (reg2q && o.kind == LK_2Q && o.nc == 0));
+  };
   auto mask_of = [&](const LoweredOp &o) -> uint32_t {
     if (o.kind == LK_DIAG_ALL) return st.T >= 32 ? ~0u : ((1u << st.T) - 1u);
     uint32_t m = 1u << o.t0;
@@ -195,6 +202,10 @@ static void group_stage_ops(qmle_plan *p, Stage &st) {
     for (int i : mem) {
       LoweredOp o = src[i];
       o.t0 = local_of[(int)o.t0];
+      if (o.kind == LK_2Q) {
+        o.t1 = local_of[(int)o.t1];
+        g.kind = GK_REG4X;
+      }
       if (o.c0 >= 0) o.c0 = local_of[(int)o.c0];
       out.push_back(o);
       out_id.push_back(src_id[i]);
@@ -527,6 +538,8 @@ uint32_t pull_back_z(const std::vector<qmle_op> &absorbed, int wire) {
   return m;
 }
 
+constexpr uint8_t kLoweredDead = 255;  // LoweredOp::kind of an operator merged away during lowering
+
 int compile_plan(qmle_plan *p) {
   const int n = p->n;
   if (n < 1 || n > QMLE_MAX_QUBITS) return QMLE_ERR_INVALID_ARG;
@@ -652,22 +665,89 @@ int compile_plan(qmle_plan *p) {
       }
     }
 
+    // Round 5: the same holds around an uncontrolled dense 4x4 (the Kraus superoperators of vec(rho) on [w, n + w],
+    // two-qubit Pauli rotations): a 1-q gate on one of its wires multiplies onto it as U (x) I / I (x) U
+    // (BuildOp::pad = 1 / 2), a 4x4 on the same ordered pair as a plain product, and a new 4x4 takes the
+    // pending 1-q matrices of its two wires with it.  A noisy model's gate-channel-gate-channel run on one wire
+    // (U (x) conj U, superoperator, ...) becomes ONE 4x4 per sample.  QMLE_NO_MERGE_2Q=1: A/B.
+    static const bool no_merge_2q = std::getenv("QMLE_NO_MERGE_2Q") != nullptr;
+    const bool merge_2q = fuse && !(p->flags & QMLE_PLAN_NO_MERGE) && !no_merge_2q;
+    if (merge_2q && lo.kind == LK_1Q && lo.nc == 0) {
+      const int prev = last_touch[lo.t0];
+      if (prev >= 0) {
+        LoweredOp &pl = p->lowered[prev];
+        if (pl.kind == LK_2Q && pl.nc == 0 && (pl.t0 == lo.t0 || pl.t1 == lo.t0)) {
+          bo.pad = pl.t0 == lo.t0 ? 1 : 2;
+          group_ops[group_of[prev]].push_back(bo);
+          if (!(lo.flags & LF_DIAG)) pl.flags &= ~LF_DIAG;
+          p->lowered_src[prev].push_back((int)i);
+          continue;
+        }
+      }
+    }
+    std::vector<BuildOp> taken;      // pending 1-q matrices a new 4x4 absorbs (they act first)
+    std::vector<int> taken_src;
+    if (merge_2q && lo.kind == LK_2Q && lo.nc == 0) {
+      const int pa = last_touch[lo.t0], pb = last_touch[lo.t1];
+      if (pa >= 0 && pa == pb) {
+        LoweredOp &pl = p->lowered[pa];
+        if (pl.kind == LK_2Q && pl.nc == 0 && pl.t0 == lo.t0 && pl.t1 == lo.t1) {
+          group_ops[group_of[pa]].push_back(bo);
+          if (!(lo.flags & LF_DIAG)) pl.flags &= ~LF_DIAG;
+          p->lowered_src[pa].push_back((int)i);
+          continue;
+        }
+      }
+      for (int side = 0; side < 2; ++side) {
+        const int t = side == 0 ? lo.t0 : lo.t1;
+        const int prev = last_touch[t];
+        if (prev < 0) continue;
+        LoweredOp &pl = p->lowered[prev];
+        if (!(pl.kind == LK_1Q && pl.nc == 0 && pl.t0 == t)) continue;
+        for (BuildOp b1 : group_ops[group_of[prev]]) {
+          b1.pad = (uint16_t)(side + 1);
+          taken.push_back(b1);
+        }
+        if (!(pl.flags & LF_DIAG)) lo.flags &= ~LF_DIAG;
+        for (int s_ : p->lowered_src[prev]) taken_src.push_back(s_);
+        group_ops[group_of[prev]].clear();  // (its matrix slot stays allocated, nothing builds or reads it)
+        pl.kind = kLoweredDead;             // removed below
+      }
+    }
+
     const uint32_t dim = lo.kind == LK_2Q ? 4u : 2u;
     lo.mat_off = p->mat_floats;
     p->mat_floats += dim * dim * 2;
     const int idx = (int)p->lowered.size();
     group_of.resize(idx + 1, -1);
     group_of[idx] = (int)group_ops.size();
-    group_ops.push_back({bo});
+    taken.push_back(bo);
+    group_ops.push_back(taken);
     group_meta.push_back({lo.mat_off, dim});
     const uint64_t m = op_mask(lo, n);
     for (int b = 0; b < n; ++b)
       if (m & bit(b)) last_touch[b] = idx;
     p->lowered.push_back(lo);
-    p->lowered_src.push_back({(int)i});
+    taken_src.push_back((int)i);
+    std::sort(taken_src.begin(), taken_src.end());
+    p->lowered_src.push_back(taken_src);
+  }
+  {  // drop the 1-q operators a 4x4 absorbed
+    size_t w = 0;
+    for (size_t r = 0; r < p->lowered.size(); ++r) {
+      if (p->lowered[r].kind == kLoweredDead) continue;
+      if (w != r) {
+        p->lowered[w] = p->lowered[r];
+        p->lowered_src[w] = std::move(p->lowered_src[r]);
+      }
+      ++w;
+    }
+    p->lowered.resize(w);
+    p->lowered_src.resize(w);
   }
   // flatten the per-matrix source lists (tape order inside each group)
   for (size_t g = 0; g < group_ops.size(); ++g) {
+    if (group_ops[g].empty()) continue;
     BuildGroup bg{(uint32_t)p->build_ops.size(), 0, group_meta[g].first, group_meta[g].second};
     for (const BuildOp &b : group_ops[g]) p->build_ops.push_back(b);
     bg.end = (uint32_t)p->build_ops.size();

@@ -1695,7 +1695,7 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
   }
   bool has_dense4 = false;  // 16x16 Kraus superoperators: separate instantiation, so that the
                             // common kernel keeps its register budget
-  for (int g = st.grp_begin; g < st.grp_end; ++g) has_dense4 |= p->op_groups[g].kind == GK_DENSE4;
+  for (int g = st.grp_begin; g < st.grp_end; ++g) has_dense4 |= p->op_groups[g].kind == GK_DENSE4 || p->op_groups[g].kind == GK_REG4X;
   const unsigned tiles = 1u << (p->n - st.T);
   // Prefetching variant: tiles are loaded (not generated), the geometry is the standard one
   // (2^(T-4) threads, 8 DMAs per wave) and every workgroup gets a run of >= 4 tiles.

@@ -78,6 +78,52 @@ __device__ __forceinline__ void reg_dispatch(float2 (&a)[16], const Mat2 &m, int
   }
 }
 
+// Dense 4x4 on group bits (T0, T1) of the register tile, row = 2 * bit[T0] + bit[T1] (lds_apply's LK_2Q rule):
+// four 4-vectors per work item.  The matrix comes straight from the sample's matrix row (wave-uniform address).
+template <int T0, int T1>
+__device__ __forceinline__ void reg_2q(float2 (&a)[16], const float *__restrict__ mm) {
+  float2 M[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M[i] = make_float2(mm[2 * i], mm[2 * i + 1]);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c & ((1 << T0) | (1 << T1))) continue;
+    const float2 a0 = a[c], a1 = a[c | (1 << T1)], a2 = a[c | (1 << T0)], a3 = a[c | (1 << T0) | (1 << T1)];
+    float2 r[4];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      float2 acc = cmul(M[row * 4 + 0], a0);
+      acc = cfma(M[row * 4 + 1], a1, acc);
+      acc = cfma(M[row * 4 + 2], a2, acc);
+      acc = cfma(M[row * 4 + 3], a3, acc);
+      r[row] = acc;
+    }
+    a[c] = r[0];
+    a[c | (1 << T1)] = r[1];
+    a[c | (1 << T0)] = r[2];
+    a[c | (1 << T0) | (1 << T1)] = r[3];
+  }
+  // (keeps the twelve instantiations apart: without it the optimiser sinks their identical tails out of the
+  // dispatch switch, indexes a[] with the merged case number and the register tile lands in scratch)
+  asm volatile("; reg_2q %0 %1" ::"n"(T0), "n"(T1));
+}
+__device__ __forceinline__ void reg_2q_dispatch(float2 (&a)[16], const float *__restrict__ mm, int t0, int t1) {
+  switch (t0 * 4 + t1) {
+    case 1: reg_2q<0, 1>(a, mm); break;
+    case 2: reg_2q<0, 2>(a, mm); break;
+    case 3: reg_2q<0, 3>(a, mm); break;
+    case 4: reg_2q<1, 0>(a, mm); break;
+    case 6: reg_2q<1, 2>(a, mm); break;
+    case 7: reg_2q<1, 3>(a, mm); break;
+    case 8: reg_2q<2, 0>(a, mm); break;
+    case 9: reg_2q<2, 1>(a, mm); break;
+    case 11: reg_2q<2, 3>(a, mm); break;
+    case 12: reg_2q<3, 0>(a, mm); break;
+    case 13: reg_2q<3, 1>(a, mm); break;
+    default: reg_2q<3, 2>(a, mm); break;
+  }
+}
+
 // Op descriptor + its per-sample 2x2 matrix, staged in LDS by the tile prologue so the
 // gate loop never waits on dependent scalar loads from global memory.
 struct OpSlot {
@@ -87,7 +133,8 @@ struct OpSlot {
 static_assert(sizeof(OpSlot) == 48, "OpSlot layout");
 
 // One GK_REG4 group: gather 16 amplitudes per work item, apply every op, scatter.
-template <bool SLOTS>
+// TWOQ: the run may hold uncontrolled LK_2Q ops as well (GK_REG4X).
+template <bool SLOTS, bool TWOQ = false>
 __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, const OpGroup g,
                                                 const LoweredOp *__restrict__ ops,
                                                 const float *__restrict__ mrow,
@@ -119,6 +166,14 @@ __device__ __forceinline__ void lds_apply_group(float2 *__restrict__ s, int T, c
       } else {
         op = ops[g.op_begin + k];
         m = load_mat2(mrow + op.mat_off);
+      }
+      if (TWOQ && op.kind == LK_2Q) {
+        // (the descriptor came out of LDS: tell the compiler it is wave-uniform, so that the 4x4 matrix is
+        // 32 scalar loads into SGPRs, not 32 VGPRs per lane)
+        const uint32_t moff = (uint32_t)__builtin_amdgcn_readfirstlane((int)op.mat_off);
+        const int tt = __builtin_amdgcn_readfirstlane((int)op.t0 * 4 + (int)op.t1);
+        reg_2q_dispatch(a, mrow + moff, tt >> 2, tt & 3);
+        continue;
       }
       const int cb = op.nc ? op.c0 : -1;
       if (op.flags & LF_PERMX) reg_dispatch<2>(a, m, cb, op.t0);
@@ -348,6 +403,11 @@ __device__ __forceinline__ void tile_compute(const TileArgs &a, float2 *s, const
       const uint32_t gm = (1u << g.bits[0]) | (1u << g.bits[1]) | (1u << g.bits[2]) | (1u << g.bits[3]);
       if (a.slots_in_lds) lds_apply_group<true>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
       else lds_apply_group<false>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
+      z &= ~gm;
+    } else if (DENSE4 && g.kind == GK_REG4X) {
+      const uint32_t gm = (1u << g.bits[0]) | (1u << g.bits[1]) | (1u << g.bits[2]) | (1u << g.bits[3]);
+      if (a.slots_in_lds) lds_apply_group<true, true>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
+      else lds_apply_group<false, true>(s, T, g, a.ops, mrow, slots, a.op_begin, z & ~gm);
       z &= ~gm;
     } else if (DENSE4 && g.kind == GK_DENSE4) {
       lds_apply_dense4(s, T, g, a.consts + a.ops[g.op_begin].mat_off);

@@ -617,6 +617,9 @@ def z_parity_mask(ob: Operation) -> Optional[List[int]]:
 
 
 # ---- noise channels ---------------------------------------------------------------------------
+_SUPEROPERATORS: dict = {}  # KrausChannel.superoperator
+
+
 class KrausChannel(Operation):
     """phi(rho) = sum_k K_k rho K_k^dagger  (``operations.py:1490-1578``).
 
@@ -636,9 +639,33 @@ class KrausChannel(Operation):
         )
 
     def superoperator(self) -> np.ndarray:
-        """sum_k K_k (x) conj(K_k): row/col index = (ket bits of the wires, bra bits)."""
+        """sum_k K_k (x) conj(K_k): row/col index = (ket bits of the wires, bra bits).
+
+        A noisy model applies the same few channels after every gate (``unitary.py:150-197``): the
+        matrix of a channel given by plain numbers is computed once per (class, parameters, wire
+        count) and handed out read-only."""
+        key = self._superoperator_key()
+        if key is not None:
+            hit = _SUPEROPERATORS.get(key)
+            if hit is not None:
+                return hit
         ks = [np.asarray(k, dtype=np.complex128) for k in self.kraus_matrices()]
-        return sum(np.kron(k, np.conj(k)) for k in ks)
+        S = sum(np.kron(k, np.conj(k)) for k in ks)
+        if key is not None:
+            if len(_SUPEROPERATORS) >= 4096:
+                _SUPEROPERATORS.clear()
+            S.setflags(write=False)
+            _SUPEROPERATORS[key] = S
+        return S
+
+    def _superoperator_key(self):
+        names = self._param_names
+        if not names:
+            return None  # (QubitChannel: explicit matrices)
+        vals = tuple(getattr(self, n_) for n_ in names)
+        if not all(isinstance(v, float) for v in vals):
+            return None
+        return type(self), vals, len(self.wires)
 
     def lower(self, n_qubits: int):
         raise TypeError(

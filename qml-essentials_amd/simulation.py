@@ -91,6 +91,20 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
       a 16x16 one for 2-wire channels; 3- and 4-wire channels become a :class:`_WideChannel`.
     """
     out: list = []
+    # Channels that follow one another on the same wires -- the five or six channels a noisy model puts
+    # behind every gate (unitary.py:150-197) -- are ONE superoperator, the product of theirs: one dense
+    # operator for the engine instead of one LDS round trip each.  `pending` holds the product per wire
+    # tuple until an operation that shares a wire with it arrives (everything emitted in between acts on
+    # other wires and commutes with it).
+    pending: dict = {}
+
+    def flush(touching=None):
+        for w in [w for w in pending if touching is None or not touching.isdisjoint(w)]:
+            S = pending.pop(w)
+            blob = np.stack([S.real, S.imag], axis=-1).astype(np.float64).reshape(-1)
+            wires = list(w) + [q + n_qubits for q in w]
+            out.append(_Lowered(("MAT2" if len(w) == 1 else "MAT4", wires, [], blob)))
+
     for op_ in tape:
         if isinstance(op_, Barrier):
             continue
@@ -100,12 +114,16 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
                 raise NotImplementedError(
                     f"{op_.name}: channels on more than 4 wires are not available on the engine")
             if k > 2:
+                flush()
                 out.append(_WideChannel(op_.kraus_matrices(), op_.wires))
                 continue
+            w = tuple(op_.wires)
             S = op_.superoperator()
-            blob = np.stack([S.real, S.imag], axis=-1).astype(np.float64).reshape(-1)
-            wires = list(op_.wires) + [w + n_qubits for w in op_.wires]
-            out.append(_Lowered(("MAT2" if k == 1 else "MAT4", wires, [], blob)))
+            if w in pending:
+                pending[w] = S @ pending[w]
+            else:
+                flush(set(w))
+                pending[w] = S
             continue
         low = op_.lower(n_qubits)
         if low is None:
@@ -113,12 +131,15 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
         if low[0] == "DIAG_ALL":
             # rho_ij -> d_i conj(d_j) rho_ij (operations.py:944-961): one diagonal pass over
             # the doubled register with marks m_i - m_j
+            flush()
             m = np.asarray(low[3], dtype=np.float64)
             out.append(_Lowered(("DIAG_ALL", [], low[2],
                                  (m[:, None] - m[None, :]).reshape(-1))))
             continue
+        flush(set(low[1]))
         out.append(_Lowered(low))
         out.append(_Lowered(conj_lower(op_, n_qubits, n_qubits)))
+    flush()
     return out
 
 

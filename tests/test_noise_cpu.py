@@ -173,6 +173,42 @@ def test_doubled_tape_reproduces_oracle_density():
     assert np.isclose(np.trace(want), 1.0)
 
 
+def test_doubled_tape_multiplies_channels_that_share_their_wires():
+    """The channels a noisy model stacks behind every gate become ONE superoperator per wire tuple (their
+    product, later channel on the left), emitted before the next operation that touches one of the wires;
+    channels on other wires and gates on other wires pass in between.  Same density as the oracle's
+    channel-by-channel evolution; equal channels share one cached matrix."""
+    n = 3
+    with recording() as tape:
+        op.RX(0.3, wires=0)
+        op.BitFlip(0.1, wires=0)
+        op.PhaseFlip(0.2, wires=1)          # another wire: does not end wire 0's run
+        op.AmplitudeDamping(0.3, wires=0)
+        op.RY(0.7, wires=2)                  # a gate on another wire does not either
+        op.DepolarizingChannel(0.05, wires=0)
+        op.PhaseDamping(0.25, wires=1)
+        op.CX(wires=[0, 1])                  # ends both runs
+        UnitaryGates.NQubitDepolarizingChannel(0.2, [0, 1])
+        UnitaryGates.NQubitDepolarizingChannel(0.1, [0, 1])
+        op.BitFlip(0.1, wires=1)             # shares a wire with the pair: the pair is emitted first
+        UnitaryGates.NQubitDepolarizingChannel(0.3, [1, 0])  # other wire order: a run of its own
+        op.ThermalRelaxationError(0.1, 1.0, 1.5, 0.3, wires=2)
+    doubled = simulation.doubled_tape(tape, n)
+    names = [d.lower(2 * n)[0] for d in doubled]
+    wires = [tuple(d.lower(2 * n)[1]) for d in doubled]
+    assert names.count("MAT2") == 4 and names.count("MAT4") == 2, names
+    assert wires[names.index("MAT2")] in ((0, 3), (1, 4))
+    i_cx = names.index("CX")
+    assert sorted(wires[i] for i in range(i_cx) if names[i] == "MAT2") == [(0, 3), (1, 4)]
+    assert [wires[i] for i in range(len(names)) if names[i] == "MAT4"] == [(0, 1, 3, 4), (1, 0, 4, 3)]
+    want = ON.simulate_mixed(frontend_to_oracle(tape), n)
+    vec = ES.simulate_pure(lowered_to_oracle(doubled, 2 * n), 2 * n, dtype=np.complex128)
+    assert np.allclose(vec.reshape(2**n, 2**n), want, atol=1e-12)
+    a, b = op.BitFlip(0.1, wires=0).superoperator(), op.BitFlip(0.1, wires=2).superoperator()
+    assert a is b and not a.flags.writeable
+    assert op.BitFlip(0.11, wires=0).superoperator() is not a
+
+
 def test_noise_free_tape_stays_pure():
     with recording() as tape:
         op.H(wires=0)
