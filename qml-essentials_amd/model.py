@@ -737,7 +737,14 @@ class Model:
         else:
             return None
         return (et, pk, xk, hash(self._enc_params.tobytes()), hash(self._data_reupload.tobytes()),
-                self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key())
+                self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key(), self._noise_key())
+
+    def _noise_key(self):
+        """Hashable view of the active noise parameters (they are constants of a compiled call)."""
+        if self.noise_params is None:
+            return None
+        return tuple(sorted((k, tuple(sorted(v.items())) if isinstance(v, dict) else v)
+                            for k, v in self.noise_params.items()))
 
     def prepared_state_call(self, n_param_sets: int):
         """The compiled device call that turns a CUDA tensor of ``n_param_sets`` parameter sets
@@ -753,7 +760,7 @@ class Model:
             return None
         fp = ("state", ("d", tuple(self._params_shape), n_param_sets > 1), ("z",),
               hash(self._enc_params.tobytes()), hash(self._data_reupload.tobytes()),
-              self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key())
+              self.remove_zero_encoding, tuple(self.repeat_batch_axis), self._oq_key(), None)
         rec = self._fast_calls.get(fp)
         if rec is None:
             return None
@@ -901,16 +908,19 @@ class Model:
             h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
         key = (meas_type, tuple((type(o).__name__, tuple(o.wires)) for o in obs), leaf_ids,
                shape_p, shape_x, self._zero_inputs, B_I == 1,
-               self.remove_zero_encoding, h.hexdigest())
+               self.remove_zero_encoding, h.hexdigest(), self._noise_key())
+        noisy = self.noise_params is not None
 
         def probe_args():
             hp = p[0].detach().cpu().numpy() if dev_params else host_p
             hx = x[0].detach().cpu().numpy() if dev_inputs else host_x
-            return (hp, hx, None, None, enc)
+            # (the channels take no randomness; the key only satisfies the noisy gates' signature)
+            return (hp, hx, None, PRNGKey(0) if noisy else None, enc)
 
         try:
-            cc = self.script.compiled(key, meas_type, obs, probe_args,
-                                      leaf_ids, dict(noise_params=None, gate_mode="unitary"))
+            cc = self.script.compiled(key, meas_type, obs, probe_args, leaf_ids,
+                                      dict(noise_params=dict(self.noise_params) if noisy else None,
+                                           gate_mode="unitary"))
         except NotAffine:
             return NotImplemented
         leaves, divs, mods = [], [], []
@@ -972,8 +982,8 @@ class Model:
         B = B_P * int(x.shape[0]) if (self.repeat_batch_axis[0] and self.repeat_batch_axis[1]) \
             else max(B_P, int(x.shape[0]))
         et = execution_type or self.execution_type
-        if B > 1 and memory.compute_chunk_size(self.n_qubits, B, et, False, self.n_qubits,
-                                               n_ops=64) < B:
+        if B > 1 and memory.compute_chunk_size(self.n_qubits, B, et, self.noise_params is not None,
+                                               self.n_qubits, n_ops=64) < B:
             return NotImplemented
         if 0 not in p.shape:
             p = torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).cuda()
@@ -1004,9 +1014,16 @@ class Model:
         own_dev = params is None and self._params_dev is not None and not x64
         if own_dev:  # the model's own parameters live on the GPU (a large initialize_params draw)
             params = self._params_dev
+        if noise_params is not None:
+            self.noise_params = noise_params
+        # incoherent channels compile like any other tape (vec(rho) on the doubled register, round 5);
+        # GateError draws fresh random angles per call and 'state' of a noisy circuit is an error: both
+        # keep the recorded path
+        compilable = self.noise_params is None or (
+            not self.noise_params.get("GateError") and (execution_type or self.execution_type) != "state")
         if (self._is_cuda(params) or self._is_cuda(inputs)) \
                 and (not as_tensor or (execution_type or self.execution_type) == "state") \
-                and noise_params is None and self.noise_params is None and gate_mode == "unitary" \
+                and compilable and gate_mode == "unitary" \
                 and pulse_params is None and self.shots is None:
             if data_reupload is not None:
                 self.data_reupload = data_reupload
@@ -1021,7 +1038,7 @@ class Model:
         inputs = inputs.detach().cpu().numpy() if self._is_cuda(inputs) else inputs
         # (as_tensor: the analysis loops -- Expressibility, Meyer-Wallach -- ask for the raw device
         # tensor of states; the compiled call serves them too: no tape re-recording per call)
-        if (noise_params is None and self.noise_params is None
+        if (compilable
                 and gate_mode == "unitary" and pulse_params is None and self.shots is None
                 and self.host_arrays_via_device and not self._is_cuda(params)
                 and not self._is_cuda(inputs) and not x64
@@ -1030,8 +1047,6 @@ class Model:
                                                 force_mean, data_reupload, as_tensor=as_tensor)
             if out is not NotImplemented:
                 return out
-        if noise_params is not None:
-            self.noise_params = noise_params
         if execution_type is not None:
             self.execution_type = execution_type
         self.gate_mode = gate_mode

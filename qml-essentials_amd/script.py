@@ -49,7 +49,20 @@ class CompiledCall:
             wrapped[k] = Batched.leaf(pr, k)
         tape = script._record(*wrapped, **kwargs)
         self.n_qubits = script._n_qubits or simulation.infer_n_qubits(tape, obs)
-        low = simulation.LoweredTape(tape, self.n_qubits)
+        # A tape with noise channels runs on vec(rho), a pure "state" of the doubled register
+        # (simulation.doubled_tape): the same plan / angle-map machinery, measured as a density matrix.
+        # Channels on 3 or 4 wires (applied Kraus operator by Kraus operator) keep the recorded path.
+        self.density = any(isinstance(o, KrausChannel) for o in tape)
+        n_reg = self.n_qubits
+        if self.density:
+            if type == "state" or self.n_qubits > simulation.MAX_DENSITY_QUBITS:
+                raise NotAffine("noisy tape")  # (the recorded path raises the reference's messages)
+            tape = simulation.doubled_tape(tape, self.n_qubits)
+            if any(isinstance(it, simulation._WideChannel) for it in tape):
+                raise NotAffine("wide channel")
+            n_reg = 2 * self.n_qubits
+        self.n_register = n_reg
+        low = simulation.LoweredTape(tape, n_reg)
         self.plan = simulation.get_plan(low)
         self.n_slots = low.n_slots
         values = np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), (2,))
@@ -58,10 +71,10 @@ class CompiledCall:
         slot = 0
         order = {k: i for i, k in enumerate(leaf_ids)}
         for op_ in tape:
-            if op_.lower(self.n_qubits) is None:
+            if op_.lower(n_reg) is None:
                 continue
             tans = op_.parameter_tangents
-            for j in range(len(op_.lower(self.n_qubits)[2])):  # one slot per lowered parameter
+            for j in range(len(op_.lower(n_reg)[2])):  # one slot per lowered parameter
                 t = tans[j] if j < len(tans) else []
                 if t is None:
                     raise NotAffine(op_.name)
@@ -97,6 +110,19 @@ class CompiledCall:
         overrides the call's measurement with another one of the same circuit ("mw": Meyer-Wallach
         out of the producing pass, for a call compiled for "state")."""
         strides = [t[0].numel() if t.shape[0] else 0 for t in leaves]
+        if self.density:
+            if meas is not None and meas != self.type:
+                raise NotImplementedError(f"measurement {meas!r} of a noisy circuit")
+            if self.n_slots:
+                am = getattr(self, "_amap", None)
+                if am is None:
+                    am = self._amap = N.AngleMapArgs(len(self.leaf_ids), self.d_ptr, self.d_arg, self.d_idx,
+                                                     self.d_coef, self.d_const, self.d_period)
+                rho = self.plan.run_map(am.set(leaves, strides, divs, mods, batch_offset), batch, "state", ())
+            else:
+                import torch
+                rho = self.plan.run(torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device), "state")
+            return simulation.measure_density_vec(rho, self.n_qubits, self.type, self.obs)
         kind = meas if meas is not None and meas != self.type else self.type
         arg = ()
         if kind == "expval":
@@ -176,6 +202,8 @@ class CompiledCall:
         chain rule all stay on the GPU."""
         import torch
 
+        if self.density:
+            raise NotImplementedError("adjoint differentiation of a noisy circuit")
         masks = [z_parity_mask(o) for o in self.obs]
         if self.type != "expval" or not self.obs or any(m is None for m in masks):
             raise NotImplementedError("adjoint differentiation needs Z / Z-parity observables")

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _native as N
-from .operations import Barrier, KrausChannel, Operation, conj_lower, z_parity_mask
+from .operations import _CONJ_NEGATE, Barrier, KrausChannel, Operation, conj_lower, z_parity_mask
 
 MEAS_TYPES = ("expval", "probs", "state", "density")
 _PLAN_CACHE: "OrderedDict[tuple, N.Plan]" = OrderedDict()
@@ -41,15 +41,41 @@ MAX_DENSITY_QUBITS = 14  # vec(rho) is a 2n-qubit register; 2n <= 28 keeps it on
 
 
 class _Lowered:
-    """An already-lowered op (what ``LoweredTape`` consumes)."""
+    """An already-lowered op (what ``LoweredTape`` consumes).  ``tangents``: per lowered parameter the
+    affine terms of the source gate's parameter (``Operation.parameter_tangents``; a compiled call builds
+    its angle map from them)."""
 
-    __slots__ = ("_low",)
+    __slots__ = ("_low", "_tan")
 
-    def __init__(self, low):
+    def __init__(self, low, tangents=None):
         self._low = low
+        self._tan = tangents
 
     def lower(self, n_qubits: int):
         return self._low
+
+    @property
+    def name(self) -> str:
+        return self._low[0]
+
+    @property
+    def parameter_tangents(self) -> list:
+        return self._tan if self._tan is not None else [[] for _ in self._low[2]]
+
+
+def _conj_tangents(op_: Operation, name: str) -> list:
+    """Tangent terms of ``conj_lower(op_)``'s parameters: the source gate's, negated where the
+    parameter is (``operations._CONJ_NEGATE``); explicit-matrix conjugates have no parameters."""
+    neg = _CONJ_NEGATE.get(name)
+    if neg is None:
+        return []
+    out = []
+    for j, t in enumerate(op_.parameter_tangents):
+        if t is None or j not in neg:
+            out.append(t)
+        else:
+            out.append([(lid, flat, -np.asarray(cf, dtype=np.float64)) for lid, flat, cf in t])
+    return out
 
 
 class _WideChannel:
@@ -134,11 +160,11 @@ def doubled_tape(tape: Sequence[Operation], n_qubits: int) -> list:
             flush()
             m = np.asarray(low[3], dtype=np.float64)
             out.append(_Lowered(("DIAG_ALL", [], low[2],
-                                 (m[:, None] - m[None, :]).reshape(-1))))
+                                 (m[:, None] - m[None, :]).reshape(-1)), op_.parameter_tangents))
             continue
         flush(set(low[1]))
-        out.append(_Lowered(low))
-        out.append(_Lowered(conj_lower(op_, n_qubits, n_qubits)))
+        out.append(_Lowered(low, op_.parameter_tangents))
+        out.append(_Lowered(conj_lower(op_, n_qubits, n_qubits), _conj_tangents(op_, low[0])))
     flush()
     return out
 
@@ -261,11 +287,17 @@ def _simulate_mixed(tape: Sequence[Operation], n_qubits: int, type: str, obs, B:
             "Measurement type 'state' is not defined for mixed (noisy) circuits. "
             "Use 'density' instead."
         )
-    torch = N.require_gpu()
+    N.require_gpu()
     if x64:
         return _density_measure_x64(_evolve_density(tape, n_qubits, B, True), n_qubits, type, obs)
-    rho_vec = _evolve_density(tape, n_qubits, B)
-    D = 1 << n_qubits
+    return measure_density_vec(_evolve_density(tape, n_qubits, B), n_qubits, type, obs)
+
+
+def measure_density_vec(rho_vec, n_qubits: int, type: str, obs):
+    """Measurement of vec(rho) [B, 4^n] (complex64): the density matrices themselves, their diagonals, or
+    Tr(O rho) per observable (``simulation.py:274-317`` ``measure_density``)."""
+    torch = N.require_gpu()
+    B, D = rho_vec.shape[0], 1 << n_qubits
     if type == "density":
         return rho_vec.view(B, D, D)
     if type == "probs":

@@ -316,3 +316,54 @@ def test_noisy_model_batched_in_x64():
     assert rho.dtype == np.complex128
     assert np.abs(np.trace(rho, axis1=-2, axis2=-1) - 1).max() < 1e-12
     assert np.abs(rho - np.conj(np.swapaxes(rho, -1, -2))).max() < 1e-13
+
+
+# ---- compiled noisy calls (round 5) ----------------------------------------------------------
+@pytest.mark.parametrize("execution_type", ["expval", "probs", "density"])
+def test_compiled_noisy_call_equals_the_recorded_path(execution_type):
+    """A noisy Model call without GateError compiles like a noise-free one (vec(rho) on the doubled
+    register, angles affine in params / inputs, U and conj(U) fed by the same leaves with opposite
+    signs): same numbers as the per-call recorded path, for host batches, CUDA tensors and a single
+    sample; the noise parameters are part of the compiled call's key."""
+    import torch
+
+    noise = {"BitFlip": 0.01, "PhaseFlip": 0.015, "Depolarizing": 0.02, "MultiQubitDepolarizing": 0.03,
+             "AmplitudeDamping": 0.05, "PhaseDamping": 0.06,
+             "ThermalRelaxation": {"t1": 2000.0, "t2": 1000.0, "t_factor": 1.0}}
+    rng = np.random.default_rng(8)
+    for ansatz, n in (("Hardware_Efficient", 4), ("Circuit_19", 3), ("Strongly_Entangling", 3)):
+        fast = Model(n_qubits=n, n_layers=2, circuit_type=ansatz, output_qubit=-1)
+        slow = Model(n_qubits=n, n_layers=2, circuit_type=ansatz, output_qubit=-1)
+        slow.host_arrays_via_device = False  # -> script.execute records the tape per call
+        P = rng.uniform(0, 2 * np.pi, size=(3, *fast.params.shape[1:]))
+        X = rng.uniform(0, 2 * np.pi, size=(2, 1))
+        for params, inputs in ((P, X), (P[:1], X[:1]), (P, None)):
+            want = slow(params=params, inputs=inputs, noise_params=dict(noise), execution_type=execution_type)
+            got = fast(params=params, inputs=inputs, noise_params=dict(noise), execution_type=execution_type)
+            assert got.shape == want.shape
+            assert np.allclose(got, want, atol=ATOL)
+        assert any(cc.density for cc in fast.script._compiled.values())
+        assert not slow.script._compiled
+        # CUDA tensors in, CUDA tensor out
+        got = fast(params=torch.from_numpy(P.astype(np.float32)).cuda(),
+                   inputs=torch.from_numpy(X.astype(np.float32)).cuda(), noise_params=dict(noise),
+                   execution_type=execution_type)
+        want = slow(params=P, inputs=X, noise_params=dict(noise), execution_type=execution_type)
+        assert got.is_cuda and np.allclose(got.cpu().numpy(), want, atol=ATOL)
+        # other noise strengths: another compiled call, other numbers
+        other = dict(noise, Depolarizing=0.2)
+        got2 = fast(params=P, inputs=X, noise_params=dict(other), execution_type=execution_type)
+        want2 = slow(params=P, inputs=X, noise_params=dict(other), execution_type=execution_type)
+        assert np.allclose(got2, want2, atol=ATOL) and not np.allclose(got2, want, atol=1e-4)
+
+
+def test_gate_error_and_noisy_state_keep_the_recorded_path():
+    """GateError draws fresh angles per call (nothing to compile); 'state' of a noisy circuit raises the
+    reference's error."""
+    model = Model(n_qubits=3, n_layers=1, circuit_type="Hardware_Efficient", output_qubit=-1)
+    P = np.random.default_rng(1).uniform(0, 2 * np.pi, size=(4, *model.params.shape[1:]))
+    a = model(params=P, noise_params={"GateError": 0.3, "BitFlip": 0.05}, execution_type="expval")
+    b = model(params=P, noise_params={"GateError": 0.3, "BitFlip": 0.05}, execution_type="expval")
+    assert not model.script._compiled and not np.allclose(a, b, atol=1e-4)
+    with pytest.raises(ValueError, match="not defined for mixed"):
+        model(params=P, noise_params={"BitFlip": 0.05}, execution_type="state")

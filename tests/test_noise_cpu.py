@@ -341,3 +341,28 @@ def test_all_zero_noise_is_none_and_unknown_key_warns():
     assert model.noise_params is None
     with pytest.warns(UserWarning, match="not supported"):
         model.noise_params = {"BitFlip": 0.1, "Bogus": 0.2}
+
+
+def test_doubled_tape_carries_the_tangents_of_its_gates():
+    """What a compiled noisy call builds its angle map from: U keeps the source gate's tangent terms,
+    conj(U) the same terms with the sign of the parameters that conjugation negates."""
+    from qml_essentials_amd.batching import Batched
+
+    leaf = Batched.leaf(np.array([[0.3, 0.7, 1.1], [0.5, 0.9, 1.7]]), 0)
+    with recording() as tape:
+        op.RX(leaf[0], wires=0)
+        op.RY(2.0 * leaf[1], wires=1)
+        op.BitFlip(0.1, wires=0)
+        op.Rot(leaf[0], leaf[1], leaf[2], wires=1)
+        op.PauliY(wires=0)
+    items = simulation.doubled_tape(tape, 2)
+    by = [(it.name, tuple(it.lower(4)[1]), it.parameter_tangents) for it in items]
+    coef = lambda t: [[(lid, flat, float(np.asarray(c).reshape(-1)[0])) for lid, flat, c in p] for p in t]
+    assert by[0][:2] == ("RX", (0,)) and coef(by[0][2]) == [[(0, 0, 1.0)]]
+    assert by[1][:2] == ("RX", (2,)) and coef(by[1][2]) == [[(0, 0, -1.0)]]
+    assert by[2][:2] == ("RY", (1,)) and coef(by[2][2]) == [[(0, 1, 2.0)]]
+    assert by[3][:2] == ("RY", (3,)) and coef(by[3][2]) == [[(0, 1, 2.0)]]       # RY is real
+    rot = [b for b in by if b[0] == "Rot"]
+    assert coef(rot[0][2]) == [[(0, 0, 1.0)], [(0, 1, 1.0)], [(0, 2, 1.0)]]
+    assert coef(rot[1][2]) == [[(0, 0, -1.0)], [(0, 1, 1.0)], [(0, 2, -1.0)]]   # phi, omega negated
+    assert all(b[2] == [] for b in by if b[0].startswith("MAT"))
