@@ -825,7 +825,13 @@ class Model:
         if _want_call:  # (Model.vjp_device) hand the compiled call + its leaves to the caller
             return cc, leaves, divs, mods, B
         lo, hi, sharded = distributed.my_block(B, *leaves)
-        result = cc.run(leaves, divs, mods, hi - lo, lo)
+        shot_key = None
+        if self.shots is not None and et in ("probs", "expval"):
+            # the key schedule of the recorded path (model.py:1670-1675): same draws either way
+            self.random_key, sub_key = safe_random_split(self.random_key)
+            _, shot_key = safe_random_split(sub_key)
+        result = cc.run(leaves, divs, mods, hi - lo, lo, shots=self.shots if shot_key is not None else None,
+                        key=shot_key)
         if sharded:
             result = distributed.all_gather_rows(result, B)
         if raw:  # the analysis loops' (B, ...) device tensor, batch axis flat
@@ -1024,7 +1030,7 @@ class Model:
         if (self._is_cuda(params) or self._is_cuda(inputs)) \
                 and (not as_tensor or (execution_type or self.execution_type) == "state") \
                 and compilable and gate_mode == "unitary" \
-                and pulse_params is None and self.shots is None:
+                and pulse_params is None:
             if data_reupload is not None:
                 self.data_reupload = data_reupload
             out = self._forward_device(params, inputs, enc_params, execution_type, force_mean,
@@ -1039,7 +1045,7 @@ class Model:
         # (as_tensor: the analysis loops -- Expressibility, Meyer-Wallach -- ask for the raw device
         # tensor of states; the compiled call serves them too: no tape re-recording per call)
         if (compilable
-                and gate_mode == "unitary" and pulse_params is None and self.shots is None
+                and gate_mode == "unitary" and pulse_params is None
                 and self.host_arrays_via_device and not self._is_cuda(params)
                 and not self._is_cuda(inputs) and not x64
                 and (not as_tensor or (execution_type or self.execution_type) == "state")):

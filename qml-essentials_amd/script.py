@@ -105,13 +105,19 @@ class CompiledCall:
         self._leaf_sizes = {order[k]: int(np.prod(np.shape(args[k]))) for k in leaf_ids}
         self._adj = None
 
-    def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0, meas: Optional[str] = None):
+    def run(self, leaves, divs, mods, batch: int, batch_offset: int = 0, meas: Optional[str] = None,
+            shots: Optional[int] = None, key=None):
         """leaves: contiguous float32 CUDA tensors [rows_k, ...] in ``leaf_ids`` order.  ``meas``
         overrides the call's measurement with another one of the same circuit ("mw": Meyer-Wallach
-        out of the producing pass, for a call compiled for "state")."""
+        out of the producing pass, for a call compiled for "state").  ``shots``: "probs" / "expval"
+        are estimated from that many draws of the exact probabilities (row b on the Philox stream
+        ``(key, batch_offset + b)``, ``simulation.sample_shots``)."""
+        if shots is not None and meas is None and self.type in ("probs", "expval"):
+            probs = self.run(leaves, divs, mods, batch, batch_offset, meas="probs")
+            return simulation.sample_shots(probs, self.n_qubits, self.type, self.obs, shots, key, batch_offset)
         strides = [t[0].numel() if t.shape[0] else 0 for t in leaves]
         if self.density:
-            if meas is not None and meas != self.type:
+            if meas not in (None, self.type, "probs"):
                 raise NotImplementedError(f"measurement {meas!r} of a noisy circuit")
             if self.n_slots:
                 am = getattr(self, "_amap", None)
@@ -122,7 +128,7 @@ class CompiledCall:
             else:
                 import torch
                 rho = self.plan.run(torch.zeros((batch, 0), dtype=torch.float32, device=self.d_const.device), "state")
-            return simulation.measure_density_vec(rho, self.n_qubits, self.type, self.obs)
+            return simulation.measure_density_vec(rho, self.n_qubits, meas or self.type, self.obs)
         kind = meas if meas is not None and meas != self.type else self.type
         arg = ()
         if kind == "expval":

@@ -149,3 +149,26 @@ def test_model_shots(execution_type, output_qubit, shape):
     assert not np.allclose(got, exact, atol=1e-6)          # 1024 shots are visibly noisy
     if execution_type == "probs":
         assert np.allclose(got.reshape(3, -1).sum(axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("noise", [None, {"BitFlip": 0.02, "Depolarizing": 0.03, "AmplitudeDamping": 0.05}])
+@pytest.mark.parametrize("execution_type", ["expval", "probs"])
+def test_compiled_call_with_shots_draws_what_the_recorded_path_draws(execution_type, noise):
+    """Round 5: shot estimates come out of the compiled call too (exact probabilities of the compiled plan,
+    then the device sampler): same key schedule as the per-call recorded path, so two models with the same
+    seed return the same draws either way -- bit for bit, call after call, with and without noise channels."""
+    fast = Model(n_qubits=4, n_layers=2, circuit_type="Hardware_Efficient", output_qubit=-1, shots=513)
+    slow = Model(n_qubits=4, n_layers=2, circuit_type="Hardware_Efficient", output_qubit=-1, shots=513)
+    slow.host_arrays_via_device = False
+    rng = np.random.default_rng(3)
+    P = rng.uniform(0, 2 * np.pi, size=(5, *fast.params.shape[1:]))
+    X = rng.uniform(0, 2 * np.pi, size=(2, 1))
+    for params, inputs in ((P, X), (P, None), (P[:1], X[:1]), (P, X)):
+        kw = dict(noise_params=dict(noise)) if noise else {}
+        a = fast(params=params, inputs=inputs, execution_type=execution_type, **kw)
+        b = slow(params=params, inputs=inputs, execution_type=execution_type, **kw)
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert fast.script._compiled and not slow.script._compiled
+    fast.shots = slow.shots = None
+    exact = slow(params=P, inputs=X, execution_type=execution_type)
+    assert not np.allclose(a, exact, atol=1e-6)
