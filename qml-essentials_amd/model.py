@@ -22,6 +22,7 @@ from .tape import recording
 from .ansaetze import Ansaetze, Circuit, Encoding
 from .batching import to_numpy
 from .gates import Gates
+from ._native import to_host as N_to_host
 from .utils import (PRNGKey, as_key, device_sampling, safe_random_split, uniform,
                     uniform_device)
 
@@ -998,7 +999,7 @@ class Model:
         out = self._forward_device(p, x, enc_params, execution_type, force_mean)
         if out is NotImplemented:
             return NotImplemented
-        return out if as_tensor else out.cpu().numpy()
+        return out if as_tensor else N_to_host(out)
 
     def _forward(self, params=None, inputs=None, pulse_params=None, enc_params=None,
                  data_reupload=None, noise_params=None, execution_type: Optional[str] = None,
@@ -1037,7 +1038,7 @@ class Model:
                                        raw=as_tensor)
             if out is not NotImplemented:
                 # CUDA tensors in -> CUDA tensor out; host arguments get a host array back
-                return out if (user_cuda or as_tensor) else out.cpu().numpy()
+                return out if (user_cuda or as_tensor) else N_to_host(out)
         if own_dev:
             params = None  # (-> the lazily materialised host mirror, self.params)
         params = params.detach().cpu().numpy() if self._is_cuda(params) else params

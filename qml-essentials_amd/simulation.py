@@ -477,7 +477,7 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
         if sampled:  # (x64: the sampler takes the float64 probabilities rounded once to float32)
             res = sample_shots(res.float() if res.dtype != torch.float32 else res, n_qubits, type, obs,
                                shots, key, row_offset)
-        return res if as_tensor else res.cpu().numpy()
+        return res if as_tensor else N.to_host(res)
     low = LoweredTape(tape, n_qubits)
     from .utils import x64_enabled
 
@@ -491,12 +491,12 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
                                obs, shots, key, row_offset)
         else:
             res = _simulate_x64(plan, low, B, n_qubits, type, list(obs))
-        return res if as_tensor else res.cpu().numpy()
+        return res if as_tensor else N.to_host(res)
     plan = get_plan(low)
     angles = torch.from_numpy(low.angle_table(B)).cuda()
     if sampled:
         res = sample_shots(plan.run(angles, "probs"), n_qubits, type, obs, shots, key, row_offset)
-        return res if as_tensor else res.cpu().numpy()
+        return res if as_tensor else N.to_host(res)
     if type == "expval":
         obs = list(obs)
         masks = [z_parity_mask(o) for o in obs]
@@ -512,7 +512,7 @@ def simulate_and_measure(tape: Sequence[Operation], n_qubits: int, type: str,
         res = plan.run(angles, type)
     if as_tensor:
         return res
-    return res.cpu().numpy()
+    return N.to_host(res)
 
 
 def _simulate_x64(plan: N.Plan, low: "LoweredTape", B: int, n_qubits: int, type: str, obs):

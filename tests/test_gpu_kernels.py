@@ -1110,3 +1110,56 @@ def test_a_row_does_not_depend_on_its_batch(n, flags_kw):
         k += len(prm)
     want = OE.simulate_pure(filled, n, np.complex128)
     assert np.abs(whole[129] - want).max() < 1e-6
+
+
+@pytest.mark.parametrize("n", [2, 5, 9, 13, 16, 19])
+def test_dense_4x4_operators_absorb_their_neighbours_and_run_in_register_tiles(n):
+    """Round 5: an uncontrolled 4x4 (two-qubit Pauli rotations, SWAP, explicit matrices -- the Kraus
+    superoperators of the density path) takes the 1-qubit gates before and behind it on its wires and the next
+    4x4 on the same ordered pair into ONE per-sample matrix (plan compiler), and runs inside a register-tile
+    group (GK_REG4X) instead of an LDS sweep of its own.  Tapes made of such runs, every engine mode, against
+    the double-precision oracle; the batch rows differ in every angle."""
+    from qml_essentials_amd import _native as N
+
+    rng = np.random.default_rng(900 + n)
+    two = ["RXX", "RYY", "RZZ", "RZX", "SWAP"]
+    one = ["RX", "RY", "RZ", "H", "S", "Rot"]
+    n_par = {"RX": 1, "RY": 1, "RZ": 1, "Rot": 3, "RXX": 1, "RYY": 1, "RZZ": 1, "RZX": 1}
+    tape = []
+    for _ in range(60):
+        r = rng.random()
+        if r < 0.45:
+            g = two[rng.integers(len(two))]
+            w = [int(x) for x in rng.choice(n, 2, replace=False)]
+            if rng.random() < 0.5 and tape and len(tape[-1][1]) == 2:
+                w = list(tape[-1][1]) if rng.random() < 0.7 else list(tape[-1][1])[::-1]  # same pair (either order)
+        elif r < 0.55 and n >= 2:
+            g, w = "CX", [int(x) for x in rng.choice(n, 2, replace=False)]
+        else:
+            g = one[rng.integers(len(one))]
+            w = [int(rng.integers(n))]
+        tape.append((g, w, tuple(float(x) for x in rng.uniform(0, 2 * np.pi, n_par.get(g, 0)))))
+    want = OE.simulate_pure(tape, n, np.complex128)
+    merged = None
+    for mode, flags in _modes(n).items():
+        got, plan = _run(tape, n, "state", flags=flags)
+        err = np.abs(got[0] - want).max()
+        assert err < 2e-6, (mode, n, err)
+        if mode == "lds":
+            merged = plan.describe()
+    assert merged["n_lowered"] < 0.6 * merged["n_ops"], (merged["n_lowered"], merged["n_ops"])
+    # a batch whose rows differ: per-sample 4x4 products
+    ops, angles, consts = tape_to_native(tape, n)
+    A = np.stack([angles, angles[::-1].copy(), rng.uniform(0, 6.28, angles.shape)]).astype(np.float32)
+    plan = N.Plan(ops, n, len(angles), consts)
+    z = plan.run(torch.from_numpy(A).cuda(), "expval", list(range(n))).cpu().numpy()
+    for b in range(3):
+        k, t2 = 0, []
+        for g, w, p in tape:
+            t2.append((g, w, tuple(float(x) for x in A[b, k:k + len(p)])))
+            k += len(p)
+        psi = OE.simulate_pure(t2, n, np.complex128)
+        pr = np.abs(psi) ** 2
+        idx = np.arange(1 << n)
+        ref = [float((pr * (1 - 2 * ((idx >> (n - 1 - q)) & 1))).sum()) for q in range(n)]
+        assert np.abs(z[b] - np.array(ref)).max() < 2e-6, (b, n)

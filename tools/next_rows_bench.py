@@ -5,8 +5,10 @@ oracle states the same computation.  Prints a markdown table (profiles/rNN_next_
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import contextlib
 import __graft_entry__ as entry
-entry.build()
+with contextlib.redirect_stdout(sys.stderr):
+    entry.build()
 from oracle import noise as ON, einsum_sim as OE
 from qml_essentials_amd.model import Model
 from qml_essentials_amd.entanglement import Entanglement
@@ -55,7 +57,7 @@ for n, layers, B in ((6, 3, 256), (8, 3, 256), (10, 2, 64), (12, 1, 16)):
 for n, S in ((6, 512), (10, 256), (12, 64)):
     m = Model(n, 2, "Hardware_Efficient")
     g = gpu_time(lambda: Entanglement.bell_measurements(m, n_samples=S, random_key=PRNGKey(1000)), reps=3)
-    row(f"Entanglement.bell_measurements Model({n},2,HE), {S} samples ({2 * n}-qubit circuits, marginals on the GPU)", g)
+    row(f"Entanglement.bell_measurements Model({n},2,HE), {S} samples ({2 * n}-qubit circuits, Z-parities out of the last pass)", g)
 for n, S in ((4, 512), (8, 64)):
     m = Model(n, 2, "Hardware_Efficient")
     g = gpu_time(lambda: Entanglement.concentratable_entanglement(m, n_samples=S, random_key=PRNGKey(1000)), reps=3)
