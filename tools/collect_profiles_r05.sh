@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-5 evidence, run on the GPU box (bash tools/collect_profiles_r05.sh [part ...]); parts: stats pmc mw sq legs
-# k1 misc bench (default: all).  Everything lands in gpurun_out/profiles_r05/, the files to keep are named r05_*.
+# k1 misc rows bench (default: all).  Everything lands in gpurun_out/profiles_r05/, the files to keep are named r05_*.
 set -e
 TAG=r05; export TAG
-PARTS=${*:-stats pmc mw sq legs k1 misc bench}
+PARTS=${*:-stats pmc mw sq legs k1 misc rows bench}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -97,6 +97,22 @@ if has misc; then
   python3 tools/loops_anatomy.py c3 c4 c4_api mw 2>/dev/null | grep -E "^(c3|c4|c4_api|mw):" > $OUT/${TAG}_loops_anatomy.txt || true
   python3 tools/whole_state_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_ws_bench.txt || true
   python3 tools/configs_bench.py 2>/dev/null | grep "^|" > $OUT/${TAG}_configs.md || true
+  cd /tmp
+fi
+if has rows; then
+  echo "[rows] widened rows (SURVEY 8-f): wall-clock table, the noisy plan under the round-5 switches"
+  cd $R
+  python3 tools/next_rows_bench.py > $OUT/next_rows_now.md 2> $OUT/next_rows.err || true
+  {
+    echo "== one LDS sweep per superoperator, gates unmerged (QMLE_NO_REG2Q=1 QMLE_NO_MERGE_2Q=1)"
+    QMLE_NO_REG2Q=1 QMLE_NO_MERGE_2Q=1 python3 tools/noise_plan_profile.py 2>&1 | grep -v amdgpu.ids
+    echo "== 4x4 operators in register-tile groups (QMLE_NO_MERGE_2Q=1)"
+    QMLE_NO_MERGE_2Q=1 python3 tools/noise_plan_profile.py 2>&1 | grep -v amdgpu.ids
+    echo "== default: gates and channels merged into the 4x4 operators"
+    python3 tools/noise_plan_profile.py 2>&1 | grep -v amdgpu.ids
+    echo "== host profile of one noisy Model(10, 2) call, 64 parameter sets (compiled call)"
+    NP_N=10 NP_L=2 NP_B=64 NP_TOP=12 python3 tools/noise_profile.py 2>&1 | grep -v amdgpu.ids
+  } > $OUT/${TAG}_noise_plan.txt
   cd /tmp
 fi
 if has bench; then
