@@ -142,7 +142,8 @@ _REV_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_groups,
                           weights: np.ndarray, want: Sequence[bool], x64: bool = False) -> np.ndarray:
     """d/d(angle slot) of sum_k weights[b, k] <Z..Z>_k for every forward slot -> [B, n_slots]
-    (columns of slots that are not wanted stay zero).  The reversed tape depends only on the
+    (columns of slots that are not wanted stay zero; ``weights`` of shape [K * B, n_obs] -- K cotangents per
+    sample, sample-minor -- give [K * B, n_slots] from one sweep over K * B states).  The reversed tape depends only on the
     STRUCTURE of the forward tape (its angles are the negated forward columns), so it is built
     once per structure.  ``x64``: float64 angle table, complex128 states, float64 gradients."""
     torch = N.require_gpu()
@@ -161,6 +162,10 @@ def adjoint_slot_gradient(low: LoweredTape, n_qubits: int, batch: int, obs_group
         _REV_CACHE.move_to_end(key)
     rev, fixed, perm = hit
     a_f = torch.from_numpy(low.angle_table(batch, dtype=np.float64) if x64 else low.angle_table(batch)).cuda()
+    rep = int(np.shape(weights)[0]) // max(1, batch)
+    if rep > 1:  # several cotangents per sample (a Jacobian: one row of weights per output) in ONE sweep
+        a_f = a_f.repeat(rep, 1)
+        batch = batch * rep
     if rev.n_slots:
         a_r = (-a_f.index_select(1, perm)).contiguous()
     else:

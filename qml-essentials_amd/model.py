@@ -656,14 +656,12 @@ class Model:
                 jac = (g if B > 1 else g[None])[:, None]       # (B, 1, *leaf)
                 force_mean = True                              # the output axis is already reduced
             else:
-                cols = []
-                for k in range(n_out):
-                    w = np.zeros((B, n_out))
-                    w[:, k] = 1.0
-                    (g,) = self.script.vjp(obs, w, args=args, kwargs=kwargs, in_axes=ax,
-                                           argnums=(argnum,))
-                    cols.append(g if B > 1 else g[None])
-                jac = np.stack(cols, axis=1)
+                # the Jacobian: one one-hot cotangent per output, all of them in ONE trace and ONE sweep over
+                # n_out * B states (round 5; before: n_out calls, each re-recording the tape)
+                w = np.zeros((n_out, B, n_out))
+                w[np.arange(n_out), :, np.arange(n_out)] = 1.0
+                (g,) = self.script.vjp(obs, w, args=args, kwargs=kwargs, in_axes=ax, argnums=(argnum,))
+                jac = np.moveaxis(g if B > 1 else g[:, None], 0, 1)   # (B, n_out, *leaf)
         else:
             (jac,) = self.script.gradient(obs, args=args, kwargs=kwargs,
                                           in_axes=in_axes if B > 1 else None, argnums=(argnum,))

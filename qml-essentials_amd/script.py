@@ -418,7 +418,9 @@ class Script:
         ``argnums`` by ADJOINT differentiation: one backward sweep for all angles
         (:mod:`adjoint`).  ``obs`` must be Z / Z-parity observables; ``cotangent`` has shape
         ``(B, n_obs)`` (``(n_obs,)`` without ``in_axes``).  Returns one array per ``argnums``
-        entry of shape ``(B, *arg_shape)`` (no ``B`` axis without ``in_axes``)."""
+        entry of shape ``(B, *arg_shape)`` (no ``B`` axis without ``in_axes``).  A ``cotangent`` with a
+        leading axis of K cotangents, ``(K, B, n_obs)``, is served by one trace and one sweep over K * B
+        states and returns ``(K, B, *arg_shape)`` (a Jacobian: K = n_obs one-hot rows)."""
         from . import adjoint
 
         masks = [z_parity_mask(o) for o in obs]
@@ -431,18 +433,25 @@ class Script:
         from .utils import x64_enabled
 
         x64 = x64_enabled()  # complex128 sweep, float64 tables (jax.grad with jax_enable_x64, test_jaqsi.py:57)
-        w = np.asarray(cotangent, dtype=np.float64 if x64 else np.float32).reshape(B, len(obs))
+        w = np.asarray(cotangent, dtype=np.float64 if x64 else np.float32)
+        K = int(w.size // (B * len(obs)))  # K > 1: ``cotangent`` is (K, B, n_obs) -- K cotangents, ONE trace and sweep
+        stacked = K > 1 or w.ndim == 3
+        w = w.reshape(K * B, len(obs))
         want = [False] * low.n_slots
         for s_, _rule, _t, _name in slots:
             want[s_] = True
-        grads = {k: np.zeros((B,) + tuple(shp)) for k, shp in leaf_shapes.items()}
+        grads = {k: np.zeros((K, B) + tuple(shp)) for k, shp in leaf_shapes.items()}
         if slots:
-            d = adjoint.adjoint_slot_gradient(low, n_qubits, B, masks, w, want, x64=x64)  # [B, n_slots]
+            d = adjoint.adjoint_slot_gradient(low, n_qubits, B, masks, w, want, x64=x64)  # [K * B, n_slots]
+            d = d.reshape(K, B, -1)
             for s_, _rule, tangent, _name in slots:
                 for lid, flat, coef in tangent:  # gate angles are scalars: one leaf element each
-                    g = grads[lid].reshape(B, -1)
-                    g[:, int(flat)] += d[:, s_] * np.asarray(coef, dtype=np.float64).reshape(B)
-        return tuple(grads[k] if batched else grads[k][0] for k in argnums)
+                    g = grads[lid].reshape(K, B, -1)
+                    g[:, :, int(flat)] += d[:, :, s_] * np.asarray(coef, dtype=np.float64).reshape(1, B)
+        if not stacked:
+            grads = {k: g[0] for k, g in grads.items()}
+            return tuple(grads[k] if batched else grads[k][0] for k in argnums)
+        return tuple(grads[k] if batched else grads[k][:, 0] for k in argnums)
 
     def gradient(self, obs: List[Operation], *, args: tuple = (), kwargs: Optional[dict] = None,
                  in_axes: Optional[Tuple] = None, argnums: Tuple[int, ...] = (0,)):

@@ -144,6 +144,16 @@ def test_adjoint_vjp_equals_parameter_shift_jacobian():
     g, gx = s.vjp(obs, W, args=(TH, X), in_axes=(0, 0), argnums=(0, 1))
     assert np.allclose(g, np.einsum("bk,bkp->bp", W, jac), atol=4e-6)
     assert np.allclose(gx, np.einsum("bk,bk->b", W, jx), atol=4e-6)
+    # several cotangents at once, (K, B, n_obs): one trace, one sweep over K * B states (the Jacobian route
+    # of Model.gradient(method="adjoint")) -- the same numbers as K calls
+    WK = rng.normal(size=(4, 5, 3))
+    gk, gxk = s.vjp(obs, WK, args=(TH, X), in_axes=(0, 0), argnums=(0, 1))
+    assert gk.shape == (4, 5, 15) and gxk.shape == (4, 5)
+    for k in range(4):
+        g1, gx1 = s.vjp(obs, WK[k], args=(TH, X), in_axes=(0, 0), argnums=(0, 1))
+        assert np.allclose(gk[k], g1, atol=1e-6) and np.allclose(gxk[k], gx1, atol=1e-6)
+    g1k, _ = s.vjp(obs, WK[:, :1], args=(th, x), argnums=(0, 1))     # un-batched arguments, K cotangents
+    assert g1k.shape == (4, 15) and np.allclose(g1k[2], s.vjp(obs, WK[2, 0], args=(th, x), argnums=(0, 1))[0], atol=1e-6)
     with pytest.raises(NotImplementedError):
         s.vjp([op.PauliX(wires=0, record=False)], np.ones(1), args=(th, x))
 
