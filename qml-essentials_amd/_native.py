@@ -273,7 +273,10 @@ def to_host(t) -> np.ndarray:
         return t.cpu().numpy()
     if not t.is_contiguous():
         t = t.contiguous()
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    try:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:  # (no page-locked memory to be had -- a memlock limit, a fragmented host: pageable copy)
+        return t.cpu().numpy()
     h.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
     return h.numpy()

@@ -695,3 +695,25 @@ def test_device_resident_params_host_mirror_is_a_read_only_snapshot():
     new = np.full(snap.shape, 0.3)
     model.params = new
     assert np.allclose(np.asarray(model(execution_type="expval")), a, atol=1e-6)
+
+
+def test_large_results_come_back_through_the_pinned_buffer_unchanged():
+    """Results of >= 1 MiB are copied into a page-locked buffer and returned as its numpy view (round 5,
+    ``_native.to_host``): same values as the pageable copy, writable, and independent of the next call's
+    result (the host block is reused only after the array is dropped)."""
+    import torch
+
+    from qml_essentials_amd import _native as N
+    from qml_essentials_amd.model import Model
+
+    t = torch.randn((3, 1 << 17, 2), device="cuda")
+    big = N.to_host(t)
+    assert big.nbytes >= N.PINNED_RESULT_BYTES and np.array_equal(big, t.cpu().numpy()) and big.flags.writeable
+    small = N.to_host(t[0, :8])
+    assert np.array_equal(small, t[0, :8].cpu().numpy())
+    model = Model(n_qubits=17, n_layers=1, circuit_type="Hardware_Efficient")
+    a = model(execution_type="state")
+    keep = a.copy()
+    b = model(params=np.asarray(model.params) + 0.1, execution_type="state")
+    assert a.shape == (1 << 17,) and np.array_equal(a, keep) and not np.allclose(a, b)
+    assert abs(np.vdot(a, a).real - 1.0) < 1e-5
