@@ -866,6 +866,60 @@ def _he_layer_ops(n):
     return ops, 3 * n
 
 
+def widened_rows_leg():
+    """SURVEY 8-f rows through the drop-in API (wall-clock per call, median of 5 after a warm-up; host arrays in and
+    out): a noisy model (vec(rho) on the doubled register, compiled call), Bell measurements on two copies of the state,
+    shot estimates.  Parity: the noisy <Z> of a 3-qubit model against oracle/noise.py's density evolution (2e-6)."""
+    from oracle import noise as ON
+    from qml_essentials_amd.entanglement import Entanglement
+    from qml_essentials_amd.model import Model
+    from qml_essentials_amd.tape import recording
+    from qml_essentials_amd.utils import PRNGKey
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from helpers import frontend_to_oracle
+
+    noise = {"BitFlip": 0.01, "PhaseFlip": 0.02, "Depolarizing": 0.03, "AmplitudeDamping": 0.05, "PhaseDamping": 0.06}
+    rng = np.random.default_rng(1000)
+
+    def wall(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+
+    out = {}
+    x = np.array([0.5], dtype=np.float32)
+    for n, layers, B in ((8, 3, 256), (10, 2, 64)):
+        m = Model(n, layers, "Hardware_Efficient")
+        P = rng.uniform(0, 2 * np.pi, (B, *m.params.shape[1:])).astype(np.float32)
+        out[f"noisy_model_{n}q_{layers}l_batch{B}_expval_ms"] = wall(
+            lambda: m(params=P, inputs=x, noise_params=dict(noise), execution_type="expval"))
+    m = Model(3, 2, "Hardware_Efficient")
+    P = rng.uniform(0, 2 * np.pi, (4, *m.params.shape[1:]))
+    got = m(params=P, inputs=x, noise_params=dict(noise), execution_type="expval")
+    err = 0.0
+    for b in range(4):
+        with recording() as tape:
+            m._variational(P[b], x, random_key=PRNGKey(0), noise_params=m.noise_params)
+        rho = ON.simulate_mixed(frontend_to_oracle(tape), 3)
+        idx = np.arange(8)
+        want = [float(np.real(np.diag(rho) * (1 - 2 * ((idx >> (2 - q)) & 1))).sum()) for q in range(3)]
+        err = max(err, float(np.abs(np.asarray(got[b]) - np.array(want)).max()))
+    assert err < 2e-6, err
+    out["noisy_expval_max_abs_diff_vs_oracle_density"] = err
+    m = Model(10, 2, "Hardware_Efficient")
+    out["bell_measurements_10q_256samples_ms"] = wall(
+        lambda: Entanglement.bell_measurements(m, n_samples=256, random_key=PRNGKey(1000)), reps=3)
+    ms = Model(10, 2, "Hardware_Efficient", shots=1024)
+    P = rng.uniform(0, 2 * np.pi, (256, *ms.params.shape[1:])).astype(np.float32)
+    out["expval_from_1024_shots_10q_batch256_ms"] = wall(lambda: ms(params=P, inputs=x, execution_type="expval"))
+    out["note"] = ("SURVEY 8-f rows, wall-clock per API call with host arrays in and out; start-of-round-5 figures and the "
+                   "CPU oracle beside them: profiles/r05_next_rows.md")
+    return out
+
+
 def mw_28q_leg(n=28, reps=100, warmup=25):
     """BASELINE config 5: Meyer-Wallach of ONE 2^28 statevector (2 GiB, HE layer applied to |0..0>),
     HIP events around `reps` calls.  Two forms: `resident` -- qmle_meyer_wallach on a state that
@@ -1309,7 +1363,7 @@ def main(argv=None):
         except Exception as e:  # pragma: no cover
             result["lds_regime"] = {"error": str(e)}
         for key, fn in (("k1_single_gate_28q", k1_sweep), ("mw_28q", mw_28q_leg),
-                        ("adjoint_gradient_20q", adjoint_gradient_wallclock)):
+                        ("adjoint_gradient_20q", adjoint_gradient_wallclock), ("widened_rows", widened_rows_leg)):
             try:
                 result[key] = fn()
             except Exception as e:  # pragma: no cover - e.g. not enough free HBM
@@ -1384,6 +1438,8 @@ def summary_of(r):
                          "fused_traffic": g(mw, "fused_roofline", "traffic"), "stand_alone_after_circuit_ms": mw.get("after_circuit_ms_stand_alone_reads"),
                          "bound": g(mw, "roofline", "bound"), "error": mw.get("error")}
     out["adjoint_gradient_20q_ms"] = g(r, "adjoint_gradient_20q", "ms")
+    if isinstance(r.get("widened_rows"), dict):
+        out["widened_rows"] = {k: v for k, v in r["widened_rows"].items() if k.endswith("_ms") or k == "error"}
     out["cpu_baseline_gate_applies_per_s"] = g(r, "cpu_baseline", "value")
     return out
 
