@@ -1204,6 +1204,19 @@ def main(argv=None):
     elapsed = head["elapsed"]
     hs = summarize(head, True)
     roofline = roofline_of(head, True, None if a.no_fusion else f"k_tile2:n{n}:dense")
+    # Round 5: the step is two passes (first tile on the top positions, then ONE measuring pass that applies the
+    # rest) instead of three: half the bytes, two thirds of the time -- and the measuring pass sits between HBM and
+    # the vector unit.  Both sides per pass, and the time-weighted verdict, beside the bytes-moved figure above
+    # (`roofline.bound` stays the contract's field for `achieved` / `peak`: bytes moved against HBM).
+    try:
+        rows = pass_table(head, True)
+        top_bound, share = bound_of(rows)
+        roofline["per_pass_both_sides"] = rows
+        roofline["time_share_by_bound"] = share
+        roofline["nearest_bound_by_time"] = top_bound
+        roofline["valu"] = valu_roofline(head, True)
+    except Exception as e:  # pragma: no cover
+        roofline["per_pass_both_sides"] = {"error": repr(e)}
     result = {
         "metric": "gate_applies_per_s", "value": round(n_gates * total_states / elapsed, 1),
         "unit": "gate-applies/s",
@@ -1213,7 +1226,8 @@ def main(argv=None):
         "config": {"workload": f"K2 all-live: Model({n}, 1, Hardware_Efficient, data_reupload=False) "
                                f"expval on all wires, {n_gates} gates/state (72 1q + 24 CX at n=24) "
                                f"ALL applied to the state, every amplitude read/computed/stored in "
-                               f"every pass after the |0..0> initialisation (QMLE_PLAN_NO_SPARSE | "
+                               f"every pass after the |0..0> initialisation (whose one non-zero tile per state "
+                               f"the plan places where it saves a pass) (QMLE_PLAN_NO_SPARSE | "
                                f"QMLE_PLAN_NO_ABSORB), batch {B} statevectors per GPU per step",
                    "n_qubits": n, "batch_per_gpu": B, "gates_per_state": n_gates,
                    "gates_applied_to_the_state": n_gates - head["folded"],
@@ -1267,6 +1281,32 @@ def main(argv=None):
             del tn
         except Exception as e:  # pragma: no cover
             result["k2_autotuned"] = {"error": repr(e)}
+        # the round-3/4 schedule of the same step (first tile on the LOW positions: initialising pass, read+write
+        # pass, measuring pass -- QMLE_NO_TOP_FIRST=1, read per compile): what BENCH_r03 / r04 measured, kept as a
+        # companion so that the two-pass headline can be read against it (more bytes at a higher HBM fraction)
+        try:
+            from qml_essentials_amd import simulation as _sim
+
+            os.environ["QMLE_NO_TOP_FIRST"] = "1"
+            _sim.clear_plan_cache()
+            try:
+                tp = timed_k2(n, B, size, 5, 2, head_flags)
+            finally:
+                os.environ.pop("QMLE_NO_TOP_FIRST", None)
+                _sim.clear_plan_cache()
+            t3 = summarize(tp, True)
+            r3 = roofline_of(tp, True, None)
+            result["k2_three_pass"] = {
+                "ms_per_step": t3["ms_per_step"], "gate_applies_per_s": t3["gate_applies_per_s"],
+                "hbm_passes_per_state": t3["hbm_passes_per_state"], "moved_frac_of_8TBps": t3["moved_frac_of_8TBps"],
+                "candidate": tp["desc"].get("candidate"),
+                "roofline": {k: r3[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                "per_pass": [{k: p_[k] for k in ("pass", "avg_launch_ms", "moved_GBps")} for p_ in per_pass(tp, True)],
+                "max_abs_diff_vs_headline_expvals": float((tp["out"] - head["out"]).abs().max()),
+                "note": "QMLE_NO_TOP_FIRST=1: the schedule the cost model picked before round 5's top-first candidates"}
+            del tp
+        except Exception as e:  # pragma: no cover
+            result["k2_three_pass"] = {"error": repr(e)}
         # the default engine on the same workload: exact, but specific to what a one-layer circuit
         # from |0..0> leaves untouched (known zeros never read / computed / stored, trailing CX layer
         # folded into Z-parity observables) -- NOT a throughput figure for gate application
@@ -1394,8 +1434,14 @@ def summary_of(r):
     out = {"k2_headline": {"ms_per_step": r.get("ms_per_step"), "gate_applies_per_s": r.get("value"),
                            "frac": g(r, "roofline", "frac"), "kernel": g(r, "roofline", "kernel"),
                            "per_pass_ms": [p["avg_launch_ms"] for p in g(r, "roofline", "per_pass", default=[])]}}
+    out["k2_headline"]["time_share_by_bound"] = g(r, "roofline", "time_share_by_bound")
+    out["k2_headline"]["valu_frac"] = g(r, "roofline", "valu", "frac")
+    out["k2_headline"]["step_moved_frac"] = r.get("step_moved_frac_of_8TBps")
     if isinstance(r.get("k2_autotuned"), dict):
         out["k2_autotuned"] = {"ms_per_step": g(r, "k2_autotuned", "ms_per_step"), "error": g(r, "k2_autotuned", "error")}
+    if isinstance(r.get("k2_three_pass"), dict):
+        out["k2_three_pass"] = {"ms_per_step": g(r, "k2_three_pass", "ms_per_step"), "frac": g(r, "k2_three_pass", "roofline", "frac"),
+                                "error": g(r, "k2_three_pass", "error")}
     for key in ("k2_unfused", "k2_circuit19"):
         if isinstance(r.get(key), dict):
             out[key] = {"ms_per_step": g(r, key, "ms_per_step"), "frac": g(r, key, "roofline", "frac"),

@@ -113,6 +113,8 @@ struct Stage {
   int op_begin = 0, op_end = 0;  // range in Plan::dev_ops
   int grp_begin = 0, grp_end = 0;  // range in Plan::op_groups (tile stages)
   int T = 0, L = 0;              // tile qubits, contiguous low bits
+  int shift = 0;                 // > 0: the tile is the contiguous run of positions [shift, shift + T) (L = T; the
+                                 // first stage of a top-first schedule: one tile per state, stored amplitude by amplitude)
   int n_tile_ops = 0;
   int8_t tile_bits[QMLE_MAX_QUBITS];   // ascending global positions of local bits
   int8_t outer_bits[QMLE_MAX_QUBITS];  // ascending global positions of the rest

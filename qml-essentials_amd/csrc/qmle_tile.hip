@@ -152,7 +152,7 @@ __global__ void k_tile(const TileArgs a) {
     tile_mw_row(lds_offset_of(s), T, (uint32_t)tid, reinterpret_cast<float *>(s),
                 reinterpret_cast<float *>(a.out) + ((size_t)b * gridDim.x + tile) * kMwFusedRow, a.mw_lean != 0);
   } else {
-    tile_epilogue<false>(a, s, lut, red, tile, gridDim.x, b, base);
+    tile_epilogue<false, false, true>(a, s, lut, red, tile, gridDim.x, b, base);
   }
 }
 
@@ -1754,6 +1754,8 @@ int launch_tile(const qmle_plan *p, const Stage &st, float2 *states, const float
     a.compact = 1;  // grid = the tiles that can be non-zero = tile 0
     a.tile_free = 0u;
     grid.x = 1u;
+  } else if (st.shift) {
+    return QMLE_ERR_UNSUPPORTED;  // a top-first tile exists as the filled first pass of a run from |0..0> only
   }
   if (from_zero && meas == TM_STORE && st.next_tile) {
     // the zero tiles are not even launched: the next tile stage never reads them

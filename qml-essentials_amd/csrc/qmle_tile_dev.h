@@ -237,6 +237,7 @@ struct TileArgs {
   uint32_t zin_local, zin_outer, tile_free;
   int compact;
   int nt;  // the launch streams >= 1 GiB of states: non-temporal tile loads / stores
+  int shift;    // > 0: the tile is positions [shift, shift + T) (Stage::shift): amplitude j lives at j << shift
   int mw_lean;  // TM_STORE_MW of a tiled state: no cross terms for local bits 0..3 (= positions 0..3, which every
                 // later read holds too: k_mw_read_later<.., LOW> reports them), populations out of the second gather
   int8_t tile_bits[QMLE_MAX_QUBITS];
@@ -421,8 +422,9 @@ __device__ __forceinline__ void tile_compute(const TileArgs &a, float2 *s, const
 }
 
 // Store / measure the finished tile.  n_tiles = tiles per state.
-template <bool RAW, bool PARTIAL_ONLY = false>  // PARTIAL_ONLY: a.meas is TM_EXPVAL_PARTIAL (k_tile2's
+template <bool RAW, bool PARTIAL_ONLY = false,  // PARTIAL_ONLY: a.meas is TM_EXPVAL_PARTIAL (k_tile2's
                                                  // multi-tile instantiation keeps its register budget)
+          bool SHIFTED = false>                  // the caller may be handed a Stage::shift tile (k_tile only)
 __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, const uint32_t *lut,
                                               float *red, uint32_t tile, uint32_t n_tiles, int b,
                                               uint64_t base, int qsrc_of_thread = -1) {
@@ -433,7 +435,11 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, float2 *s, cons
   const uint32_t lowmask = (1u << L) - 1u;
   float2 *st = a.states + (size_t)b * D;
   if (!PARTIAL_ONLY && (a.meas == TM_STORE || a.meas == TM_STORE_MW)) {
-    if ((half % (8u * nt)) == 0) {
+    if (SHIFTED && a.shift) {
+      // the one tile per state of a top-first schedule: its amplitudes sit 2^shift apart, one 8-byte store each
+      // (2^14 of them per state, behind the fill that wrote the zeros; launch_tile admits no other use)
+      for (uint32_t j = tid; j < (1u << T); j += nt) st[(uint64_t)j << a.shift] = s[sw(j)];
+    } else if ((half % (8u * nt)) == 0) {
       for (uint32_t j0 = tid; j0 < half; j0 += 8u * nt) {
         float4 v[8];
 #pragma unroll
@@ -849,6 +855,7 @@ static TileArgs fill_tile_args(const qmle_plan *p, const Stage &st, float2 *stat
   a.n = p->n;
   a.T = st.T;
   a.L = st.L;
+  a.shift = st.shift;
   a.n_slots = p->n_slots;
   a.init_zero = init_zero ? 1 : 0;
   a.meas = meas;

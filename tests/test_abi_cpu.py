@@ -187,22 +187,34 @@ def test_xor_addressed_tile_kernels_have_no_static_lds():
     assert N.lib().qmle_status_string(-12).decode().startswith("internal invariant")
 
 
-def test_from_zero_variant_of_the_all_live_k2_plan():
-    """Plan compiler, host only (round 3).  qmle_run_batch always starts from |0..0>, where the
-    first stage computes ONE tile per state whatever the tile size: the plan it executes (the
-    from-zero variant, reported by executed()) may stage 2^14
-    amplitudes first, and carries bit position 6 so that the read+write pass's tile is {0-3, 6,
-    13-19} -- the shape that streams 15 % faster.  The plan's own stages, which
-    qmle_apply_inplace and the adjoint sweep apply to LIVE states, keep the round-2 schedule."""
+def test_from_zero_variant_of_the_all_live_k2_plan(monkeypatch):
+    """Plan compiler, host only.  qmle_run_batch always starts from |0..0>, where the first stage computes
+    ONE tile per state whatever the tile: the plan it executes (the from-zero variant, reported by executed())
+    stages 2^14 amplitudes first.  Round 5: on the TOP 14 positions {10..23} (Stage::shift), which leaves the
+    low positions, the deferred CX(10 -> 9) and the wrap-around CX(0 -> 23) to ONE measuring pass on {0..10, 23}
+    -- two passes.  Round 3's schedule (first tile on {0..13}, position 6 carried so that the read+write pass's
+    tile is {0-3, 6, 13-19}, three passes) is candidate 26.  The plan's own stages, which qmle_apply_inplace and
+    the adjoint sweep apply to LIVE states, keep the round-2 schedule."""
     ops, slots = he_layer_ops(24)
     top = N.Plan(ops, 24, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
     own = top.describe()
     assert own["zero_run"] is False and [s["T"] for s in own["stages"]] == [12, 12, 12]
+    assert all(s["shift"] == 0 for s in own["stages"])
     assert [sum(g["n_ops"] for g in s["fast_groups"]) for s in own["stages"]] == [12, 8, 4]
     assert top.expval_child() is None   # NO_ABSORB: nothing folded; executed() names the variant
     var = top.executed("expval")
     assert var is not top
     d = var.describe()
+    assert d["zero_run"] is True and d["model_cost"] < own["model_cost"] and d["candidate"] >= 48
+    st = d["stages"]
+    assert len(st) == 2 and [s["T"] for s in st] == [14, 12] and [s["shift"] for s in st] == [10, 0]
+    assert st[0]["bits"] == list(range(10, 24)) and not st[0]["fast"]   # one tile per state, generic kernel
+    assert st[1]["bits"] == list(range(11)) + [23] and st[1]["fast"] and len(st[1]["fast_groups"]) == 3
+    assert sorted(o for s in st for o in s["src_ops"]) == list(range(96))
+    # the round-3 schedule, still a candidate (what QMLE_NO_TOP_FIRST=1 falls back to)
+    monkeypatch.setenv("QMLE_FORCE_CAND", "26")
+    d = N.Plan(ops, 24, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB).executed("expval").describe()
+    monkeypatch.delenv("QMLE_FORCE_CAND")
     assert d["zero_run"] is True and d["model_cost"] < own["model_cost"]
     st = d["stages"]
     assert len(st) == 3 and [s["T"] for s in st] == [14, 12, 12]
@@ -343,8 +355,8 @@ def test_philox_sampler_is_numpys_stream_bit_for_bit():
 
 
 def test_every_schedule_candidate_places_every_gate_exactly_once(monkeypatch):
-    """Plan-compiler invariant, all 48 candidates (tile geometry x lazy CX x wide first tile / carried
-    position 6) and the last-stage padding switch: whatever the schedule, the stages' `src_ops` are a
+    """Plan-compiler invariant, all 60 candidates (tile geometry x lazy CX x wide first tile / carried
+    position 6 / first tile on the top positions) and the last-stage padding switch: whatever the schedule, the stages' `src_ops` are a
     permutation of the tape -- no gate dropped, none applied twice -- and the tile of every stage
     holds the positions its gates act on (wire w <-> position n - 1 - w)."""
     n = 20
@@ -357,10 +369,14 @@ def test_every_schedule_candidate_places_every_gate_exactly_once(monkeypatch):
     for pad in (None, "1"):
         if pad:
             monkeypatch.setenv("QMLE_PAD_HIGH", pad)
-        for k in range(48):
+        for k in range(60):  # (48..59: the first tile on the top 14 positions -- tuner candidates, round 5)
             monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
             top = N.Plan(ops, n, slots, flags=N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)
             d = top.executed("expval").describe()
+            if k >= 48:
+                assert d["candidate"] == k and d["stages"][0]["shift"] == n - 14
+            else:
+                assert all(st.get("shift", 0) == 0 for st in d["stages"])
             placed = sorted(s for st in d["stages"] for s in st["src_ops"])
             assert placed == list(range(len(ops))), (k, pad)
             for st in d["stages"]:

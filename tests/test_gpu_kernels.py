@@ -894,8 +894,8 @@ def test_multi_tile_walk_over_known_zeros_inside_the_tile(layers, monkeypatch):
 
 
 def test_every_schedule_candidate_gives_the_same_result(monkeypatch):
-    """All 48 schedule candidates of the plan compiler (QMLE_FORCE_CAND; tile geometry x lazy CX x
-    wide first tile / carried position 6), with and without the last-stage padding switch, on one
+    """All 60 schedule candidates of the plan compiler (QMLE_FORCE_CAND; tile geometry x lazy CX x
+    wide first tile / carried position 6 / first tile on the top positions), with and without the last-stage padding switch, on one
     3-layer circuit at n = 18: state and <Z> equal the model-chosen schedule's at float32 level and
     the fp64 oracle's <Z> -- the rarely chosen geometries (L = 5..7 rows, T = 13 with a carried
     position) run the same kernels as the common ones."""
@@ -918,18 +918,22 @@ def test_every_schedule_candidate_gives_the_same_result(monkeypatch):
     pr = (np.abs(psi) ** 2).reshape((2,) * n)
     z = np.array([pr.take(0, axis=w).sum() - pr.take(1, axis=w).sum() for w in range(n)])
     assert np.abs(want_z[0].cpu().numpy() - z).max() < 1e-6
-    shapes = set()
+    shapes, top_first = set(), set()
     for pad in (None, "1"):
         if pad:
             monkeypatch.setenv("QMLE_PAD_HIGH", pad)
-        for k in range(48):
+        for k in range(60):  # (48..59, round 5: first tile on the TOP 14 positions, stored amplitude by amplitude)
             monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
             p = N.Plan(ops, n, slots, flags=flags)
             d = p.executed("expval").describe()
             shapes.add(tuple(tuple(st["bits"]) for st in d["stages"]))
+            if k >= 48:
+                assert d["candidate"] == k and d["stages"][0]["shift"] == n - 14, (k, d["candidate"])
+                assert d["stages"][0]["bits"] == list(range(n - 14, n))
+                top_first.add(len(d["stages"]))
             assert (p.run(ang, "state") - want_s).abs().max().item() < 1e-6, (k, pad)
             assert (p.run(ang, "expval", list(range(n))) - want_z).abs().max().item() < 1e-6, (k, pad)
-    assert len(shapes) >= 8
+    assert len(shapes) >= 8 and top_first
 
 
 @pytest.mark.parametrize("layers", [1, 2])
