@@ -1167,3 +1167,45 @@ def test_dense_4x4_operators_absorb_their_neighbours_and_run_in_register_tiles(n
         idx = np.arange(1 << n)
         ref = [float((pr * (1 - 2 * ((idx >> (n - 1 - q)) & 1))).sum()) for q in range(n)]
         assert np.abs(z[b] - np.array(ref)).max() < 2e-6, (b, n)
+
+
+@pytest.mark.parametrize("n", [16, 17, 19, 22, 25])
+def test_first_tile_on_the_top_positions_every_register_size(n, monkeypatch):
+    """Round 5: candidates 48..59 put the one tile a run from |0..0> computes per state on the TOP
+    14 positions (amplitude j of the tile at address j << shift, one 8-byte store each, behind the zero fill) and
+    schedule the rest on the low positions.  From the smallest register that admits it (shift = 2) upwards, two
+    geometries each: the state and <Z> equal the round-4 schedule's (QMLE_NO_TOP_FIRST=1) bit for float32 rounding,
+    the state equals the oracle's C port, and a batch of distinct parameter sets stays distinct."""
+    from oracle import c_port
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    layers = 2 if n <= 22 else 1
+    ops, slots = [], 0
+    for _ in range(layers):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    ops += [("CRX", [0, n - 1], [0], -1), ("RZ", [n // 2], [1], -1), ("H", [1], [], -1), ("CX", [n - 1, 2], [], -1)]
+    B = 3 if n <= 22 else 2
+    ang = np.random.default_rng(n).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)
+    angd = torch.from_numpy(ang).cuda()
+    flags = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
+    monkeypatch.setenv("QMLE_NO_TOP_FIRST", "1")
+    ref = N.Plan(ops, n, slots, flags=flags)
+    assert all(st["shift"] == 0 for st in ref.executed("state").describe()["stages"])
+    want_s, want_z = ref.run(angd, "state"), ref.run(angd, "expval", list(range(n)))
+    monkeypatch.delenv("QMLE_NO_TOP_FIRST")
+    assert (want_s[0] - want_s[1]).abs().max().item() > 1e-3
+    if n <= 22:
+        tape = [(g, w, [float(ang[1, s]) for s in sl]) for g, w, sl, _ in ops]
+        psi = c_port.simulate(oracle_tape(tape, n), n)
+        assert np.abs(want_s[1].cpu().numpy() - psi).max() < 1e-6
+    for k in (50, 57):
+        monkeypatch.setenv("QMLE_FORCE_CAND", str(k))
+        p = N.Plan(ops, n, slots, flags=flags)
+        d = p.executed("state").describe()
+        assert d["candidate"] == k and d["stages"][0]["shift"] == n - 14 and len(d["stages"]) >= 2, (k, d["candidate"])
+        assert (p.run(angd, "state") - want_s).abs().max().item() < 1e-6, (n, k)
+        assert (p.run(angd, "expval", list(range(n))) - want_z).abs().max().item() < 1e-6, (n, k)
+        monkeypatch.delenv("QMLE_FORCE_CAND")
