@@ -1215,6 +1215,10 @@ def main(argv=None):
         roofline["time_share_by_bound"] = share
         roofline["nearest_bound_by_time"] = top_bound
         roofline["valu"] = valu_roofline(head, True)
+        roofline["counters_note"] = ("SQ counters of the same plan (profiles/r05_k2_headline_sq.txt): the measuring k_tile2 pass "
+                                     "issues vector instructions 69 % of its cycles (81 % of them the packed FMAs of its 11 dense "
+                                     "2x2 gates), LDS 35 % busy with 20 % bank conflicts: nearer the vector unit than HBM, whatever "
+                                     "the nominal-flops fraction above says; the initialising pass is a 6.4 TB/s fill")
     except Exception as e:  # pragma: no cover
         roofline["per_pass_both_sides"] = {"error": repr(e)}
     result = {
