@@ -1220,6 +1220,10 @@ def main(argv=None):
         roofline["time_share_by_bound"] = share
         roofline["nearest_bound_by_time"] = top_bound
         roofline["valu"] = valu_roofline(head, True)
+        roofline["overlap_note"] = ("two chunks of 32 states are in flight, one stage apart, on two internal streams (the fill of one "
+                                    "beside the measuring pass of the other): avg_launch_ms / achieved / frac above are live HIP-event "
+                                    "figures of launches that share the card; `isolated_launch` has the same kernel alone, "
+                                    "step_moved_frac_of_8TBps the bytes of the whole step over its wall-clock")
         roofline["counters_note"] = ("SQ counters of the same plan (profiles/r05_k2_headline_sq.txt): the measuring k_tile2 pass "
                                      "issues vector instructions 69 % of its cycles (81 % of them the packed FMAs of its 11 dense "
                                      "2x2 gates), LDS 35 % busy with 20 % bank conflicts: nearer the vector unit than HBM, whatever "
@@ -1290,6 +1294,29 @@ def main(argv=None):
             del tn
         except Exception as e:  # pragma: no cover
             result["k2_autotuned"] = {"error": repr(e)}
+        # the same step with its chunks on ONE stream (QMLE_NO_CHUNK_OVERLAP=1, read per call): the kernels' launch
+        # durations in isolation -- in the headline two chunks are in flight one stage apart, so a launch shares the card
+        # with the other chunk's pass and its HIP-event duration is longer than the kernel needs alone
+        try:
+            os.environ["QMLE_NO_CHUNK_OVERLAP"] = "1"
+            try:
+                t1 = timed_k2(n, B, size, 5, 2, head_flags)
+            finally:
+                os.environ.pop("QMLE_NO_CHUNK_OVERLAP", None)
+            s1 = summarize(t1, True)
+            r1 = roofline_of(t1, True, None)
+            result["k2_one_stream"] = {
+                "ms_per_step": s1["ms_per_step"], "gate_applies_per_s": s1["gate_applies_per_s"],
+                "moved_frac_of_8TBps": s1["moved_frac_of_8TBps"],
+                "roofline": {k: r1[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
+                "per_pass": [{k: p_[k] for k in ("pass", "avg_launch_ms", "moved_GBps")} for p_ in per_pass(t1, True)],
+                "max_abs_diff_vs_headline_expvals": float((t1["out"] - head["out"]).abs().max()),
+                "note": "QMLE_NO_CHUNK_OVERLAP=1: chunks one after the other on the caller's stream (rounds 1-4)"}
+            roofline["isolated_launch"] = {"avg_launch_ms": r1["avg_launch_ms"], "achieved": r1["achieved"], "frac": r1["frac"],
+                                           "note": "the dominant kernel's launches with nothing else on the card (k2_one_stream)"}
+            del t1
+        except Exception as e:  # pragma: no cover
+            result["k2_one_stream"] = {"error": repr(e)}
         # the round-3/4 schedule of the same step (first tile on the LOW positions: initialising pass, read+write
         # pass, measuring pass -- QMLE_NO_TOP_FIRST=1, read per compile): what BENCH_r03 / r04 measured, kept as a
         # companion so that the two-pass headline can be read against it (more bytes at a higher HBM fraction)
@@ -1448,6 +1475,9 @@ def summary_of(r):
     out["k2_headline"]["step_moved_frac"] = r.get("step_moved_frac_of_8TBps")
     if isinstance(r.get("k2_autotuned"), dict):
         out["k2_autotuned"] = {"ms_per_step": g(r, "k2_autotuned", "ms_per_step"), "error": g(r, "k2_autotuned", "error")}
+    if isinstance(r.get("k2_one_stream"), dict):
+        out["k2_one_stream"] = {"ms_per_step": g(r, "k2_one_stream", "ms_per_step"), "frac": g(r, "k2_one_stream", "roofline", "frac"),
+                                "error": g(r, "k2_one_stream", "error")}
     if isinstance(r.get("k2_three_pass"), dict):
         out["k2_three_pass"] = {"ms_per_step": g(r, "k2_three_pass", "ms_per_step"), "frac": g(r, "k2_three_pass", "roofline", "frac"),
                                 "error": g(r, "k2_three_pass", "error")}

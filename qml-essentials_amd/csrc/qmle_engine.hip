@@ -424,6 +424,43 @@ static size_t mw_ws_bytes(const qmle_plan *p, int batch) {
   return align_up(one, 256) * (size_t)batch;
 }
 
+// Round 5: consecutive chunks of a batch are independent (own states, own partial sums), and their passes want
+// different things from the GPU -- the zero fill HBM writes, the one-tile-per-state kernel 32 workgroups, a measuring
+// pass the vector unit.  Two processes sharing the card ran the all-live K2 step 18 % faster than one (1.93 against 1.63 M
+// gate-applies/s); the same overlap inside one call: chunks alternate between two internal streams that fork from the
+// caller's stream and join it again.  QMLE_NO_CHUNK_OVERLAP=1: the one-stream loop (read per call).
+static bool chunk_overlap_on() { return std::getenv("QMLE_NO_CHUNK_OVERLAP") == nullptr; }
+constexpr int kPipeStages = 32;
+struct SideStreams {
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  // software pipeline: stage k of chunk i + 1 starts when stage k of chunk i is done -- two chunks in lockstep
+  // (fill next to fill, measuring pass next to measuring pass) share the card evenly and gain nothing; one stage
+  // apart, the HBM-bound pass of one chunk runs beside the vector-bound pass of the other
+  hipEvent_t stage_done[2][kPipeStages] = {};
+  bool ok = false;
+};
+static SideStreams *side_streams() {
+  static SideStreams per_dev[kMaxDevices];
+  static std::mutex mu;
+  const int dev = current_device();
+  if (dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStreams &x = per_dev[dev];
+  if (!x.ok) {
+    bool good = hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 && good; ++k) {
+      good = hipStreamCreateWithFlags(&x.s[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&x.join[k], hipEventDisableTiming) == hipSuccess;
+      for (int e = 0; e < kPipeStages && good; ++e)
+        good = hipEventCreateWithFlags(&x.stage_done[k][e], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!good) { (void)hipGetLastError(); return nullptr; }
+    x.ok = true;
+  }
+  return &x;
+}
+
 static size_t per_state_ws_bytes(const qmle_plan *p, int meas_type) {
   size_t b = align_up((size_t)8 << p->n, 256);
   if (meas_type == QMLE_MEAS_EXPVAL_Z)
@@ -442,7 +479,10 @@ size_t qmle::workspace_bytes_one(const qmle_plan *plan, int batch, int meas_type
   if (meas_type != QMLE_MEAS_STATE && !lds_direct_meas) {
     int s = states_in_flight > 0 ? states_in_flight : default_states_in_flight(plan, batch);
     if (s > batch) s = batch;
-    total += (size_t)s * per_state_ws_bytes(plan, meas_type);
+    // (a batch of several chunks runs them alternately on two internal streams, each with its own state / partial
+    // buffers -- chunk_overlap below; a caller that hands in less gets the one-stream loop)
+    const int slots = (s < batch && chunk_overlap_on()) ? 2 : 1;
+    total += (size_t)slots * (size_t)s * per_state_ws_bytes(plan, meas_type);
   }
   return total;
 }
@@ -644,6 +684,29 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
     ws += (size_t)in_flight * align_up(sb, 256);
   }
   if (in_flight > 65535) in_flight = 65535;
+  // two slots (state buffer + partial sums each) when the batch has several chunks and the workspace has room
+  const float2 *const d_states0_dbg = d_states;
+  SideStreams *side = nullptr;
+  char *slot1 = nullptr;
+  if (in_flight < batch && chunk_overlap_on()) {
+    if (meas_type == QMLE_MEAS_STATE) {
+      // every chunk writes its own rows of d_out; partial sums are not used
+      side = side_streams();
+    } else {
+      // (`workspace_bytes` is what was left when the state buffers were carved: they start at d_states.  A workspace
+      // sized by qmle_workspace_bytes holds two slots of the chunk it was asked for; one that holds less is split in two)
+      const size_t per = per_state_ws_bytes(plan, meas_type);
+      int two = (int)std::min<size_t>(workspace_bytes / per / 2, 65535);
+      const int dflt = default_states_in_flight(plan, batch);
+      if (two > dflt) two = dflt;
+      if (two >= 1 && (side = side_streams()) != nullptr) {
+        // the partial sums sit behind the state block of `in_flight` states: re-carve slot 0 for `two`
+        in_flight = two;
+        slot1 = (char *)d_states + (size_t)two * per;
+        ws = (char *)d_states + (size_t)two * align_up(sb, 256);
+      }
+    }
+  }
   void *d_partial = ws;
   const size_t partial_bytes =
       (size_t)in_flight * expval_partial_rows(plan) * (QMLE_MAX_QUBITS + 1) * sizeof(float);
@@ -653,8 +716,44 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
   const bool fuse_mw = meas_type == QMLE_MEAS_MEYER_WALLACH && plan_mw_fusable(plan);
   const size_t mw_bytes = meas_type == QMLE_MEAS_MEYER_WALLACH ? mw_ws_bytes(plan, in_flight) : 0;
 
-  for (int b0 = 0; b0 < batch; b0 += in_flight) {
+  if (std::getenv("QMLE_DBG_OVERLAP"))
+    fprintf(stderr, "[qmle] chunks of %d of %d states, overlap %s (slot1 %p, ws %zu bytes, used before the states %zu, two slots %zu)\n",
+            in_flight, batch, side ? "on" : "off", (void *)slot1, workspace_bytes,
+            (size_t)((char *)d_states0_dbg - (char *)d_workspace), 2 * (size_t)in_flight * per_state_ws_bytes(plan, meas_type));
+  hipStream_t const caller_stream = stream;
+  if (side) {  // fork: what the caller's stream has queued so far (the matrices, the angle table) comes first
+    if (hipEventRecord(side->fork, caller_stream) != hipSuccess ||
+        hipStreamWaitEvent(side->s[0], side->fork, 0) != hipSuccess ||
+        hipStreamWaitEvent(side->s[1], side->fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      side = nullptr;
+    }
+  }
+  float2 *const d_states0 = d_states;
+  void *const d_partial0 = d_partial;
+  auto join_side = [&]() {
+    if (!side) return;
+    for (int k = 0; k < 2; ++k)
+      if (hipEventRecord(side->join[k], side->s[k]) == hipSuccess)
+        (void)hipStreamWaitEvent(caller_stream, side->join[k], 0);
+  };
+  struct JoinGuard {  // (also on the error returns inside the loop)
+    decltype(join_side) &f;
+    ~JoinGuard() { f(); }
+  } join_guard{join_side};
+  int chunk_no = 0;
+  for (int b0 = 0; b0 < batch; b0 += in_flight, ++chunk_no) {
     const int bc = batch - b0 < in_flight ? batch - b0 : in_flight;
+    if (side) {
+      stream = side->s[chunk_no & 1];
+      if (slot1 && (chunk_no & 1)) {
+        d_states = (float2 *)slot1;
+        d_partial = slot1 + ((char *)d_partial0 - (char *)d_states0);
+      } else {
+        d_states = d_states0;
+        d_partial = d_partial0;
+      }
+    }
     float2 *stc = meas_type == QMLE_MEAS_STATE ? d_states + (size_t)b0 * D : d_states;
     const float *mats = d_mats + (size_t)b0 * plan->mat_floats;
     const float *ang = d_angles ? d_angles + (size_t)b0 * plan->n_slots : nullptr;
@@ -663,6 +762,13 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
     int tile_row_shift = 0;  // k_tile2's multi-tile measuring variant: 2^shift tiles per row
     for (size_t si = 0; si < plan->stages.size(); ++si) {
       const Stage &st = plan->stages[si];
+      const bool piped = side && plan->stages.size() <= (size_t)kPipeStages;
+      if (piped && chunk_no > 0)  // behind the same stage of the previous chunk (the other stream)
+        (void)hipStreamWaitEvent(stream, side->stage_done[(chunk_no - 1) & 1][si], 0);
+      struct StageDone {  // recorded when the stage's launches are queued (any exit from this iteration)
+        hipEvent_t ev; hipStream_t st_;
+        ~StageDone() { if (ev) (void)hipEventRecord(ev, st_); }
+      } stage_done{piped ? side->stage_done[chunk_no & 1][si] : nullptr, stream};
       ProfScope prof_scope(plan, (int)si, stream);
       if (st.kind == ST_TILE && fuse_mw && si + 1 == plan->stages.size()) {
         // the last pass stores the state AND reports its tile's Meyer-Wallach sums (one row per tile)

@@ -73,7 +73,10 @@ def estimate_peak_bytes(n_qubits: int, batch_size: int, type: str, use_density: 
         in_flight = 0  # whole state lives in LDS, never in HBM
     else:
         target = F64_IN_FLIGHT_TARGET_BYTES if x64 else IN_FLIGHT_TARGET_BYTES
-        in_flight = min(batch_size, max(1, target // state)) * state
+        per_chunk = max(1, target // state)
+        in_flight = min(batch_size, per_chunk) * state
+        if not x64 and batch_size > per_chunk:
+            in_flight *= 2  # (round 5: a batch of several chunks alternates between two sets of state buffers)
     mats = batch_size * max(n_ops, 1) * (64 if x64 else 32)
     return int(1.1 * (out + in_flight + mats)) + (1 << 20)
 

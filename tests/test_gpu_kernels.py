@@ -1209,3 +1209,35 @@ def test_first_tile_on_the_top_positions_every_register_size(n, monkeypatch):
         assert (p.run(angd, "state") - want_s).abs().max().item() < 1e-6, (n, k)
         assert (p.run(angd, "expval", list(range(n))) - want_z).abs().max().item() < 1e-6, (n, k)
         monkeypatch.delenv("QMLE_FORCE_CAND")
+
+
+@pytest.mark.parametrize("n,flags", [(16, 0), (18, 128 | 32), (20, 128)])
+def test_chunks_of_a_batch_on_two_streams_give_the_one_stream_results(n, flags, monkeypatch):
+    """Round 5: a batch that needs several chunks runs them alternately on two internal streams, one stage apart
+    (own state / partial-sum buffers per stream; the caller's stream forks and joins).  Seven chunks of three states
+    (states_in_flight = 3) for every measurement: bit-identical to the one-stream loop (QMLE_NO_CHUNK_OVERLAP=1) and
+    to the single-chunk run, with work queued on the caller's stream before and after the call."""
+    from qml_essentials_amd import _native as N
+    from tests.test_abi_cpu import he_layer_ops
+
+    ops, slots = [], 0
+    for _ in range(2):
+        o, s_ = he_layer_ops(n)
+        ops += [(g, w, [x + slots for x in sl], m) for g, w, sl, m in o]
+        slots += s_
+    B = 20
+    ang = torch.from_numpy(np.random.default_rng(5 * n).uniform(0, 2 * np.pi, (B, slots)).astype(np.float32)).cuda()
+    plan = N.Plan(ops, n, slots, flags=flags)
+    for meas, obs in (("expval", list(range(n))), ("state", ()), ("probs", ()), ("mw", ())):
+        whole = plan.run(ang, meas, obs).clone()
+        scratch = torch.zeros(1 << 20, device="cuda")
+        scratch += 1.0                                   # (queued on the caller's stream before the call)
+        piped = plan.run(ang, meas, obs, states_in_flight=3).clone()
+        scratch *= 2.0
+        monkeypatch.setenv("QMLE_NO_CHUNK_OVERLAP", "1")
+        serial = plan.run(ang, meas, obs, states_in_flight=3).clone()
+        monkeypatch.delenv("QMLE_NO_CHUNK_OVERLAP")
+        assert torch.equal(piped, serial), (meas, (piped - serial).abs().max().item())
+        assert (piped - whole).abs().max().item() < 1e-6, meas
+        assert float(scratch[0]) == 2.0 and float(scratch[-1]) == 2.0
+        assert (piped[0] - piped[1]).abs().max().item() > 1e-4   # rows are distinct parameter sets
