@@ -1324,11 +1324,13 @@ def main(argv=None):
             from qml_essentials_amd import simulation as _sim
 
             os.environ["QMLE_NO_TOP_FIRST"] = "1"
+            os.environ["QMLE_NO_CHUNK_OVERLAP"] = "1"
             _sim.clear_plan_cache()
             try:
                 tp = timed_k2(n, B, size, 5, 2, head_flags)
             finally:
                 os.environ.pop("QMLE_NO_TOP_FIRST", None)
+                os.environ.pop("QMLE_NO_CHUNK_OVERLAP", None)
                 _sim.clear_plan_cache()
             t3 = summarize(tp, True)
             r3 = roofline_of(tp, True, None)
@@ -1339,7 +1341,7 @@ def main(argv=None):
                 "roofline": {k: r3[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")},
                 "per_pass": [{k: p_[k] for k in ("pass", "avg_launch_ms", "moved_GBps")} for p_ in per_pass(tp, True)],
                 "max_abs_diff_vs_headline_expvals": float((tp["out"] - head["out"]).abs().max()),
-                "note": "QMLE_NO_TOP_FIRST=1: the schedule the cost model picked before round 5's top-first candidates"}
+                "note": "QMLE_NO_TOP_FIRST=1 QMLE_NO_CHUNK_OVERLAP=1: the schedule the cost model picked before round 5's top-first candidates, chunks on one stream -- the step as rounds 3-4 ran it"}
             del tp
         except Exception as e:  # pragma: no cover
             result["k2_three_pass"] = {"error": repr(e)}
