@@ -295,7 +295,7 @@ def load_traffic(key, path=None, sha=None):
     return rec["hbm_bytes_per_launch"], rec.get("source"), rec.get("states_per_launch"), None
 
 
-def roofline_of(run, dense, traffic_key=None):
+def roofline_of(run, dense, traffic_key=None, prefer=None):
     """`roofline` object of a K2-style run.  achieved / frac are BYTES REALLY MOVED by the dominant
     kernel's launches (the plan compiler's per-pass read + write bytes, which the PMC counters in
     profiles/ confirm) / its HIP-event launch time / the 8 TB/s peak -- a fraction <= 1.  The
@@ -303,6 +303,11 @@ def roofline_of(run, dense, traffic_key=None):
     the bytes moved is the fusion factor (reference gates applied per HBM round trip)."""
     fam = families(run, dense)
     name = max(fam, key=lambda k: fam[k]["ms"])
+    if prefer in fam and fam[prefer]["ms"] >= 0.8 * fam[name]["ms"]:
+        # (chunks in flight on two streams: the initialising pass's launches stretch while they share the card with the
+        # other chunk's measuring pass, and which family's summed HIP-event time is larger flips from run to run; the
+        # kernel the PMC record belongs to stays the one reported)
+        name = prefer
     dom = fam[name]
     sec = dom["ms"] * 1e-3
     algo = dom["algo"] / sec / 1e9 if sec > 0 else 0.0
@@ -1208,7 +1213,7 @@ def main(argv=None):
     total_states = B * size * a.steps
     elapsed = head["elapsed"]
     hs = summarize(head, True)
-    roofline = roofline_of(head, True, None if a.no_fusion else f"k_tile2:n{n}:dense")
+    roofline = roofline_of(head, True, None if a.no_fusion else f"k_tile2:n{n}:dense", prefer="k_tile2")
     # Round 5: the step is two passes (first tile on the top positions, then ONE measuring pass that applies the
     # rest) instead of three: half the bytes, two thirds of the time -- and the measuring pass sits between HBM and
     # the vector unit.  Both sides per pass, and the time-weighted verdict, beside the bytes-moved figure above
@@ -1304,7 +1309,7 @@ def main(argv=None):
             finally:
                 os.environ.pop("QMLE_NO_CHUNK_OVERLAP", None)
             s1 = summarize(t1, True)
-            r1 = roofline_of(t1, True, None)
+            r1 = roofline_of(t1, True, None, prefer="k_tile2")
             result["k2_one_stream"] = {
                 "ms_per_step": s1["ms_per_step"], "gate_applies_per_s": s1["gate_applies_per_s"],
                 "moved_frac_of_8TBps": s1["moved_frac_of_8TBps"],
