@@ -163,7 +163,7 @@ def max_over_ranks(value):
 
 
 def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, profile=True,
-             circuit="Hardware_Efficient"):
+             circuit="Hardware_Efficient", isolate_passes=False):
     """`steps` timed calls of Model(n, layers, circuit) on B parameter sets per rank under plan flags
     `flags`; returns timing, the plan description and the per-stage HIP-event times (rank 0)."""
     from qml_essentials_amd import _native as N
@@ -206,12 +206,32 @@ def timed_k2(n, B, size, steps, warmup, flags, layers=1, dru=False, x=None, prof
         stage_ms = stage_cnt = overflow = None
         if profile and rank == 0:
             stage_ms, stage_cnt, overflow = plan.profile_end()
+        if isolate_passes and profile and size == 1:
+            # Round 5: a batch of several chunks keeps two of them in flight, one stage apart, on two streams: the
+            # wall-clock above is what a caller gets, but a launch's HIP-event duration then includes the share of
+            # the card the other chunk's pass took.  The per-pass figures (bytes / flops against their peaks) are about
+            # the kernels themselves: taken from the same steps with the chunks on one stream.
+            os.environ["QMLE_NO_CHUNK_OVERLAP"] = "1"
+            try:
+                step(); torch.cuda.synchronize()
+                plan.profile_begin(n_stages * max(8, B) * steps + 16)
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    out = step()
+                torch.cuda.synchronize()
+                elapsed_one_stream = time.perf_counter() - t1
+                stage_ms, stage_cnt, overflow = plan.profile_end()
+            finally:
+                os.environ.pop("QMLE_NO_CHUNK_OVERLAP", None)
+        else:
+            elapsed_one_stream = None
     per_rank = max_over_ranks(elapsed)
     elapsed = max(per_rank)
     assert tuple(out.reshape(-1, n).shape) == (B * size, n) and bool(torch.isfinite(out).all())
     return {"elapsed": elapsed, "elapsed_per_rank": per_rank, "out": out, "desc": desc,
             "n_gates": len(low.ops), "folded": folded,
             "stage_ms": stage_ms, "stage_cnt": stage_cnt, "overflow": overflow, "params": params,
+            "elapsed_one_stream": elapsed_one_stream,
             "flags": flags, "steps": steps, "B": B, "n": n}
 
 
@@ -367,7 +387,12 @@ def summarize(run, dense, count_gates=None):
         if i == len(desc["stages"]) - 1 and st["kind"] == "tile":
             m = st["read_bytes_from_zero"]
         moved += m
-    return {"ms_per_step": round(el / steps * 1e3, 3),
+    extra = {}
+    if run.get("elapsed_one_stream"):
+        extra = {"ms_per_step_one_stream": round(run["elapsed_one_stream"] / steps * 1e3, 3),
+                 "per_pass_note": "per-pass figures of this leg come from the same steps with the chunks on one stream "
+                                  "(QMLE_NO_CHUNK_OVERLAP=1); ms_per_step is the default: two chunks in flight, one stage apart"}
+    return {**extra, "ms_per_step": round(el / steps * 1e3, 3),
             "gate_applies_per_s": round(gates * B * size * steps / el, 1),
             "gates_counted_per_state": gates,
             "statevectors_per_s": round(B * size * steps / el, 2),
@@ -674,7 +699,7 @@ def k2_unfused_leg(n, B, steps=2):
     from qml_essentials_amd import _native as N
 
     fl = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB | N.PLAN_NO_FUSION | N.PLAN_NO_MERGE
-    run = timed_k2(n, B, 1, steps, 1, fl)
+    run = timed_k2(n, B, 1, steps, 1, fl, isolate_passes=True)
     desc = run["desc"]
     states = B * steps
     kinds = {}
@@ -779,7 +804,7 @@ def c2_leg(cpu_seconds=6.0):
     runs = {}
     for label, B, steps, fl in (("single_sample", 1, 40, 0), ("batch_256", 256, 8, 0), ("batch_1024", 1024, 4, 0),
                                 ("batch_1024_all_live", 1024, 4, N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB)):
-        run = timed_k2(n, B, 1, steps, 3, fl, layers=layers, dru=True, x=0.5)
+        run = timed_k2(n, B, 1, steps, 3, fl, layers=layers, dru=True, x=0.5, isolate_passes=True)
         dense = fl != 0
         sm = summarize(run, dense)
         rows = pass_table(run, dense)
@@ -853,7 +878,7 @@ def k2_circuit19_leg(n, B, size, steps, warmup):
     from qml_essentials_amd import _native as N
 
     fl = N.PLAN_NO_SPARSE | N.PLAN_NO_ABSORB
-    run = timed_k2(n, B, size, steps, warmup, fl, circuit="Circuit_19")
+    run = timed_k2(n, B, size, steps, warmup, fl, circuit="Circuit_19", isolate_passes=True)
     sm = summarize(run, True)
     rf = roofline_of(run, True, None)
     sm["operators_executed_per_state"] = run["desc"]["n_lowered"]
@@ -1353,7 +1378,7 @@ def main(argv=None):
         # the default engine on the same workload: exact, but specific to what a one-layer circuit
         # from |0..0> leaves untouched (known zeros never read / computed / stored, trailing CX layer
         # folded into Z-parity observables) -- NOT a throughput figure for gate application
-        sc = timed_k2(n, B, size, a.steps, a.warmup, 0)
+        sc = timed_k2(n, B, size, a.steps, a.warmup, 0, isolate_passes=True)
         s2 = summarize(sc, False)
         s2["roofline"] = {k: v for k, v in roofline_of(sc, False, None).items()
                           if k in ("kernel", "achieved", "frac", "algorithmic_GBps", "fusion_factor", "avg_launch_ms")}
@@ -1388,7 +1413,7 @@ def main(argv=None):
         try:
             deep = {}
             for label, fl in (("all_live", DENSE), ("default_flags", 0)):
-                d = timed_k2(n, B, size, 3, 1, fl, layers=4, dru=True, x=0.5)
+                d = timed_k2(n, B, size, 3, 1, fl, layers=4, dru=True, x=0.5, isolate_passes=True)
                 deep[label] = summarize(d, fl != 0)
                 deep[label]["operators_executed_per_state"] = d["desc"]["n_lowered"]
                 rf = roofline_of(d, fl != 0, None)

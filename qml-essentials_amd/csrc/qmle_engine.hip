@@ -688,7 +688,9 @@ int qmle::run_batch_masks(qmle_plan *plan, const float *d_angles, int batch, int
   const float2 *const d_states0_dbg = d_states;
   SideStreams *side = nullptr;
   char *slot1 = nullptr;
-  if (in_flight < batch && chunk_overlap_on()) {
+  // (one streaming pass per gate -- QMLE_PLAN_NO_FUSION -- is HBM-bound in every pass: two of them at once share the
+  // bandwidth and lose 2-3 % to the mix; those plans keep the one-stream loop)
+  if (in_flight < batch && chunk_overlap_on() && !(plan->flags & QMLE_PLAN_NO_FUSION)) {
     if (meas_type == QMLE_MEAS_STATE) {
       // every chunk writes its own rows of d_out; partial sums are not used
       side = side_streams();
