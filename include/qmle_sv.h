@@ -196,7 +196,12 @@ int qmle_plan_describe(const qmle_plan *plan, char *buf, size_t cap);
 int qmle_plan_stats(const qmle_plan *plan, int64_t stats[8]);
 
 /* Minimum workspace for `batch` samples and the bytes that let the engine keep
- * `states_in_flight` states resident (0 = engine default).  */
+ * `states_in_flight` states resident (0 = engine default).  A batch larger than one chunk of that many
+ * states is run with TWO chunks in flight, one stage apart, on two streams the library owns (they fork from
+ * `stream` by an event and join it again before the call returns its last launch: to the caller the call is
+ * ordered on `stream` like any other); the figure returned includes the second set of state buffers.  A
+ * smaller workspace is legal: the engine splits what it gets in two, or keeps one chunk on `stream` alone.
+ * QMLE_NO_CHUNK_OVERLAP=1 (read per call): always the one-stream loop. */
 size_t qmle_workspace_bytes(const qmle_plan *plan, int batch, int meas_type,
                             int n_obs, int states_in_flight);
 
