@@ -81,3 +81,18 @@ def test_complex128_states_in_flight_for_every_measurement_type():
     s10 = 16 << 10
     d = memory.estimate_peak_bytes(10, 32, "density", False, x64=True)
     assert d >= 32 * s10 * 1024 + 32 * s10
+
+
+def test_batches_of_several_chunks_count_two_sets_of_state_buffers():
+    """Round 5: a batch larger than one chunk of state buffers keeps two chunks in flight (two internal streams,
+    qmle_engine.hip), so the engine's workspace holds two sets of buffers -- the model must too, or a batch sized
+    to just fit would be sent whole and fail inside the call."""
+    from qml_essentials_amd import memory as M
+
+    n = 24
+    state = (1 << n) * 8
+    per_chunk = M.IN_FLIGHT_TARGET_BYTES // state
+    one = M.estimate_peak_bytes(n, per_chunk, "expval", n_obs=n)
+    two = M.estimate_peak_bytes(n, per_chunk + 1, "expval", n_obs=n)
+    assert two - one > 0.9 * per_chunk * state          # the second slot
+    assert M.estimate_peak_bytes(n, 4 * per_chunk, "expval", n_obs=n) - two < 0.1 * per_chunk * state  # and no third
