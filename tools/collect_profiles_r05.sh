@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-5 evidence, run on the GPU box (bash tools/collect_profiles_r05.sh [part ...]); parts: stats pmc mw sq legs
-# k1 misc rows bench (default: all).  Everything lands in gpurun_out/profiles_r05/, the files to keep are named r05_*.
+# k1 misc rows ab bench (default: all).  Everything lands in gpurun_out/profiles_r05/, the files to keep are named r05_*.
 set -e
 TAG=r05; export TAG
-PARTS=${*:-stats pmc mw sq legs k1 misc rows bench}
+PARTS=${*:-stats pmc mw sq legs k1 misc rows ab bench}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -113,6 +113,14 @@ if has rows; then
     echo "== host profile of one noisy Model(10, 2) call, 64 parameter sets (compiled call)"
     NP_N=10 NP_L=2 NP_B=64 NP_TOP=12 python3 tools/noise_profile.py 2>&1 | grep -v amdgpu.ids
   } > $OUT/${TAG}_noise_plan.txt
+  cd /tmp
+fi
+if has ab; then
+  echo "[ab] schedule / engine switches against the defaults, per-pass times"
+  cd $R
+  bash tools/top_first_ab.sh > $OUT/${TAG}_top_first_ab.txt 2>&1 || true
+  bash tools/chunk_overlap_ab.sh > $OUT/${TAG}_chunk_overlap_ab.txt 2>&1 || true
+  bash tools/pad_high_ab.sh > $OUT/${TAG}_pad_high_ab.txt 2>&1 || true
   cd /tmp
 fi
 if has bench; then
